@@ -1,0 +1,156 @@
+/*
+ * hnsw_mi355x.h -- C ABI of libhnsw_mi355x.so: the MI355X (gfx950) HNSW search path.
+ *
+ * Drop-in boundary for ONE path of lehy/ocaml-hnsw: batched k-NN search = greedy upper-layer
+ * descent + ef-bounded best-first expansion on layer 0.  The reference has no FFI of its own
+ * (it is 100 % OCaml); each entry point below names the OCaml function whose BODY it replaces
+ * while the OCaml signature stays (see INTEGRATION.md for the ctypes binding):
+ *
+ *   hnsw_index_create        flatten + upload of Ohnsw.Hgraph.t (lib/ohnsw.ml:307-312, iterated
+ *                            with Graph.iter_neighbours :176-180) or Hnsw.Ba.Hgraph.t
+ *                            (lib/hnsw.ml:342-351, fold_layers) plus the vectors (value:
+ *                            lib/ohnsw.ml:842, lib/hnsw.ml:313)
+ *   hnsw_search_batch        Ohnsw.knn_batch_bigarray (lib/ohnsw.ml:877-897)
+ *                            Hnsw.Ba.knn_batch / MakeBatch.knn_batch (lib/hnsw.ml:769-777)
+ *   hnsw_knn                 Ohnsw.knn (lib/ohnsw.ml:859-875), Hnsw.Ba.knn (lib/hnsw.ml:763-767),
+ *                            Hnsw_algo.Knn.knn (lib/hnsw_algo.ml:990-1011)
+ *   hnsw_distance_batch      Ohnsw.distance_l2 / EuclideanBa.distance (lib/ohnsw.ml:899,
+ *                            lib/hnsw.ml:809-815) as timed by bench_dist/bench_dist.ml:22-33
+ *
+ * Plain pointers and sizes only.  All host buffers stay owned by the caller and are not
+ * retained after a call returns (OCaml Bigarrays are not moved by the GC, so they can be passed
+ * for the duration of a call).  One thread at a time per handle.
+ *
+ * Search semantics (identical to the reference's imperative path, with its heap tie order --
+ * which the reference leaves to an un-vendored library -- fixed to the total order
+ * (distance, node id)):
+ *   - descent on layers max_layer..1: Ohnsw.search_one_simple (lib/ohnsw.ml:492-508);
+ *   - layer 0: Ohnsw.search_k (lib/ohnsw.ml:543-588) with W bounded by ef: a neighbour is
+ *     accepted iff |W| < ef or d < max(W).d (strict, :574); neighbours of an expanded node are
+ *     tested in adjacency-row order (:570); the search stops when the nearest unexpanded
+ *     candidate is farther than max(W) (:568);
+ *   - the result is W[0..k), ascending.  (Hnsw.Nearest.nearest_k, lib/hnsw.ml:522-525, returns
+ *     the k FARTHEST of W when ef > k; that defect is not reproduced.)  k > ef is rejected.
+ */
+#ifndef HNSW_MI355X_H
+#define HNSW_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HNSW_ABI_VERSION 1
+
+typedef struct hnsw_index hnsw_index;
+
+/* Error convention: 0 = ok, negative = error; the message is in hnsw_last_error().
+ * The OCaml shim maps BAD_ARG / EMPTY_INDEX / DEGREE_OVERFLOW to Invalid_argument (as
+ * "knn: empty hgraph", lib/ohnsw.ml:862) and the rest to Failure. */
+enum {
+    HNSW_OK = 0,
+    HNSW_ERR_BAD_ARG = -1,
+    HNSW_ERR_EMPTY_INDEX = -2,     /* Invalid_argument "knn: empty hgraph" */
+    HNSW_ERR_DEGREE_OVERFLOW = -3, /* a neighbour list longer than its row: never truncated */
+    HNSW_ERR_NO_DEVICE = -4,
+    HNSW_ERR_HIP = -5,
+    HNSW_ERR_OOM = -6,
+    HNSW_ERR_UNSUPPORTED = -7
+};
+
+enum { HNSW_METRIC_L2 = 0,  /* sqrt(sum (a_i-b_i)^2)                                     */
+       HNSW_METRIC_IP = 1 };/* 1 - <a,b>  (new: the reference has Euclidean only,
+                               benchmark/dataset.ml:6-13; extension point = DISTANCE sig) */
+
+enum { HNSW_FILL_OHNSW = 0, /* missing results: id -1, distance NaN  (lib/ohnsw.ml:880-881) */
+       HNSW_FILL_BA = 1 };  /* missing results: id -1, distance +inf (lib/hnsw.ml:771)      */
+
+/* One upper layer (l >= 1) as a sparse list of the nodes present in it. */
+typedef struct hnsw_layer_desc {
+    int64_t n_nodes;
+    const int64_t *nodes; /* [n_nodes] node ids (id_base-based), any order                  */
+    const int32_t *deg;   /* [n_nodes]                                                      */
+    const int32_t *nbr;   /* [n_nodes][max_degree] ids (id_base-based) in the reference's
+                             iteration order (Neighbours.iter / fold); entries >= deg ignored */
+} hnsw_layer_desc;
+
+typedef struct hnsw_index_desc {
+    const float *vectors; /* [n][row_stride] fp32: a Lacaml.S.mat (dim x n, Fortran layout)  */
+    int64_t n;
+    int32_t d;
+    int64_t row_stride;   /* floats between consecutive vectors (>= d)                       */
+    int32_t metric;       /* HNSW_METRIC_*                                                   */
+    int32_t id_base;      /* 0 for Ohnsw (lib/ohnsw.ml:159), 1 for Hnsw.Ba (lib/hnsw.ml:325) */
+    int32_t max_degree0;  /* row width of nbr0 = Mmax0 = 2M (lib/hnsw.ml:719, ohnsw.ml:818)  */
+    int32_t max_degree;   /* row width of upper rows = Mmax = M                              */
+    int32_t max_layer;    /* number of upper layers                                          */
+    int64_t entry_point;  /* id_base-based; id_base-1 (or any value < id_base) = empty index */
+    const int32_t *deg0;  /* [n]                                                             */
+    const int32_t *nbr0;  /* [n][max_degree0], reference iteration order                     */
+    const hnsw_layer_desc *upper; /* [max_layer]; upper[l-1] describes layer l               */
+} hnsw_index_desc;
+
+typedef struct hnsw_search_params {
+    int32_t ef;   /* ~num_neighbours_search (lib/hnsw.ml:763); Ohnsw: ef == k (ohnsw.ml:859) */
+    int32_t k;    /* ~num_neighbours / ~k                                                    */
+    int32_t fill; /* HNSW_FILL_*                                                             */
+    int32_t reserved;
+} hnsw_search_params;
+
+typedef struct hnsw_index_info {
+    int64_t n;
+    int32_t d, metric, id_base, max_degree0, max_degree, max_layer;
+    int64_t entry_point;
+    int64_t device_bytes;      /* HBM held by the index                                       */
+    int64_t row_stride_bytes;  /* padded vector row on the device                             */
+    int32_t device;
+    int32_t reserved;
+} hnsw_index_info;
+
+int32_t hnsw_abi_version(void);
+const char *hnsw_last_error(void);
+int32_t hnsw_device_count(int32_t *count);
+
+/* Copies vectors and graph to `device` (HBM); validates ids and degrees (never truncates).
+ * An empty graph (no entry point) creates a valid handle whose searches fail with
+ * HNSW_ERR_EMPTY_INDEX, like the reference. */
+int32_t hnsw_index_create(const hnsw_index_desc *desc, int32_t device, hnsw_index **out);
+int32_t hnsw_index_destroy(hnsw_index *idx);
+int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info);
+/* Tuning knobs that never change results: "vt_bits" = log2 entries of the per-query LDS
+ * visited cache (0 = automatic). */
+int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value);
+
+/* Batched search, host buffers.  queries: [nq][q_stride] fp32 (a Lacaml.S.mat d x nq).
+ * out_ids [nq][k] int32 (id_base-based), out_dist [nq][k] fp32, ascending.
+ * out_ndist / out_nhops (optional, [nq]): distance evaluations and expanded candidates on
+ * layer 0 per query -- the unit the reference counts in lib/hnsw.ml:730-751. */
+int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
+                          const hnsw_search_params *params, int32_t *out_ids, float *out_dist,
+                          uint32_t *out_ndist, uint32_t *out_nhops);
+
+/* Same, device buffers, asynchronous on `stream` (a hipStream_t; NULL = default stream).
+ * d_status (optional, [nq] uint32): bit 0 set if the query's tie-overflow list spilled (the
+ * result is then still a valid search result but may differ from the canonical tie order). */
+int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_t nq,
+                                 int64_t q_stride, const hnsw_search_params *params,
+                                 int32_t *d_ids, float *d_dist, uint32_t *d_ndist,
+                                 uint32_t *d_nhops, uint32_t *d_status, void *stream);
+
+/* Single query (Ohnsw.knn / Hnsw.Ba.knn).  *out_count = number of results (<= k). */
+int32_t hnsw_knn(hnsw_index *idx, const float *query, const hnsw_search_params *params,
+                 int32_t *out_ids, float *out_dist, int32_t *out_count);
+
+/* Gathered distances: out[q][j] = distance(query q, vector ids[q][j]); ids id_base-based.
+ * Counterpart of bench_dist/bench_dist.ml (one distance call per pair). */
+int32_t hnsw_distance_batch(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
+                            const int32_t *ids, int32_t m, float *out);
+int32_t hnsw_distance_batch_device(hnsw_index *idx, const float *d_queries, int64_t nq,
+                                   int64_t q_stride, const int32_t *d_ids, int32_t m,
+                                   float *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNSW_MI355X_H */

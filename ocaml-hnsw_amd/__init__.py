@@ -1,0 +1,272 @@
+"""ocaml-hnsw_amd -- MI355X-native HNSW search behind ocaml-hnsw's own API surface.
+
+Host-side mirror (Python, over the C ABI of include/hnsw_mi355x.h) of the reference modules whose
+search bodies move to the GPU:
+
+    Ohnsw.knn / Ohnsw.knn_batch_bigarray / Ohnsw.distance_l2      lib/ohnsw.ml:859-899
+    Ba.knn / Ba.knn_batch (= Hnsw.Ba, MakeBatch(EuclideanBa))     lib/hnsw.ml:763-777, 817-819
+
+Same names, argument meaning and error behaviour (Invalid_argument -> InvalidArgument,
+Failure -> Failure).  The OCaml graph builder stays OCaml: this side takes the flattened graph
+(`Hgraph`) that the OCaml shim produces.  There is no CPU path: every compute call goes to
+libhnsw_mi355x.so and fails loudly if the library or a device is missing.
+"""
+import ctypes as _C
+import os as _os
+
+import numpy as _np
+
+_PKG_DIR = _os.path.dirname(_os.path.abspath(__file__)) if "__file__" in globals() and \
+    _os.path.basename(_os.path.dirname(_os.path.abspath(__file__))) == "ocaml-hnsw_amd" else \
+    _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "ocaml-hnsw_amd")
+LIB_PATH = _os.path.join(_PKG_DIR, "libhnsw_mi355x.so")
+
+OK, ERR_BAD_ARG, ERR_EMPTY_INDEX, ERR_DEGREE_OVERFLOW = 0, -1, -2, -3
+ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = -4, -5, -6, -7
+METRIC_L2, METRIC_IP = 0, 1
+FILL_OHNSW, FILL_BA = 0, 1
+
+# every symbol include/hnsw_mi355x.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "hnsw_abi_version", "hnsw_last_error", "hnsw_device_count", "hnsw_index_create",
+    "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_search_batch",
+    "hnsw_search_batch_device", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
+]
+
+
+class InvalidArgument(ValueError):
+    """OCaml Invalid_argument (e.g. "knn: empty hgraph", lib/ohnsw.ml:862)."""
+
+
+class Failure(RuntimeError):
+    """OCaml Failure: device / runtime errors."""
+
+
+class _LayerDesc(_C.Structure):
+    _fields_ = [("n_nodes", _C.c_int64), ("nodes", _C.c_void_p), ("deg", _C.c_void_p),
+                ("nbr", _C.c_void_p)]
+
+
+class _IndexDesc(_C.Structure):
+    _fields_ = [("vectors", _C.c_void_p), ("n", _C.c_int64), ("d", _C.c_int32),
+                ("row_stride", _C.c_int64), ("metric", _C.c_int32), ("id_base", _C.c_int32),
+                ("max_degree0", _C.c_int32), ("max_degree", _C.c_int32), ("max_layer", _C.c_int32),
+                ("entry_point", _C.c_int64), ("deg0", _C.c_void_p), ("nbr0", _C.c_void_p),
+                ("upper", _C.c_void_p)]
+
+
+class _SearchParams(_C.Structure):
+    _fields_ = [("ef", _C.c_int32), ("k", _C.c_int32), ("fill", _C.c_int32), ("reserved", _C.c_int32)]
+
+
+class IndexInfo(_C.Structure):
+    _fields_ = [("n", _C.c_int64), ("d", _C.c_int32), ("metric", _C.c_int32), ("id_base", _C.c_int32),
+                ("max_degree0", _C.c_int32), ("max_degree", _C.c_int32), ("max_layer", _C.c_int32),
+                ("entry_point", _C.c_int64), ("device_bytes", _C.c_int64),
+                ("row_stride_bytes", _C.c_int64), ("device", _C.c_int32), ("reserved", _C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree libhnsw_mi355x.so (built by build.py / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _os.path.exists(LIB_PATH):
+        raise Failure("%s is missing: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950); "
+                      "there is no CPU fallback" % LIB_PATH)
+    L = _C.CDLL(LIB_PATH)
+    vp, i32, i64 = _C.c_void_p, _C.c_int32, _C.c_int64
+    L.hnsw_abi_version.restype = i32
+    L.hnsw_last_error.restype = _C.c_char_p
+    L.hnsw_device_count.argtypes = [vp]
+    L.hnsw_index_create.argtypes = [vp, i32, vp]
+    L.hnsw_index_destroy.argtypes = [vp]
+    L.hnsw_index_get_info.argtypes = [vp, vp]
+    L.hnsw_index_set_option.argtypes = [vp, _C.c_char_p, i64]
+    L.hnsw_search_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp]
+    L.hnsw_search_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.hnsw_knn.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.hnsw_distance_batch.argtypes = [vp, vp, i64, i64, vp, i32, vp]
+    L.hnsw_distance_batch_device.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp]
+    for f in ("hnsw_device_count", "hnsw_index_create", "hnsw_index_destroy", "hnsw_index_get_info",
+              "hnsw_index_set_option", "hnsw_search_batch", "hnsw_search_batch_device", "hnsw_knn",
+              "hnsw_distance_batch", "hnsw_distance_batch_device"):
+        getattr(L, f).restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc == OK:
+        return
+    msg = load().hnsw_last_error().decode()
+    if rc in (ERR_BAD_ARG, ERR_EMPTY_INDEX, ERR_DEGREE_OVERFLOW):
+        raise InvalidArgument(msg)
+    raise Failure("[%d] %s" % (rc, msg))
+
+
+def device_count():
+    c = _C.c_int32(0)
+    rc = load().hnsw_device_count(_C.byref(c))
+    return c.value if rc == OK else 0
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_C.c_void_p)
+
+
+class Hgraph:
+    """The flattened form of Ohnsw.Hgraph.t (lib/ohnsw.ml:307-312) / Hnsw.Ba.Hgraph.t
+    (lib/hnsw.ml:342-348) that crosses the C ABI: vectors + per-layer neighbour rows in the
+    reference's iteration order, ids `id_base`-based (0 for Ohnsw, 1 for Hnsw.Ba).
+
+    vectors [n][d] fp32; deg0 [n]; nbr0 [n][max_degree0]; upper = list of (nodes, deg, nbr) for
+    layers 1..max_layer; entry_point id_base-based or None (empty hgraph)."""
+
+    def __init__(self, vectors, deg0, nbr0, upper=(), entry_point=None, id_base=0,
+                 max_degree=None, metric=METRIC_L2):
+        self.vectors = _np.ascontiguousarray(vectors, dtype=_np.float32)
+        if self.vectors.ndim != 2:
+            raise InvalidArgument("vectors must be [n][d]")
+        self.n, self.d = self.vectors.shape
+        self.deg0 = _np.ascontiguousarray(deg0, dtype=_np.int32)
+        self.nbr0 = _np.ascontiguousarray(nbr0, dtype=_np.int32)
+        if self.nbr0.ndim != 2 or self.nbr0.shape[0] != self.n or self.deg0.shape != (self.n,):
+            raise InvalidArgument("deg0 / nbr0 shapes do not match n")
+        self.max_degree0 = int(self.nbr0.shape[1])
+        self.upper = []
+        for (nodes, deg, nbr) in upper:
+            nodes = _np.ascontiguousarray(nodes, dtype=_np.int64)
+            deg = _np.ascontiguousarray(deg, dtype=_np.int32)
+            nbr = _np.ascontiguousarray(nbr, dtype=_np.int32).reshape(len(nodes), -1)
+            self.upper.append((nodes, deg, nbr))
+        self.max_layer = len(self.upper)
+        self.max_degree = int(max_degree if max_degree is not None else
+                              (self.upper[0][2].shape[1] if self.upper else max(1, self.max_degree0 // 2)))
+        self.id_base = int(id_base)
+        self.entry_point = None if entry_point is None or entry_point < id_base else int(entry_point)
+        self.metric = int(metric)
+        self._index = None
+        self._device = None
+
+    def to_device(self, device=0):
+        """Upload to HBM (hnsw_index_create).  Idempotent per device."""
+        if self._index is not None and self._device == device:
+            return self
+        self.release()
+        L = load()
+        nl = self.max_layer
+        layers = (_LayerDesc * max(nl, 1))()
+        for i, (nodes, deg, nbr) in enumerate(self.upper):
+            if nbr.shape[1] != self.max_degree and len(nodes):
+                raise InvalidArgument("upper rows must be max_degree wide")
+            layers[i].n_nodes = len(nodes)
+            layers[i].nodes, layers[i].deg, layers[i].nbr = nodes.ctypes.data, deg.ctypes.data, nbr.ctypes.data
+        d = _IndexDesc()
+        d.vectors = self.vectors.ctypes.data
+        d.n, d.d, d.row_stride = self.n, self.d, self.vectors.shape[1]
+        d.metric, d.id_base = self.metric, self.id_base
+        d.max_degree0, d.max_degree, d.max_layer = self.max_degree0, self.max_degree, nl
+        d.entry_point = self.id_base - 1 if self.entry_point is None else self.entry_point
+        d.deg0, d.nbr0 = self.deg0.ctypes.data, self.nbr0.ctypes.data
+        d.upper = _C.cast(layers, _C.c_void_p)
+        h = _C.c_void_p()
+        _check(L.hnsw_index_create(_C.byref(d), device, _C.byref(h)))
+        self._index, self._device = h, device
+        return self
+
+    @property
+    def handle(self):
+        if self._index is None:
+            self.to_device(0)
+        return self._index
+
+    def info(self):
+        inf = IndexInfo()
+        _check(load().hnsw_index_get_info(self.handle, _C.byref(inf)))
+        return inf
+
+    def set_option(self, name, value):
+        _check(load().hnsw_index_set_option(self.handle, name.encode(), int(value)))
+
+    def release(self):
+        if self._index is not None:
+            load().hnsw_index_destroy(self._index)
+            self._index = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def _search(hgraph, batch, ef, k, fill, counters=False):
+    Q = _np.ascontiguousarray(batch, dtype=_np.float32)
+    if Q.ndim != 2 or (Q.shape[0] and Q.shape[1] != hgraph.d):
+        raise InvalidArgument("batch must be [nq][d]")
+    nq = Q.shape[0]
+    ids = _np.empty((nq, k), _np.int32)
+    dist = _np.empty((nq, k), _np.float32)
+    nd = _np.zeros(nq, _np.uint32) if counters else None
+    nh = _np.zeros(nq, _np.uint32) if counters else None
+    p = _SearchParams(ef, k, fill, 0)
+    _check(load().hnsw_search_batch(hgraph.handle, _ptr(Q), nq, hgraph.d, _C.byref(p), _ptr(ids),
+                                    _ptr(dist), _ptr(nd), _ptr(nh)))
+    return (ids, dist, nd, nh) if counters else (ids, dist)
+
+
+def search_batch_device(hgraph, d_queries, nq, q_stride, ef, k, d_ids, d_dist, d_ndist=0, d_nhops=0,
+                        d_status=0, stream=0, fill=FILL_OHNSW):
+    """Asynchronous search on device pointers (ints), on HIP stream `stream` (int handle)."""
+    p = _SearchParams(ef, k, fill, 0)
+    _check(load().hnsw_search_batch_device(hgraph.handle, d_queries, nq, q_stride, _C.byref(p), d_ids,
+                                           d_dist, d_ndist or None, d_nhops or None,
+                                           d_status or None, stream or None))
+
+
+class Ohnsw:
+    """lib/ohnsw.ml -- the imperative API, 0-based ids, ef == k unless `ef` is given."""
+
+    @staticmethod
+    def knn(hgraph, k, target, ef=None):
+        """Ohnsw.knn hgraph visited ~k target (lib/ohnsw.ml:859-875) -> [(node, distance)] ascending
+        (the reference returns a MinQueue popped in that order, :886-893)."""
+        ids, dist = _search(hgraph, _np.asarray(target, _np.float32)[None, :], k if ef is None else ef, k, FILL_OHNSW)
+        return [(int(i), float(d)) for i, d in zip(ids[0], dist[0]) if i >= hgraph.id_base]
+
+    @staticmethod
+    def knn_batch_bigarray(hgraph, k, batch, ef=None, counters=False):
+        """Ohnsw.knn_batch_bigarray hgraph ~k batch (lib/ohnsw.ml:877-897) -> (ids, distances):
+        ids [nq][k] (-1 where fewer than k were found), distances [nq][k] fp32 (NaN there)."""
+        return _search(hgraph, batch, k if ef is None else ef, k, FILL_OHNSW, counters)
+
+    @staticmethod
+    def distance_l2(hgraph, queries, ids):
+        """Batched Ohnsw.distance_l2 (lib/ohnsw.ml:899): out[q][j] = distance(queries[q], value ids[q][j])."""
+        Q = _np.ascontiguousarray(queries, dtype=_np.float32)
+        I = _np.ascontiguousarray(ids, dtype=_np.int32)
+        out = _np.empty(I.shape, _np.float32)
+        _check(load().hnsw_distance_batch(hgraph.handle, _ptr(Q), Q.shape[0], Q.shape[1], _ptr(I),
+                                          I.shape[1], _ptr(out)))
+        return out
+
+
+class Ba:
+    """Hnsw.Ba = MakeBatch(EuclideanBa) (lib/hnsw.ml:729-778, 817-819): 1-based ids, separate
+    ~num_neighbours_search (ef) and ~num_neighbours (k)."""
+
+    @staticmethod
+    def knn(hgraph, point, num_neighbours_search, num_neighbours):
+        """-> [{node; distance_to_target}] nearest first (lib/hnsw.ml:763-767)."""
+        ids, dist = _search(hgraph, _np.asarray(point, _np.float32)[None, :], num_neighbours_search,
+                            num_neighbours, FILL_BA)
+        return [(int(i), float(d)) for i, d in zip(ids[0], dist[0]) if i >= hgraph.id_base]
+
+    @staticmethod
+    def knn_batch(hgraph, batch, num_neighbours_search, num_neighbours):
+        """-> distances [nq][k] fp32, +inf where fewer than k were found (lib/hnsw.ml:769-777)."""
+        return _search(hgraph, batch, num_neighbours_search, num_neighbours, FILL_BA)[1]

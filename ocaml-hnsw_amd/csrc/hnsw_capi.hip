@@ -1,0 +1,413 @@
+// hnsw_capi.hip -- host side of libhnsw_mi355x.so: the C ABI of include/hnsw_mi355x.h.
+//
+// Flattens the reference's graph containers (Ohnsw.Hgraph.t lib/ohnsw.ml:307-312 /
+// Hnsw.Ba.Hgraph.t lib/hnsw.ml:342-348, as handed over by the OCaml shim) into HBM-resident
+// tables and launches the gfx950 kernels of hnsw_device.hip.h.  No CPU fallback: without a
+// usable device every compute entry point fails with HNSW_ERR_NO_DEVICE.
+#include "../../include/hnsw_mi355x.h"
+#include "hnsw_device.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using hnsw_dev::IndexView;
+using hnsw_dev::SearchArgs;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(e__ == hipErrorOutOfMemory ? HNSW_ERR_OOM : HNSW_ERR_HIP,            \
+                        "%s failed: %s", #expr, hipGetErrorString(e__));                     \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return HNSW_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        HIP_TRY(hipMalloc(&p, bytes));
+        cap = bytes;
+        return HNSW_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+int env_int(const char *name, int dflt) {
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+} // namespace
+
+struct hnsw_index {
+    int device = -1;
+    IndexView iv{};
+    hnsw_index_info info{};
+    void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr;
+    DevBuf sQ, sIds, sDist, sNd, sNh, sSt; // scratch for the host-buffer entry points
+    int vt_bits_override = 0;
+};
+
+// ---- kernel dispatch ---------------------------------------------------------------------------
+namespace {
+
+template <int NCH, int RB, int NSLOT, int METRIC>
+hipError_t launch_search(const IndexView &iv, const SearchArgs &a, hipStream_t st) {
+    const size_t lds = ((size_t)(1u << a.vt_bits) + 128 + hnsw_dev::OVF_CAP) * sizeof(uint32_t);
+    hipLaunchKernelGGL((hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, METRIC>), dim3((unsigned)a.nq),
+                       dim3(64), lds, st, iv, a);
+    return hipGetLastError();
+}
+
+template <int NCH, int RB, int METRIC>
+hipError_t dispatch_slot(int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st) {
+    switch (nslot) {
+    case 1: return launch_search<NCH, RB, 1, METRIC>(iv, a, st);
+    case 2: return launch_search<NCH, RB, 2, METRIC>(iv, a, st);
+    case 4: return launch_search<NCH, RB, 4, METRIC>(iv, a, st);
+    case 8: return launch_search<NCH, RB, 8, METRIC>(iv, a, st);
+    default: return launch_search<NCH, RB, 16, METRIC>(iv, a, st);
+    }
+}
+
+template <int METRIC>
+hipError_t dispatch_nch(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st) {
+    switch (nch) {
+    case 1: return dispatch_slot<1, 8, METRIC>(nslot, iv, a, st);
+    case 2: return dispatch_slot<2, 8, METRIC>(nslot, iv, a, st);
+    case 4: return dispatch_slot<4, 4, METRIC>(nslot, iv, a, st);
+    case 8: return dispatch_slot<8, 2, METRIC>(nslot, iv, a, st);
+    default: return dispatch_slot<16, 1, METRIC>(nslot, iv, a, st);
+    }
+}
+
+int pick_nch(int nchunks) {
+    const int per_lane = (nchunks + 15) / 16;
+    for (int c : {1, 2, 4, 8, 16}) if (per_lane <= c) return c;
+    return 0;
+}
+int pick_nslot(int ef) {
+    for (int s : {1, 2, 4, 8, 16}) if (ef <= 64 * s) return s;
+    return 0;
+}
+
+template <int METRIC>
+hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq,
+                         const int32_t *ids, int32_t m, float *out, hipStream_t st) {
+    const unsigned gy = (unsigned)std::max(1, std::min(64, (m + 3) / 4));
+    dim3 grid((unsigned)nq, gy), block(64);
+    switch (nch) {
+    case 1: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<1, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
+    case 2: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<2, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
+    case 4: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<4, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
+    case 8: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<8, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
+    default: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
+    }
+    return hipGetLastError();
+}
+
+int check_params(const hnsw_index *idx, const hnsw_search_params *p) {
+    if (!idx) return fail(HNSW_ERR_BAD_ARG, "null index");
+    if (!p) return fail(HNSW_ERR_BAD_ARG, "null params");
+    if (p->ef < 1 || p->k < 1) return fail(HNSW_ERR_BAD_ARG, "ef and k must be >= 1 (ef=%d k=%d)", p->ef, p->k);
+    if (p->k > p->ef)
+        return fail(HNSW_ERR_BAD_ARG, "k=%d > ef=%d: the reference silently misbehaves here "
+                    "(lib/hnsw_algo.ml:257-258); rejected", p->k, p->ef);
+    if (p->ef > 1024) return fail(HNSW_ERR_UNSUPPORTED, "ef=%d > 1024 not supported", p->ef);
+    if (p->fill != HNSW_FILL_OHNSW && p->fill != HNSW_FILL_BA) return fail(HNSW_ERR_BAD_ARG, "bad fill %d", p->fill);
+    if (idx->iv.entry_point < 0) return fail(HNSW_ERR_EMPTY_INDEX, "knn: empty hgraph");
+    return HNSW_OK;
+}
+
+int default_vt_bits(const hnsw_index *idx, int ef) {
+    int b = idx->vt_bits_override ? idx->vt_bits_override : env_int("HNSW_VT_BITS", 0);
+    if (b <= 0) {
+        // ~25 evaluations per unit of ef; a cache of about half of them keeps the
+        // re-evaluation rate low at 8 KiB/wave for ef = 128
+        b = 8;
+        while ((1 << b) < 16 * ef && b < 13) ++b;
+    }
+    return std::max(4, std::min(14, b));
+}
+
+} // namespace
+
+// ---- ABI ---------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t hnsw_abi_version(void) { return HNSW_ABI_VERSION; }
+const char *hnsw_last_error(void) { return g_last_error.c_str(); }
+
+int32_t hnsw_device_count(int32_t *count) {
+    if (!count) return fail(HNSW_ERR_BAD_ARG, "null count");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return fail(HNSW_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e)); }
+    *count = c;
+    return HNSW_OK;
+}
+
+int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index **out) {
+    if (!d || !out) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    if (d->n < 0 || d->n > 0x7FFFFFF0LL) return fail(HNSW_ERR_BAD_ARG, "n=%lld out of range", (long long)d->n);
+    if (d->d < 1) return fail(HNSW_ERR_BAD_ARG, "d=%d", d->d);
+    if (d->row_stride < d->d) return fail(HNSW_ERR_BAD_ARG, "row_stride < d");
+    if (d->metric != HNSW_METRIC_L2 && d->metric != HNSW_METRIC_IP) return fail(HNSW_ERR_BAD_ARG, "bad metric %d", d->metric);
+    if (d->max_degree0 < 1 || d->max_degree0 > 64) return fail(HNSW_ERR_UNSUPPORTED, "max_degree0=%d must be in 1..64", d->max_degree0);
+    if (d->max_layer < 0 || d->max_layer > 255) return fail(HNSW_ERR_BAD_ARG, "max_layer=%d", d->max_layer);
+    if (d->max_layer > 0 && (d->max_degree < 1 || d->max_degree > 64)) return fail(HNSW_ERR_UNSUPPORTED, "max_degree=%d must be in 1..64", d->max_degree);
+    if (d->n > 0 && (!d->vectors || !d->deg0 || !d->nbr0)) return fail(HNSW_ERR_BAD_ARG, "null vectors/deg0/nbr0");
+    if (d->max_layer > 0 && !d->upper) return fail(HNSW_ERR_BAD_ARG, "null upper");
+    const int nchunks = (d->d + 3) / 4;
+    if (pick_nch(nchunks) == 0) return fail(HNSW_ERR_UNSUPPORTED, "d=%d > 1024 not supported", d->d);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(HNSW_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)"); }
+    if (device < 0 || device >= ndev) return fail(HNSW_ERR_BAD_ARG, "device %d out of range (have %d)", device, ndev);
+
+    const int64_t n = d->n;
+    const int32_t base = d->id_base;
+    const int S0 = d->max_degree0, SU = d->max_layer > 0 ? d->max_degree : 1;
+    int64_t ep = d->entry_point - base;
+    if (n == 0 || ep < 0) ep = -1;
+    if (ep >= n) return fail(HNSW_ERR_BAD_ARG, "Hgraph.set_entry_point: invalid node"); /* lib/ohnsw.ml:343 */
+
+    // ---- layer 0: validate, rebase to 0, pad with -1 ----
+    std::vector<int32_t> nbr0((size_t)n * S0, -1);
+    for (int64_t i = 0; i < n; ++i) {
+        const int dg = d->deg0[i];
+        if (dg < 0) return fail(HNSW_ERR_BAD_ARG, "deg0[%lld] < 0", (long long)i);
+        if (dg > S0) return fail(HNSW_ERR_DEGREE_OVERFLOW, "node %lld has %d layer-0 neighbours > max_degree0=%d", (long long)i + base, dg, S0);
+        for (int j = 0; j < dg; ++j) {
+            const int64_t v = (int64_t)d->nbr0[i * S0 + j] - base;
+            if (v < 0 || v >= n) return fail(HNSW_ERR_BAD_ARG, "Vector.get: neighbour id %lld of node %lld out of range", (long long)v + base, (long long)i + base); /* lib/ohnsw.ml:25 */
+            nbr0[(size_t)i * S0 + j] = (int32_t)v;
+        }
+    }
+    // ---- upper layers: per node, rows for layers 1..lvl(node), contiguous ----
+    std::vector<uint8_t> lvl((size_t)std::max<int64_t>(n, 1), 0);
+    for (int l = 1; l <= d->max_layer; ++l) {
+        const hnsw_layer_desc &L = d->upper[l - 1];
+        if (L.n_nodes < 0 || (L.n_nodes > 0 && (!L.nodes || !L.deg || !L.nbr))) return fail(HNSW_ERR_BAD_ARG, "layer %d: null arrays", l);
+        for (int64_t s = 0; s < L.n_nodes; ++s) {
+            const int64_t v = L.nodes[s] - base;
+            if (v < 0 || v >= n) return fail(HNSW_ERR_BAD_ARG, "layer %d: node id out of range", l);
+            lvl[(size_t)v] = (uint8_t)std::max<int>(lvl[(size_t)v], l);
+        }
+    }
+    std::vector<int32_t> off((size_t)std::max<int64_t>(n, 1), -1);
+    int64_t rowsU = 0;
+    for (int64_t i = 0; i < n; ++i) if (lvl[(size_t)i]) { off[(size_t)i] = (int32_t)rowsU; rowsU += lvl[(size_t)i]; }
+    if (rowsU > 0x7FFFFFF0LL) return fail(HNSW_ERR_UNSUPPORTED, "too many upper rows");
+    std::vector<int32_t> nbrU((size_t)std::max<int64_t>(rowsU, 1) * SU, -1);
+    for (int l = 1; l <= d->max_layer; ++l) {
+        const hnsw_layer_desc &L = d->upper[l - 1];
+        for (int64_t s = 0; s < L.n_nodes; ++s) {
+            const int64_t v = L.nodes[s] - base;
+            const int dg = L.deg[s];
+            if (dg < 0) return fail(HNSW_ERR_BAD_ARG, "layer %d: negative degree", l);
+            if (dg > SU) return fail(HNSW_ERR_DEGREE_OVERFLOW, "node %lld has %d neighbours on layer %d > max_degree=%d", (long long)v + base, dg, l, SU);
+            int32_t *row = &nbrU[((size_t)off[(size_t)v] + (l - 1)) * SU];
+            for (int j = 0; j < dg; ++j) {
+                const int64_t u = (int64_t)L.nbr[s * SU + j] - base;
+                if (u < 0 || u >= n) return fail(HNSW_ERR_BAD_ARG, "layer %d: neighbour id out of range", l);
+                row[j] = (int32_t)u;
+            }
+        }
+    }
+
+    HIP_TRY(hipSetDevice(device));
+    hnsw_index *idx = new hnsw_index();
+    idx->device = device;
+    auto bail = [&](int code) { hnsw_index_destroy(idx); return code; };
+
+    // ---- vectors: rows zero-padded to a multiple of 64 B so every float4 chunk is in bounds ----
+    const int64_t stride = ((int64_t)d->d + 15) / 16 * 16;
+    const size_t xbytes = (size_t)std::max<int64_t>(n, 1) * stride * sizeof(float);
+    if (hipMalloc(&idx->dX, xbytes) != hipSuccess) { (void)hipGetLastError(); return bail(fail(HNSW_ERR_OOM, "hipMalloc(%zu) for vectors failed", xbytes)); }
+    if (n > 0) {
+        if (stride == d->row_stride) {
+            if (hipMemcpy(idx->dX, d->vectors, xbytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(HNSW_ERR_HIP, "vector upload failed"));
+        } else {
+            const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / (stride * 4));
+            std::vector<float> stage((size_t)chunk_rows * stride);
+            for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+                const int64_t nr = std::min(chunk_rows, n - r0);
+                std::fill(stage.begin(), stage.begin() + (size_t)nr * stride, 0.0f);
+                for (int64_t i = 0; i < nr; ++i)
+                    memcpy(&stage[(size_t)i * stride], d->vectors + (r0 + i) * d->row_stride, sizeof(float) * (size_t)d->d);
+                if (hipMemcpy((float *)idx->dX + r0 * stride, stage.data(), (size_t)nr * stride * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    return bail(fail(HNSW_ERR_HIP, "vector upload failed"));
+            }
+        }
+    }
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> bool {
+        if (hipMalloc(dst, std::max<size_t>(bytes, 16)) != hipSuccess) return false;
+        return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!upload(&idx->dNbr0, nbr0.data(), nbr0.size() * 4) || !upload(&idx->dNbrU, nbrU.data(), nbrU.size() * 4) ||
+        !upload(&idx->dOff, off.data(), off.size() * 4) || !upload(&idx->dLvl, lvl.data(), lvl.size())) {
+        (void)hipGetLastError();
+        return bail(fail(HNSW_ERR_OOM, "graph upload failed"));
+    }
+
+    IndexView &iv = idx->iv;
+    iv.X = (const float *)idx->dX; iv.stride = stride; iv.n = n; iv.d = d->d; iv.nchunks = nchunks;
+    iv.nbr0 = (const int32_t *)idx->dNbr0; iv.S0 = S0; iv.SU = SU;
+    iv.nbrU = (const int32_t *)idx->dNbrU; iv.upper_off = (const int32_t *)idx->dOff;
+    iv.upper_lvl = (const uint8_t *)idx->dLvl;
+    iv.max_layer = d->max_layer; iv.entry_point = (int32_t)ep; iv.id_base = base;
+
+    hnsw_index_info &inf = idx->info;
+    inf.n = n; inf.d = d->d; inf.metric = d->metric; inf.id_base = base; inf.max_degree0 = S0;
+    inf.max_degree = d->max_degree; inf.max_layer = d->max_layer; inf.entry_point = ep < 0 ? base - 1 : ep + base;
+    inf.device_bytes = (int64_t)(xbytes + nbr0.size() * 4 + nbrU.size() * 4 + off.size() * 4 + lvl.size());
+    inf.row_stride_bytes = stride * 4; inf.device = device;
+    *out = idx;
+    return HNSW_OK;
+}
+
+int32_t hnsw_index_destroy(hnsw_index *idx) {
+    if (!idx) return HNSW_OK;
+    if (idx->device >= 0) (void)hipSetDevice(idx->device);
+    for (void *p : {idx->dX, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl}) if (p) (void)hipFree(p);
+    idx->sQ.release(); idx->sIds.release(); idx->sDist.release(); idx->sNd.release(); idx->sNh.release(); idx->sSt.release();
+    delete idx;
+    return HNSW_OK;
+}
+
+int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info) {
+    if (!idx || !info) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    *info = idx->info;
+    return HNSW_OK;
+}
+
+int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) {
+    if (!idx || !name) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    if (!strcmp(name, "vt_bits")) { idx->vt_bits_override = (int)value; return HNSW_OK; }
+    return fail(HNSW_ERR_BAD_ARG, "unknown option %s", name);
+}
+
+int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
+                                 const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
+                                 uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, void *stream) {
+    int rc = check_params(idx, params);
+    if (rc) return rc;
+    if (nq < 0 || nq > 0x7FFFFFFFLL) return fail(HNSW_ERR_BAD_ARG, "nq out of range");
+    if (nq == 0) return HNSW_OK;
+    if (!d_queries || !d_ids || !d_dist) return fail(HNSW_ERR_BAD_ARG, "null buffer");
+    if (q_stride < idx->iv.d) return fail(HNSW_ERR_BAD_ARG, "q_stride < d");
+    HIP_TRY(hipSetDevice(idx->device));
+    SearchArgs a{};
+    a.Q = d_queries; a.q_stride = q_stride; a.nq = nq; a.ef = params->ef; a.k = params->k; a.fill = params->fill;
+    a.vt_bits = default_vt_bits(idx, params->ef);
+    a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_ndist; a.out_nhops = d_nhops; a.out_status = d_status;
+    const int nch = pick_nch(idx->iv.nchunks), nslot = pick_nslot(params->ef);
+    hipError_t e = idx->info.metric == HNSW_METRIC_L2
+                       ? dispatch_nch<0>(nch, nslot, idx->iv, a, (hipStream_t)stream)
+                       : dispatch_nch<1>(nch, nslot, idx->iv, a, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(HNSW_ERR_HIP, "search kernel launch failed: %s", hipGetErrorString(e));
+    return HNSW_OK;
+}
+
+int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
+                          const hnsw_search_params *params, int32_t *out_ids, float *out_dist,
+                          uint32_t *out_ndist, uint32_t *out_nhops) {
+    int rc = check_params(idx, params);
+    if (rc) return rc;
+    if (nq == 0) return HNSW_OK;
+    if (nq < 0 || !queries || !out_ids || !out_dist) return fail(HNSW_ERR_BAD_ARG, "bad buffers");
+    if (q_stride < idx->iv.d) return fail(HNSW_ERR_BAD_ARG, "q_stride < d");
+    HIP_TRY(hipSetDevice(idx->device));
+    const int k = params->k;
+    const size_t qbytes = ((size_t)(nq - 1) * q_stride + idx->iv.d) * sizeof(float);
+    if ((rc = idx->sQ.ensure(qbytes)) || (rc = idx->sIds.ensure((size_t)nq * k * 4)) ||
+        (rc = idx->sDist.ensure((size_t)nq * k * 4)) || (rc = idx->sNd.ensure((size_t)nq * 4)) ||
+        (rc = idx->sNh.ensure((size_t)nq * 4)) || (rc = idx->sSt.ensure((size_t)nq * 4)))
+        return rc;
+    HIP_TRY(hipMemcpy(idx->sQ.p, queries, qbytes, hipMemcpyHostToDevice));
+    rc = hnsw_search_batch_device(idx, (const float *)idx->sQ.p, nq, q_stride, params, (int32_t *)idx->sIds.p,
+                                  (float *)idx->sDist.p, (uint32_t *)idx->sNd.p, (uint32_t *)idx->sNh.p,
+                                  (uint32_t *)idx->sSt.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_ids, idx->sIds.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_dist, idx->sDist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    if (out_ndist) HIP_TRY(hipMemcpy(out_ndist, idx->sNd.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    if (out_nhops) HIP_TRY(hipMemcpy(out_nhops, idx->sNh.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    return HNSW_OK;
+}
+
+int32_t hnsw_knn(hnsw_index *idx, const float *query, const hnsw_search_params *params,
+                 int32_t *out_ids, float *out_dist, int32_t *out_count) {
+    if (!idx || !query) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    int rc = hnsw_search_batch(idx, query, 1, idx->iv.d, params, out_ids, out_dist, nullptr, nullptr);
+    if (rc) return rc;
+    if (out_count) {
+        int c = 0;
+        while (c < params->k && out_ids[c] >= idx->iv.id_base) ++c;
+        *out_count = c;
+    }
+    return HNSW_OK;
+}
+
+int32_t hnsw_distance_batch_device(hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
+                                   const int32_t *d_ids, int32_t m, float *d_out, void *stream) {
+    if (!idx) return fail(HNSW_ERR_BAD_ARG, "null index");
+    if (nq == 0 || m == 0) return HNSW_OK;
+    if (nq < 0 || m < 0 || !d_queries || !d_ids || !d_out) return fail(HNSW_ERR_BAD_ARG, "bad buffers");
+    if (q_stride < idx->iv.d) return fail(HNSW_ERR_BAD_ARG, "q_stride < d");
+    HIP_TRY(hipSetDevice(idx->device));
+    const int nch = pick_nch(idx->iv.nchunks);
+    hipError_t e = idx->info.metric == HNSW_METRIC_L2
+                       ? dispatch_dist<0>(nch, idx->iv, d_queries, q_stride, nq, d_ids, m, d_out, (hipStream_t)stream)
+                       : dispatch_dist<1>(nch, idx->iv, d_queries, q_stride, nq, d_ids, m, d_out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(HNSW_ERR_HIP, "distance kernel launch failed: %s", hipGetErrorString(e));
+    return HNSW_OK;
+}
+
+int32_t hnsw_distance_batch(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
+                            const int32_t *ids, int32_t m, float *out) {
+    if (!idx) return fail(HNSW_ERR_BAD_ARG, "null index");
+    if (nq == 0 || m == 0) return HNSW_OK;
+    if (nq < 0 || m < 0 || !queries || !ids || !out) return fail(HNSW_ERR_BAD_ARG, "bad buffers");
+    for (int64_t i = 0; i < nq * m; ++i) {
+        const int64_t v = (int64_t)ids[i] - idx->iv.id_base;
+        if (v < 0 || v >= idx->iv.n) return fail(HNSW_ERR_BAD_ARG, "Vector.get: id out of range");
+    }
+    HIP_TRY(hipSetDevice(idx->device));
+    int rc;
+    const size_t qbytes = ((size_t)(nq - 1) * q_stride + idx->iv.d) * sizeof(float);
+    if ((rc = idx->sQ.ensure(qbytes)) || (rc = idx->sIds.ensure((size_t)nq * m * 4)) || (rc = idx->sDist.ensure((size_t)nq * m * 4))) return rc;
+    HIP_TRY(hipMemcpy(idx->sQ.p, queries, qbytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(idx->sIds.p, ids, (size_t)nq * m * 4, hipMemcpyHostToDevice));
+    rc = hnsw_distance_batch_device(idx, (const float *)idx->sQ.p, nq, q_stride, (const int32_t *)idx->sIds.p, m, (float *)idx->sDist.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, idx->sDist.p, (size_t)nq * m * 4, hipMemcpyDeviceToHost));
+    return HNSW_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,428 @@
+// hnsw_device.hip.h -- gfx950 device code of the HNSW search path (one wavefront per query).
+//
+// Replaces the bodies of Ohnsw.search_one_simple / search_k / knn (lib/ohnsw.ml:492-508,
+// 543-588, 859-875) and the distance stub (lib/ohnsw.ml:899, lib/hnsw.ml:814).
+//
+// Execution model
+//   * one 64-lane wavefront = one query; a workgroup is one wave (no cross-wave sync anywhere);
+//   * a vector row is read by a 16-lane group (= one DPP row): lane l16 loads float4 chunks
+//     l16, l16+16, ... so a wave-instruction fetches 4 rows x 256 contiguous bytes; the 16
+//     partial sums are reduced with DPP row_ror:8/4/2/1 adds (no LDS, no ds_bpermute);
+//   * all rows of a hop are requested before the first one is consumed (up to RB*4 rows and
+//     RB*NCH global_load_dwordx4 in flight per wave);
+//   * W (the ef nearest so far, lib/ohnsw.ml:574-577) lives in registers as a sorted list of
+//     64-bit keys (ordered distance bits << 32 | id << 1 | expanded), striped slot-major across
+//     the wave; an insertion is ballot-rank + DPP wave_shr:1 shift.  The candidate queue C of
+//     the reference is the set of unexpanded members of W plus a small stack of entries that
+//     were evicted while tied with max(W) (they are still expandable, lib/ohnsw.ml:568);
+//   * the visited set (lib/ohnsw.ml:256-268) is an LDS cache of ids with false negatives only:
+//     a re-evaluated node can never enter W again (it is either still in W -- detected as a
+//     duplicate key -- or was rejected/evicted with d >= max(W).d, which never grows), so the
+//     result equals the exact-visited-set result while LDS stays small enough for 16+ waves/CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hnsw_dev {
+
+constexpr uint32_t KEY_INF = 0xFFFFFFFFu;
+
+struct IndexView {
+    const float *X;          // [n][stride] zero-padded rows
+    int64_t stride;          // floats, multiple of 4
+    int64_t n;
+    int32_t d;
+    int32_t nchunks;         // ceil(d/4)
+    const int32_t *nbr0;     // [n][S0], -1 padded, 0-based ids, reference iteration order
+    int32_t S0;
+    int32_t SU;
+    const int32_t *nbrU;     // [rowsU][SU]
+    const int32_t *upper_off;// [n] first upper row of the node (layer 1), -1 if none
+    const uint8_t *upper_lvl;// [n] number of upper rows of the node
+    int32_t max_layer;
+    int32_t entry_point;     // 0-based, -1 = empty
+    int32_t id_base;
+};
+
+struct SearchArgs {
+    const float *Q;
+    int64_t q_stride;
+    int64_t nq;
+    int32_t ef, k, fill;
+    int32_t vt_bits;         // log2 of the LDS visited-cache entries
+    int32_t *out_ids;
+    float *out_dist;
+    uint32_t *out_ndist, *out_nhops, *out_status;
+};
+
+// ---- distance keys -------------------------------------------------------------------------
+// L2: the key is the fp32 squared distance (>= +0, so its bit pattern is monotone); sqrt is
+// monotone and injective on floats when taken in double (lib/ohnsw.ml:899), so ordering squared
+// distances == ordering the reference's distances.  IP: distance 1 - <a,b> may be negative:
+// standard order-preserving bit flip.
+template <int METRIC> __device__ __forceinline__ uint32_t dist_to_key(float acc) {
+    if (METRIC == 0) return __float_as_uint(acc);
+    float dist = 1.0f - acc;
+    uint32_t b = __float_as_uint(dist);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+template <int METRIC> __device__ __forceinline__ float key_to_dist(uint32_t key) {
+    if (METRIC == 0) return sqrtf(__uint_as_float(key)); // correctly rounded == (float)sqrt((double)x)
+    uint32_t b = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+    return __uint_as_float(b);
+}
+
+// ---- DPP helpers ---------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(t);
+}
+// sum over the 16 lanes of a DPP row; every lane ends with the same bits:
+// p[j] += p[j+8]; p[j] += p[j+4]; p[j] += p[j+2]; p[j] += p[j+1]  (oracle: OG_TREE16)
+__device__ __forceinline__ float reduce16(float v) {
+    v = dpp_add<0x128>(v); // row_ror:8
+    v = dpp_add<0x124>(v); // row_ror:4
+    v = dpp_add<0x122>(v); // row_ror:2
+    v = dpp_add<0x121>(v); // row_ror:1
+    return v;
+}
+// lane i <- lane i-1; lane 0 <- carry (wave_shr:1, bound_ctrl off keeps `old` in lane 0)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- row evaluation ------------------------------------------------------------------------
+// Distances of the cnt candidates listed in LDS cand_id[] to the query held in qv; the ordered
+// key of candidate ci is written to LDS cand_key[ci].
+template <int NCH, int RB, int METRIC>
+__device__ __forceinline__ void eval_candidates(const IndexView &iv, const float4 (&qv)[NCH],
+                                                const int32_t *cand_id, uint32_t *cand_key,
+                                                int cnt, int r, int l16) {
+    const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
+    const int64_t stride4 = iv.stride >> 2;
+    for (int base = 0; base < cnt; base += 4 * RB) {
+        float4 v[RB][NCH];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int ci = base + 4 * b + r;
+            const bool valid = ci < cnt;
+            const int id = valid ? cand_id[ci] : 0;
+            const float4 *row = X4 + (int64_t)id * stride4;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = i * 16 + l16;
+                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid && c < iv.nchunks) z = row[c];
+                v[b][i] = z;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                // lanes past the row end hold v == 0 and qv == 0: they add exactly 0
+                if (METRIC == 0) {
+                    float dx = v[b][i].x - qv[i].x; acc = __builtin_fmaf(dx, dx, acc);
+                    float dy = v[b][i].y - qv[i].y; acc = __builtin_fmaf(dy, dy, acc);
+                    float dz = v[b][i].z - qv[i].z; acc = __builtin_fmaf(dz, dz, acc);
+                    float dw = v[b][i].w - qv[i].w; acc = __builtin_fmaf(dw, dw, acc);
+                } else {
+                    acc = __builtin_fmaf(v[b][i].x, qv[i].x, acc);
+                    acc = __builtin_fmaf(v[b][i].y, qv[i].y, acc);
+                    acc = __builtin_fmaf(v[b][i].z, qv[i].z, acc);
+                    acc = __builtin_fmaf(v[b][i].w, qv[i].w, acc);
+                }
+            }
+            acc = reduce16(acc);
+            const int ci = base + 4 * b + r;
+            if (l16 == 0 && ci < cnt) cand_key[ci] = dist_to_key<METRIC>(acc);
+        }
+    }
+}
+
+// ---- W: sorted register-resident list ------------------------------------------------------
+template <int NSLOT> struct WList {
+    uint32_t hi[NSLOT], lo[NSLOT]; // entry j lives in slot j/64, lane j%64
+    int count;                     // wave-uniform
+    uint32_t wmax;                 // key.hi of entry ef-1 once full, KEY_INF before
+    // tied-at-max evicted-but-unexpanded entries (still poppable, lib/ohnsw.ml:568): a stack
+    int ovf_cnt;
+    uint32_t ovf_key;
+};
+
+constexpr int OVF_CAP = 64; // LDS entries
+
+template <int NSLOT>
+__device__ __forceinline__ void wlist_init(WList<NSLOT> &w) {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) { w.hi[s] = KEY_INF; w.lo[s] = KEY_INF; }
+    w.count = 0; w.wmax = KEY_INF; w.ovf_cnt = 0; w.ovf_key = 0;
+}
+
+// Insert (kd, kid) -- both wave-uniform.  Mirrors lib/ohnsw.ml:575-577: push W, pop the
+// farthest if |W| > ef.  Returns nothing; duplicates (same id already in W) are ignored.
+template <int NSLOT>
+__device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint32_t kid, int ef,
+                                             int lane, uint32_t *ovf_lds, uint32_t &status) {
+    const uint32_t klo = kid << 1;
+    int p = 0;
+    bool dup = false;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const bool lt = (w.hi[s] < kd) || (w.hi[s] == kd && w.lo[s] < klo);
+        const bool eq = (w.hi[s] == kd) && ((w.lo[s] >> 1) == kid);
+        p += __popcll(__ballot(lt));
+        dup = dup || (__ballot(eq) != 0ull);
+    }
+    if (dup) return;
+    const bool full = (w.count == ef);
+    if (full && p >= ef) return;
+    const int SL = (ef - 1) >> 6, LL = (ef - 1) & 63;
+    uint32_t ev_hi = KEY_INF, ev_lo = KEY_INF;
+    if (full) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s)
+            if (s == SL) { ev_hi = rdlane(w.hi[s], LL); ev_lo = rdlane(w.lo[s], LL); }
+    }
+#pragma unroll
+    for (int s = NSLOT - 1; s >= 0; --s) {
+        uint32_t chi = 0, clo = 0;
+        if (s > 0) { chi = rdlane(w.hi[s - 1], 63); clo = rdlane(w.lo[s - 1], 63); }
+        const uint32_t shi = wave_shr1(w.hi[s], chi);
+        const uint32_t slo = wave_shr1(w.lo[s], clo);
+        const int idx = s * 64 + lane;
+        uint32_t nhi = idx < p ? w.hi[s] : (idx == p ? kd : shi);
+        uint32_t nlo = idx < p ? w.lo[s] : (idx == p ? klo : slo);
+        if (idx >= ef) { nhi = KEY_INF; nlo = KEY_INF; }
+        w.hi[s] = nhi; w.lo[s] = nlo;
+    }
+    if (!full) w.count++;
+    if (w.count == ef) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s)
+            if (s == SL) w.wmax = rdlane(w.hi[s], LL);
+    }
+    if (full) {
+        if (w.ovf_cnt > 0 && w.ovf_key != w.wmax) w.ovf_cnt = 0; // max(W).d dropped: all dead
+        if (!(ev_lo & 1u) && ev_hi == w.wmax) {                   // evicted, tied, unexpanded
+            if (w.ovf_cnt < OVF_CAP) { if (lane == 0) ovf_lds[w.ovf_cnt] = ev_lo >> 1; w.ovf_cnt++; }
+            else status |= 1u;
+            w.ovf_key = ev_hi;
+        }
+    }
+}
+
+// Nearest unexpanded member of W (= pop_min of the reference's visit_me, lib/ohnsw.ml:565),
+// marking it expanded; -1 if none.
+template <int NSLOT>
+__device__ __forceinline__ int wlist_pop_unexpanded(WList<NSLOT> &w, int lane) {
+    int c = -1;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        if (c < 0) {
+            const uint64_t m = __ballot((w.lo[s] & 1u) == 0u);
+            if (m) {
+                const int L = __builtin_ctzll(m);
+                c = (int)(rdlane(w.lo[s], L) >> 1);
+                if (lane == L) w.lo[s] |= 1u;
+            }
+        }
+    }
+    return c;
+}
+
+// ---- the search kernel ---------------------------------------------------------------------
+template <int NCH, int RB, int NSLOT, int METRIC>
+__global__ void __launch_bounds__(64)
+hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
+    extern __shared__ uint32_t lds[];
+    const int vt_size = 1 << a.vt_bits;
+    uint32_t *vt = lds;                                        // visited cache
+    int32_t *cand_id = reinterpret_cast<int32_t *>(lds + vt_size); // [64]
+    uint32_t *cand_key = lds + vt_size + 64;                   // [64]
+    uint32_t *ovf = lds + vt_size + 128;                       // [OVF_CAP]
+
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, l16 = lane & 15;
+    const int64_t q = blockIdx.x;
+    if (q >= a.nq) return;
+
+    // query -> registers (zero beyond d)
+    float4 qv[NCH];
+    {
+        const float *qp = a.Q + q * a.q_stride;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int e0 = 4 * (i * 16 + l16);
+            qv[i].x = (e0 + 0 < iv.d) ? qp[e0 + 0] : 0.f;
+            qv[i].y = (e0 + 1 < iv.d) ? qp[e0 + 1] : 0.f;
+            qv[i].z = (e0 + 2 < iv.d) ? qp[e0 + 2] : 0.f;
+            qv[i].w = (e0 + 3 < iv.d) ? qp[e0 + 3] : 0.f;
+        }
+    }
+    for (int i = lane; i < vt_size; i += 64) vt[i] = 0xFFFFFFFFu; // Visited.clear
+    const uint32_t vt_shift = 32u - (uint32_t)a.vt_bits;
+
+    uint32_t n_dist = 0, n_hops = 0, status = 0;
+
+    // ---- entry point ----
+    int cur = iv.entry_point;
+    if (lane == 0) cand_id[0] = cur;
+    __syncthreads();
+    eval_candidates<NCH, RB, METRIC>(iv, qv, cand_id, cand_key, 1, r, l16);
+    __syncthreads();
+    uint32_t cur_key = cand_key[0];
+    n_dist += 1;
+
+    // ---- descent: Ohnsw.search_one_simple on layers max_layer..1 (lib/ohnsw.ml:865-867) ----
+    for (int layer = iv.max_layer; layer >= 1; --layer) {
+        for (;;) {
+            const int off = iv.upper_off[cur];
+            const int lvl = iv.upper_lvl[cur];
+            int nb = -1;
+            if (lane < iv.SU && layer <= lvl) nb = iv.nbrU[((int64_t)off + (layer - 1)) * iv.SU + lane];
+            const bool valid = nb >= 0;
+            const uint64_t m = __ballot(valid);
+            const int cnt = __popcll(m);
+            if (cnt == 0) break;
+            const int pos = __popcll(m & ((1ull << lane) - 1ull));
+            __syncthreads();
+            if (valid) cand_id[pos] = nb;
+            __syncthreads();
+            eval_candidates<NCH, RB, METRIC>(iv, qv, cand_id, cand_key, cnt, r, l16);
+            __syncthreads();
+            n_dist += cnt;
+            // first-in-row-order minimum (strict '<' while scanning, lib/ohnsw.ml:502)
+            uint64_t best = (lane < cnt) ? (((uint64_t)cand_key[lane] << 32) | (uint32_t)lane) : ~0ull;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const uint64_t other = __shfl_xor(best, o);
+                best = other < best ? other : best;
+            }
+            const uint32_t bkey = (uint32_t)(best >> 32);
+            if (bkey < cur_key) { cur = cand_id[(int)(best & 63u)]; cur_key = bkey; }
+            else break;
+        }
+    }
+
+    // ---- layer 0: Ohnsw.search_k (lib/ohnsw.ml:543-588) ----
+    WList<NSLOT> w;
+    wlist_init(w);
+    wlist_insert(w, cur_key, (uint32_t)cur, a.ef, lane, ovf, status);   // :555-557 seeds W
+    if (lane == 0) vt[((uint32_t)cur * 0x9E3779B1u) >> vt_shift] = (uint32_t)cur;
+    __syncthreads();
+
+    for (;;) {
+        int c = wlist_pop_unexpanded(w, lane);                           // :565
+        if (c < 0) {
+            // no unexpanded member of W: only entries evicted while tied with max(W) can still
+            // satisfy "not (c.d > max(W).d)" (:568)
+            if (w.ovf_cnt > 0 && w.count == a.ef && w.ovf_key == w.wmax) c = (int)ovf[--w.ovf_cnt];
+            else break;
+        }
+        n_hops++;
+        int nb = -1;
+        if (lane < iv.S0) nb = iv.nbr0[(int64_t)c * iv.S0 + lane];       // Graph.adjacent, :570
+        const bool valid = nb >= 0;
+        const uint32_t slot = ((uint32_t)nb * 0x9E3779B1u) >> vt_shift;
+        const bool seen = valid && (vt[slot] == (uint32_t)nb);           // Visited.mem, :571
+        const bool fresh = valid && !seen;
+        const uint64_t m = __ballot(fresh);
+        const int cnt = __popcll(m);
+        if (cnt == 0) continue;
+        const int pos = __popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (fresh) { vt[slot] = (uint32_t)nb; cand_id[pos] = nb; }       // Visited.add, :572
+        __syncthreads();
+        eval_candidates<NCH, RB, METRIC>(iv, qv, cand_id, cand_key, cnt, r, l16); // :573
+        __syncthreads();
+        n_dist += cnt;
+        const uint32_t my_key = (lane < cnt) ? cand_key[lane] : KEY_INF;
+        const uint32_t my_id = (lane < cnt) ? (uint32_t)cand_id[lane] : 0u;
+        // :574 accept iff |W| < ef or d < max(W).d -- tested in row order against the CURRENT W
+        uint64_t pass = __ballot(lane < cnt && (w.count < a.ef || my_key < w.wmax));
+        while (pass) {
+            const int i = __builtin_ctzll(pass);
+            pass &= pass - 1;
+            const uint32_t kd = rdlane(my_key, i);
+            if (w.count == a.ef && !(kd < w.wmax)) continue;
+            wlist_insert(w, kd, rdlane(my_id, i), a.ef, lane, ovf, status);    // :575-577
+        }
+    }
+
+    // ---- results: W[0..k) ascending (lib/ohnsw.ml:886-893) ----
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int idx = s * 64 + lane;
+        if (idx < a.k) {
+            int32_t oid = -1;
+            float od = a.fill == 0 ? __uint_as_float(0x7FC00000u) : __uint_as_float(0x7F800000u);
+            if (idx < w.count) { oid = (int32_t)(w.lo[s] >> 1) + iv.id_base; od = key_to_dist<METRIC>(w.hi[s]); }
+            a.out_ids[q * a.k + idx] = oid;
+            a.out_dist[q * a.k + idx] = od;
+        }
+    }
+    if (lane == 0) {
+        if (a.out_ndist) a.out_ndist[q] = n_dist;
+        if (a.out_nhops) a.out_nhops[q] = n_hops;
+        if (a.out_status) a.out_status[q] = status;
+    }
+}
+
+// ---- gathered distances (bench_dist/bench_dist.ml counterpart) --------------------------------
+// one 16-lane group per (query, id) pair; a wave handles 4 pairs of the same query per step.
+template <int NCH, int METRIC>
+__global__ void __launch_bounds__(64)
+hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq,
+                     const int32_t *ids, int32_t m, float *out) {
+    const int lane = threadIdx.x;
+    const int r = lane >> 4, l16 = lane & 15;
+    const int64_t q = blockIdx.x;
+    if (q >= nq) return;
+    float4 qv[NCH];
+    const float *qp = Q + q * q_stride;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int e0 = 4 * (i * 16 + l16);
+        qv[i].x = (e0 + 0 < iv.d) ? qp[e0 + 0] : 0.f;
+        qv[i].y = (e0 + 1 < iv.d) ? qp[e0 + 1] : 0.f;
+        qv[i].z = (e0 + 2 < iv.d) ? qp[e0 + 2] : 0.f;
+        qv[i].w = (e0 + 3 < iv.d) ? qp[e0 + 3] : 0.f;
+    }
+    const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
+    const int64_t stride4 = iv.stride >> 2;
+    for (int base = blockIdx.y * 4; base < m; base += 4 * gridDim.y) {
+        const int j = base + r;
+        const bool valid = j < m;
+        const int id = valid ? ids[q * m + j] - iv.id_base : 0;
+        const float4 *row = X4 + (int64_t)id * stride4;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 16 + l16;
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && c < iv.nchunks) z = row[c];
+            if (METRIC == 0) {
+                float dx = z.x - qv[i].x; acc = __builtin_fmaf(dx, dx, acc);
+                float dy = z.y - qv[i].y; acc = __builtin_fmaf(dy, dy, acc);
+                float dz = z.z - qv[i].z; acc = __builtin_fmaf(dz, dz, acc);
+                float dw = z.w - qv[i].w; acc = __builtin_fmaf(dw, dw, acc);
+            } else {
+                acc = __builtin_fmaf(z.x, qv[i].x, acc);
+                acc = __builtin_fmaf(z.y, qv[i].y, acc);
+                acc = __builtin_fmaf(z.z, qv[i].z, acc);
+                acc = __builtin_fmaf(z.w, qv[i].w, acc);
+            }
+        }
+        acc = reduce16(acc);
+        if (valid && l16 == 0) out[q * m + j] = key_to_dist<METRIC>(dist_to_key<METRIC>(acc));
+    }
+}
+
+} // namespace hnsw_dev

@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/hnsw_mi355x.h declares, and fails loudly (no CPU fallback) when no device is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def H():
+    import __graft_entry__ as ge
+    ge._load_build_module().build()
+    import ocaml_hnsw_amd as H
+    H.load()
+    return H
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "hnsw_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(hnsw_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_exports_every_declared_symbol(H):
+    L = H.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    assert sorted(H.ABI_SYMBOLS) == declared
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.hnsw_abi_version() == 1
+
+
+def test_no_torch_types_in_abi():
+    hdr = open(os.path.join(ROOT, "include", "hnsw_mi355x.h")).read()
+    assert "torch" not in hdr and "at::" not in hdr and "std::" not in hdr
+
+
+def test_product_does_not_touch_oracle():
+    """The product path must never route through the oracle or any CPU fallback."""
+    pkg = os.path.join(ROOT, "ocaml-hnsw_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".ml")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "liboracle" not in txt and "hnsw_oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_fails_loudly_without_device(H):
+    if H.device_count() > 0:
+        pytest.skip("a device is present")
+    X = np.zeros((4, 8), np.float32)
+    hg = H.Hgraph(X, np.zeros(4, np.int32), np.full((4, 4), -1, np.int32), entry_point=0)
+    with pytest.raises(H.Failure, match="no HIP device"):
+        H.Ohnsw.knn_batch_bigarray(hg, 2, X)
+
+
+def test_argument_validation_is_host_side(H):
+    # shapes are checked before anything touches a device
+    with pytest.raises(H.InvalidArgument):
+        H.Hgraph(np.zeros((4, 8), np.float32), np.zeros(3, np.int32), np.zeros((4, 4), np.int32))

