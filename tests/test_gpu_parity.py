@@ -127,11 +127,18 @@ def test_within_tolerance_of_reference_arithmetic(H, oracle, case):
     oids, odist = oracle.Ohnsw.knn_batch_bigarray(c["g"], sp, c["Q"], k=c["k"], ef=c["ef"], ties=oracle.TIES_HEAP)
     ok = np.isfinite(odist)
     assert np.array_equal(ok, np.isfinite(dist))
-    scale = np.maximum(np.abs(odist[ok]), 1e-3 if c["metric"] else 0)
-    close = np.abs(dist[ok] - odist[ok]) <= 4 * REL_TOL * np.maximum(scale, 1e-30)
-    assert close.mean() > 0.999
-    same_rows = np.all(ids == oids, axis=1).mean()
-    assert same_rows > 0.97
+    scale = np.maximum(np.abs(odist), 1e-3 if c["metric"] else 1e-30)
+    close = ~ok | (np.abs(dist - odist) <= 4 * REL_TOL * scale)
+    assert close[ok].mean() > 0.999
+    # ids: a differing position is legitimate only as a swap inside the tolerance band
+    differs = ids != oids
+    unexplained = differs & ~close
+    assert unexplained.any(axis=1).mean() <= 0.02
+    near_tie = np.zeros_like(differs)
+    near_tie[:, 1:] |= np.abs(odist[:, 1:] - odist[:, :-1]) <= 8 * REL_TOL * scale[:, 1:]
+    near_tie[:, :-1] |= near_tie[:, 1:].copy()
+    near_tie[:, -1] = True   # the k-th boundary can trade with rank k+1
+    assert (differs & ~near_tie).any(axis=1).mean() <= 0.02
 
 
 def test_visited_cache_size_never_changes_results(H, oracle, case):
