@@ -150,6 +150,32 @@ int32_t hnsw_distance_batch_device(hnsw_index *idx, const float *d_queries, int6
                                    int64_t q_stride, const int32_t *d_ids, int32_t m,
                                    float *d_out, void *stream);
 
+/* ---- graph construction on the device (next-row scope: the reference's builder stays OCaml;
+ * this entry point exists so an index can also be produced where no OCaml build is at hand,
+ * e.g. by bench.py).  Batched restatement of Ohnsw.build_batch_bigarray (lib/ohnsw.ml:840-857):
+ * same level law, same per-node steps (search_one descent, search_k with efConstruction,
+ * select_neighbours with M / 2M, symmetric links, shrink), nodes inserted in batches against
+ * the graph as of batch start.  Deterministic for a given seed. */
+typedef struct hnsw_build_params {
+    int32_t num_connections;               /* M   (~num_connections, lib/ohnsw.ml:841)          */
+    int32_t num_nodes_search_construction; /* efConstruction                                   */
+    int32_t metric;
+    int32_t id_base;
+    uint64_t seed;                         /* level draws (own RNG)                            */
+    int32_t max_batch;                     /* 0 = default (8192)                               */
+    int32_t batch_div;                     /* batch <= nodes already inserted / batch_div; 0 = 16 */
+} hnsw_build_params;
+
+int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_stride,
+                   const hnsw_build_params *params, int32_t device, hnsw_index **out);
+
+/* Export of the flattened graph held by an index (inverse of hnsw_index_create): ids
+ * id_base-based, rows compacted, -1 padded. */
+int32_t hnsw_index_export_layer0(const hnsw_index *idx, int32_t *deg0, int32_t *nbr0);
+int32_t hnsw_index_export_upper_count(const hnsw_index *idx, int32_t layer, int64_t *n_nodes);
+int32_t hnsw_index_export_upper(const hnsw_index *idx, int32_t layer, int64_t *nodes, int32_t *deg,
+                                int32_t *nbr);
+
 #ifdef __cplusplus
 }
 #endif

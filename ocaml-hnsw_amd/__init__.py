@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "hnsw_abi_version", "hnsw_last_error", "hnsw_device_count", "hnsw_index_create",
     "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_search_batch",
     "hnsw_search_batch_device", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
+    "hnsw_build", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
 ]
 
 
@@ -57,6 +58,12 @@ class _IndexDesc(_C.Structure):
 
 class _SearchParams(_C.Structure):
     _fields_ = [("ef", _C.c_int32), ("k", _C.c_int32), ("fill", _C.c_int32), ("reserved", _C.c_int32)]
+
+
+class _BuildParams(_C.Structure):
+    _fields_ = [("num_connections", _C.c_int32), ("num_nodes_search_construction", _C.c_int32),
+                ("metric", _C.c_int32), ("id_base", _C.c_int32), ("seed", _C.c_uint64),
+                ("max_batch", _C.c_int32), ("batch_div", _C.c_int32)]
 
 
 class IndexInfo(_C.Structure):
@@ -91,6 +98,13 @@ def load():
     L.hnsw_knn.argtypes = [vp, vp, vp, vp, vp, vp]
     L.hnsw_distance_batch.argtypes = [vp, vp, i64, i64, vp, i32, vp]
     L.hnsw_distance_batch_device.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp]
+    L.hnsw_build.argtypes = [vp, i64, i32, i64, vp, i32, vp]
+    L.hnsw_index_export_layer0.argtypes = [vp, vp, vp]
+    L.hnsw_index_export_upper_count.argtypes = [vp, i32, vp]
+    L.hnsw_index_export_upper.argtypes = [vp, i32, vp, vp, vp]
+    for f in ("hnsw_build", "hnsw_index_export_layer0", "hnsw_index_export_upper_count",
+              "hnsw_index_export_upper"):
+        getattr(L, f).restype = i32
     for f in ("hnsw_device_count", "hnsw_index_create", "hnsw_index_destroy", "hnsw_index_get_info",
               "hnsw_index_set_option", "hnsw_search_batch", "hnsw_search_batch_device", "hnsw_knn",
               "hnsw_distance_batch", "hnsw_distance_batch_device"):
@@ -151,6 +165,40 @@ class Hgraph:
         self.metric = int(metric)
         self._index = None
         self._device = None
+
+    @classmethod
+    def _from_handle(cls, handle, device, vectors, id_base, metric):
+        """Wrap an index that already lives on the device (hnsw_build); the host copy of the
+        graph is fetched on demand by export()."""
+        self = cls.__new__(cls)
+        self.vectors = vectors
+        self.n, self.d = vectors.shape
+        self._index, self._device = handle, device
+        self.id_base, self.metric = int(id_base), int(metric)
+        inf = IndexInfo()
+        _check(load().hnsw_index_get_info(handle, _C.byref(inf)))
+        self.max_degree0, self.max_degree, self.max_layer = inf.max_degree0, inf.max_degree, inf.max_layer
+        self.entry_point = int(inf.entry_point) if inf.entry_point >= id_base else None
+        self.deg0 = self.nbr0 = None
+        self.upper = None
+        return self
+
+    def export(self):
+        """Fetch the flattened graph from the device: fills deg0, nbr0, upper (ids id_base-based)."""
+        L = load()
+        self.deg0 = _np.empty(self.n, _np.int32)
+        self.nbr0 = _np.empty((self.n, self.max_degree0), _np.int32)
+        _check(L.hnsw_index_export_layer0(self.handle, _ptr(self.deg0), _ptr(self.nbr0)))
+        self.upper = []
+        for l in range(1, self.max_layer + 1):
+            c = _C.c_int64(0)
+            _check(L.hnsw_index_export_upper_count(self.handle, l, _C.byref(c)))
+            nodes = _np.empty(c.value, _np.int64)
+            deg = _np.empty(c.value, _np.int32)
+            nbr = _np.empty((c.value, self.max_degree), _np.int32)
+            _check(L.hnsw_index_export_upper(self.handle, l, _ptr(nodes), _ptr(deg), _ptr(nbr)))
+            self.upper.append((nodes, deg, nbr))
+        return self
 
     def to_device(self, device=0):
         """Upload to HBM (hnsw_index_create).  Idempotent per device."""
@@ -243,6 +291,20 @@ class Ohnsw:
         """Ohnsw.knn_batch_bigarray hgraph ~k batch (lib/ohnsw.ml:877-897) -> (ids, distances):
         ids [nq][k] (-1 where fewer than k were found), distances [nq][k] fp32 (NaN there)."""
         return _search(hgraph, batch, k if ef is None else ef, k, FILL_OHNSW, counters)
+
+    @staticmethod
+    def build_batch_bigarray(batch, num_connections, num_nodes_search_construction, seed=0,
+                             metric=METRIC_L2, device=0, max_batch=0, batch_div=0):
+        """Ohnsw.build_batch_bigarray distance batch ~num_connections ~num_nodes_search_construction
+        (lib/ohnsw.ml:840-857), batched on the device (the OCaml builder itself stays OCaml; this
+        is for hosts without one).  -> Hgraph resident in HBM."""
+        X = _np.ascontiguousarray(batch, dtype=_np.float32)
+        if X.ndim != 2 or X.shape[0] < 1:
+            raise InvalidArgument("batch must be [n][d], n >= 1")
+        p = _BuildParams(num_connections, num_nodes_search_construction, metric, 0, seed, max_batch, batch_div)
+        h = _C.c_void_p()
+        _check(load().hnsw_build(_ptr(X), X.shape[0], X.shape[1], X.shape[1], _C.byref(p), device, _C.byref(h)))
+        return Hgraph._from_handle(h, device, X, 0, metric)
 
     @staticmethod
     def distance_l2(hgraph, queries, ids):

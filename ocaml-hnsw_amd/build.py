@@ -8,8 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libhnsw_mi355x.so")
-SOURCES = ["hnsw_capi.hip"]
-DEPS = ["hnsw_capi.hip", "hnsw_device.hip.h", os.path.join(ROOT, "include", "hnsw_mi355x.h")]
+SOURCES = ["hnsw_capi.hip", "hnsw_build.hip"]
+DEPS = ["hnsw_capi.hip", "hnsw_build.hip", "hnsw_device.hip.h", "hnsw_build_device.hip.h", "hnsw_internal.h",
+        os.path.join(ROOT, "include", "hnsw_mi355x.h")]
 
 
 def _hipcc():
@@ -33,18 +34,35 @@ def up_to_date():
 def build(force=False, verbose=False, resource_log=None):
     if not force and up_to_date():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include")]
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include")]
     if resource_log:
-        cmd += ["-Rpass-analysis=kernel-resource-usage"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+        base += ["-Rpass-analysis=kernel-resource-usage"]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for s_ in SOURCES:  # one hipcc per translation unit, in parallel
+        obj = os.path.join(objdir, s_ + ".o")
+        cmd = base + ["-c", os.path.join(CSRC, s_), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        log = open(resource_log + "." + s_, "w") if resource_log else None
+        procs.append((subprocess.Popen(cmd, stderr=log), obj, cmd, log))
+    objs = []
+    for pr, obj, cmd, log in procs:
+        rc = pr.wait()
+        if log:
+            log.close()
+        if rc != 0:
+            raise subprocess.CalledProcessError(rc, cmd)
+        objs.append(obj)
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd), flush=True)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     if resource_log:
         with open(resource_log, "w") as f:
-            subprocess.check_call(cmd, stderr=f)
-    else:
-        subprocess.check_call(cmd)
+            for s_ in SOURCES:
+                f.write(open(resource_log + "." + s_).read())
     return LIB
 
 

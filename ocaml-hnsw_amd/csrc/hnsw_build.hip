@@ -1,0 +1,332 @@
+// hnsw_build.hip -- host driver of the batched GPU graph builder + graph export.
+//
+// Restates Ohnsw.build_batch_bigarray / Ohnsw.insert (lib/ohnsw.ml:766-857) batch-wise on the
+// device (kernels: hnsw_build_device.hip.h).  The level law is the reference's
+// (round_nearest(-ln(U) * 1/ln M), lib/ohnsw.ml:781,844); the RNG is this library's own seeded
+// splitmix64 (OCaml's Random cannot and need not be reproduced: search parity is defined GIVEN a
+// graph).  A node that raises max_layer ends its batch and becomes the entry point (:832-836).
+#include "hnsw_build_device.hip.h"
+#include "hnsw_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+
+using namespace hnsw_host;
+using hnsw_dev::BatchView;
+using hnsw_dev::BuildView;
+using hnsw_dev::IndexView;
+using hnsw_dev::MergeArgs;
+using hnsw_dev::SelectArgs;
+
+namespace {
+
+inline uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+inline double rng_unit(uint64_t *s) { return ((double)(splitmix64(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+template <int NCH, int RB, int METRIC>
+hipError_t launch_k1(int nslot, const BuildView &bv, const BatchView &bt, hipStream_t st) {
+    const size_t lds = hnsw_dev::wave_lds_words(bv.vt_bits) * sizeof(uint32_t);
+    dim3 grid((unsigned)bt.B), block(64);
+    switch (nslot) {
+    case 1: hipLaunchKernelGGL((hnsw_dev::build_search_kernel<NCH, RB, 1, METRIC>), grid, block, lds, st, bv, bt); break;
+    case 2: hipLaunchKernelGGL((hnsw_dev::build_search_kernel<NCH, RB, 2, METRIC>), grid, block, lds, st, bv, bt); break;
+    case 4: hipLaunchKernelGGL((hnsw_dev::build_search_kernel<NCH, RB, 4, METRIC>), grid, block, lds, st, bv, bt); break;
+    default: hipLaunchKernelGGL((hnsw_dev::build_search_kernel<NCH, RB, 8, METRIC>), grid, block, lds, st, bv, bt); break;
+    }
+    return hipGetLastError();
+}
+template <int METRIC>
+hipError_t dispatch_k1(int nch, int nslot, const BuildView &bv, const BatchView &bt, hipStream_t st) {
+    switch (nch) {
+    case 1: return launch_k1<1, 8, METRIC>(nslot, bv, bt, st);
+    case 2: return launch_k1<2, 8, METRIC>(nslot, bv, bt, st);
+    case 4: return launch_k1<4, 4, METRIC>(nslot, bv, bt, st);
+    case 8: return launch_k1<8, 2, METRIC>(nslot, bv, bt, st);
+    default: return launch_k1<16, 1, METRIC>(nslot, bv, bt, st);
+    }
+}
+template <int METRIC>
+hipError_t dispatch_k2(int nch, const BuildView &bv, const BatchView &bt, const SelectArgs &sa, hipStream_t st) {
+    const size_t lds = (2 * (size_t)bv.cand_stride + 64) * sizeof(uint32_t);
+    dim3 grid((unsigned)(sa.rec_end - sa.rec_begin)), block(64);
+    switch (nch) {
+    case 1: hipLaunchKernelGGL((hnsw_dev::build_select_kernel<1, METRIC>), grid, block, lds, st, bv, bt, sa); break;
+    case 2: hipLaunchKernelGGL((hnsw_dev::build_select_kernel<2, METRIC>), grid, block, lds, st, bv, bt, sa); break;
+    case 4: hipLaunchKernelGGL((hnsw_dev::build_select_kernel<4, METRIC>), grid, block, lds, st, bv, bt, sa); break;
+    case 8: hipLaunchKernelGGL((hnsw_dev::build_select_kernel<8, METRIC>), grid, block, lds, st, bv, bt, sa); break;
+    default: hipLaunchKernelGGL((hnsw_dev::build_select_kernel<16, METRIC>), grid, block, lds, st, bv, bt, sa); break;
+    }
+    return hipGetLastError();
+}
+template <int METRIC>
+hipError_t dispatch_k4(int nch, const BuildView &bv, const MergeArgs &ma, hipStream_t st) {
+    dim3 grid((unsigned)ma.n_edges), block(64);
+    switch (nch) {
+    case 1: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<1, 8, METRIC>), grid, block, 0, st, bv, ma); break;
+    case 2: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<2, 8, METRIC>), grid, block, 0, st, bv, ma); break;
+    case 4: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<4, 4, METRIC>), grid, block, 0, st, bv, ma); break;
+    case 8: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<8, 2, METRIC>), grid, block, 0, st, bv, ma); break;
+    default: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<16, 1, METRIC>), grid, block, 0, st, bv, ma); break;
+    }
+    return hipGetLastError();
+}
+
+#define HIP_TRY_B(expr)                                                                      \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            rc = fail(e__ == hipErrorOutOfMemory ? HNSW_ERR_OOM : HNSW_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+            goto done;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+} // namespace
+
+extern "C" {
+
+int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_stride,
+                   const hnsw_build_params *p, int32_t device, hnsw_index **out) {
+    if (!out || !p) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    if (n < 1 || n > 0x7FFFFFF0LL) return fail(HNSW_ERR_BAD_ARG, "n=%lld out of range", (long long)n);
+    if (!vectors || d < 1 || row_stride < d) return fail(HNSW_ERR_BAD_ARG, "bad vectors/d/row_stride");
+    if (p->metric != HNSW_METRIC_L2 && p->metric != HNSW_METRIC_IP) return fail(HNSW_ERR_BAD_ARG, "bad metric");
+    const int M = p->num_connections, efc = p->num_nodes_search_construction;
+    if (M < 2 || 2 * M > 64) return fail(HNSW_ERR_UNSUPPORTED, "num_connections=%d must be in 2..32", M);
+    if (efc < 1 || efc > 512) return fail(HNSW_ERR_UNSUPPORTED, "num_nodes_search_construction=%d must be in 1..512", efc);
+    const int nchunks = (d + 3) / 4;
+    const int nch = pick_nch(nchunks);
+    if (!nch) return fail(HNSW_ERR_UNSUPPORTED, "d=%d > 1024 not supported", d);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(HNSW_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)"); }
+    if (device < 0 || device >= ndev) return fail(HNSW_ERR_BAD_ARG, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+
+    // ---- levels (lib/ohnsw.ml:781): the first node draws nothing (:774-778) ----
+    const double level_mult = 1.0 / std::log((double)M);                                  // :844
+    std::vector<uint8_t> lvl((size_t)n, 0);
+    {
+        uint64_t rng = p->seed;
+        for (int64_t i = 1; i < n; ++i) {
+            const double u = rng_unit(&rng);
+            int l = (int)std::floor(-std::log(u) * level_mult + 0.5);
+            lvl[(size_t)i] = (uint8_t)std::min(l, 15);
+        }
+    }
+    int lcap = 1;
+    for (int64_t i = 0; i < n; ++i) lcap = std::max(lcap, (int)lvl[(size_t)i] + 1);
+    std::vector<int32_t> off((size_t)n, -1);
+    int64_t rowsU = 0;
+    for (int64_t i = 0; i < n; ++i) if (lvl[(size_t)i]) { off[(size_t)i] = (int32_t)rowsU; rowsU += lvl[(size_t)i]; }
+
+    hnsw_index *idx = new hnsw_index();
+    idx->device = device;
+    int rc = HNSW_OK;
+    const int S0 = 2 * M, SU = M;
+    const int64_t stride = padded_stride(d);
+    size_t xbytes = 0;
+    const int bdiv = p->batch_div > 0 ? p->batch_div : 16;
+    const int bmax = p->max_batch > 0 ? p->max_batch : 8192;
+    const int cand_stride = (efc + 63) / 64 * 64;
+    const int nslot = pick_nslot(efc);
+    const int64_t maxrec = (int64_t)bmax * lcap;
+    const int64_t max_edges = (int64_t)bmax * S0;
+    hipStream_t st = nullptr;
+    void *dNodes = nullptr, *dRecOf = nullptr, *dRecNode = nullptr, *dCandId = nullptr, *dCandKey = nullptr,
+         *dCandCnt = nullptr, *dEdges = nullptr, *dEdgesSorted = nullptr, *dRem = nullptr, *dRemCnt = nullptr, *dTemp = nullptr;
+    size_t temp_bytes = 0;
+    BuildView bv{};
+    int32_t *hp_nodes[2] = {nullptr, nullptr}, *hp_rec_of[2] = {nullptr, nullptr}, *hp_rec_node[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int64_t batch_no = 0;
+    std::vector<int32_t> rec_begin((size_t)lcap + 1, 0);
+    int cur_max = 0, entry = 0;
+
+    if ((rc = upload_vectors(vectors, n, d, row_stride, &idx->dX, &xbytes))) goto done;
+    HIP_TRY_B(hipMalloc(&idx->dNbr0, (size_t)n * S0 * 4));
+    HIP_TRY_B(hipMemset(idx->dNbr0, 0xFF, (size_t)n * S0 * 4));
+    HIP_TRY_B(hipMalloc(&idx->dNbrU, (size_t)std::max<int64_t>(rowsU, 1) * SU * 4));
+    HIP_TRY_B(hipMemset(idx->dNbrU, 0xFF, (size_t)std::max<int64_t>(rowsU, 1) * SU * 4));
+    HIP_TRY_B(hipMalloc(&idx->dOff, (size_t)n * 4));
+    HIP_TRY_B(hipMemcpy(idx->dOff, off.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY_B(hipMalloc(&idx->dLvl, (size_t)n));
+    HIP_TRY_B(hipMemcpy(idx->dLvl, lvl.data(), (size_t)n, hipMemcpyHostToDevice));
+    idx->rowsU = rowsU;
+    {
+        IndexView &iv = idx->iv;
+        iv.X = (const float *)idx->dX; iv.stride = stride; iv.n = n; iv.d = d; iv.nchunks = nchunks;
+        iv.nbr0 = (const int32_t *)idx->dNbr0; iv.S0 = S0; iv.SU = SU;
+        iv.nbrU = (const int32_t *)idx->dNbrU; iv.upper_off = (const int32_t *)idx->dOff;
+        iv.upper_lvl = (const uint8_t *)idx->dLvl;
+        iv.max_layer = 0; iv.entry_point = 0; iv.id_base = p->id_base;
+    }
+    bv.iv = idx->iv; bv.nbr0_w = (int32_t *)idx->dNbr0; bv.nbrU_w = (int32_t *)idx->dNbrU;
+    bv.efc = efc; bv.cand_stride = cand_stride;
+    bv.vt_bits = 8;
+    while ((1 << bv.vt_bits) < 16 * efc && bv.vt_bits < 13) ++bv.vt_bits;
+
+    HIP_TRY_B(hipStreamCreate(&st));
+    HIP_TRY_B(hipMalloc(&dNodes, (size_t)bmax * 4));
+    HIP_TRY_B(hipMalloc(&dRecOf, (size_t)bmax * lcap * 4));
+    HIP_TRY_B(hipMalloc(&dRecNode, (size_t)maxrec * 4));
+    HIP_TRY_B(hipMalloc(&dCandId, (size_t)maxrec * cand_stride * 4));
+    HIP_TRY_B(hipMalloc(&dCandKey, (size_t)maxrec * cand_stride * 4));
+    HIP_TRY_B(hipMalloc(&dCandCnt, (size_t)maxrec * 4));
+    HIP_TRY_B(hipMalloc(&dEdges, (size_t)max_edges * 8));
+    HIP_TRY_B(hipMalloc(&dEdgesSorted, (size_t)max_edges * 8));
+    HIP_TRY_B(hipMalloc(&dRem, (size_t)max_edges * 2 * 8));
+    HIP_TRY_B(hipMalloc(&dRemCnt, 16));
+    HIP_TRY_B(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, (uint64_t *)dEdges, (uint64_t *)dEdgesSorted, (int)max_edges, 0, 64, st));
+    HIP_TRY_B(hipMalloc(&dTemp, std::max<size_t>(temp_bytes, 16)));
+
+    for (int k = 0; k < 2; ++k) {   // pinned, double buffered: batch b+2 waits for batch b's uploads
+        HIP_TRY_B(hipHostMalloc((void **)&hp_nodes[k], (size_t)bmax * 4, hipHostMallocDefault));
+        HIP_TRY_B(hipHostMalloc((void **)&hp_rec_of[k], (size_t)bmax * lcap * 4, hipHostMallocDefault));
+        HIP_TRY_B(hipHostMalloc((void **)&hp_rec_node[k], (size_t)maxrec * 4, hipHostMallocDefault));
+        HIP_TRY_B(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    }
+
+    // ---- batches, in node order (fold_cols, lib/ohnsw.ml:848); node 0 is the first entry point ----
+    for (int64_t pos = 1; pos < n;) {
+        int64_t bsz = std::max<int64_t>(1, std::min<int64_t>(bmax, pos / bdiv));
+        int64_t end = std::min(n, pos + bsz);
+        for (int64_t j = pos; j < end; ++j)
+            if ((int)lvl[(size_t)j] > cur_max) { end = j + 1; break; }       // :832-836
+        const int B = (int)(end - pos);
+        const int kb = (int)(batch_no & 1);
+        if (batch_no >= 2) HIP_TRY_B(hipEventSynchronize(ev[kb]));
+        int32_t *h_nodes = hp_nodes[kb], *h_rec_of = hp_rec_of[kb], *h_rec_node = hp_rec_node[kb];
+        // records: (layer, batch slot) for layer <= min(level, cur_max), ordered by layer then slot
+        int nrec = 0;
+        std::fill(h_rec_of, h_rec_of + (size_t)B * lcap, -1);
+        for (int l = 0; l <= cur_max; ++l) {
+            rec_begin[(size_t)l] = nrec;
+            for (int i = 0; i < B; ++i) {
+                h_nodes[i] = (int32_t)(pos + i);
+                if ((int)lvl[(size_t)(pos + i)] >= l) { h_rec_of[(size_t)i * lcap + l] = nrec; h_rec_node[nrec] = (int32_t)(pos + i); nrec++; }
+            }
+        }
+        rec_begin[(size_t)cur_max + 1] = nrec;
+        HIP_TRY_B(hipMemcpyAsync(dNodes, h_nodes, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY_B(hipMemcpyAsync(dRecOf, h_rec_of, (size_t)B * lcap * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY_B(hipMemcpyAsync(dRecNode, h_rec_node, (size_t)nrec * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY_B(hipEventRecord(ev[kb], st));
+
+        BatchView bt{};
+        bt.nodes = (const int32_t *)dNodes; bt.rec_of = (const int32_t *)dRecOf; bt.B = B; bt.lcap = lcap;
+        bt.cur_max_layer = cur_max; bt.entry = entry;
+        bt.cand_id = (int32_t *)dCandId; bt.cand_key = (uint32_t *)dCandKey; bt.cand_cnt = (int32_t *)dCandCnt;
+        bv.iv.max_layer = cur_max; bv.iv.entry_point = entry;
+        HIP_TRY_B(p->metric == HNSW_METRIC_L2 ? dispatch_k1<0>(nch, nslot, bv, bt, st) : dispatch_k1<1>(nch, nslot, bv, bt, st));
+
+        for (int l = cur_max; l >= 0; --l) {
+            const int rb = rec_begin[(size_t)l], re = rec_begin[(size_t)l + 1];
+            if (re == rb) continue;
+            const int R = l == 0 ? S0 : SU;                                    // :818
+            SelectArgs sa{};
+            sa.rec_node = (const int32_t *)dRecNode; sa.rec_begin = rb; sa.rec_end = re; sa.layer = l; sa.R = R;
+            sa.edges = (uint64_t *)dEdges;
+            HIP_TRY_B(p->metric == HNSW_METRIC_L2 ? dispatch_k2<0>(nch, bv, bt, sa, st) : dispatch_k2<1>(nch, bv, bt, sa, st));
+            const int n_edges = (re - rb) * R;
+            size_t tb = temp_bytes;
+            HIP_TRY_B(hipcub::DeviceRadixSort::SortKeys(dTemp, tb, (uint64_t *)dEdges, (uint64_t *)dEdgesSorted, n_edges, 0, 64, st));
+            HIP_TRY_B(hipMemsetAsync(dRemCnt, 0, 4, st));
+            MergeArgs ma{};
+            ma.edges = (const uint64_t *)dEdgesSorted; ma.n_edges = n_edges; ma.layer = l; ma.R = R;
+            ma.removals = (uint64_t *)dRem; ma.rem_cnt = (uint32_t *)dRemCnt; ma.rem_cap = (uint32_t)(max_edges * 2);
+            HIP_TRY_B(p->metric == HNSW_METRIC_L2 ? dispatch_k4<0>(nch, bv, ma, st) : dispatch_k4<1>(nch, bv, ma, st));
+            const unsigned rem_threads = (unsigned)std::min<int64_t>((int64_t)n_edges * 2, max_edges * 2);
+            hipLaunchKernelGGL(hnsw_dev::build_unlink_kernel, dim3((rem_threads + 255) / 256), dim3(256), 0, st, bv,
+                               (const uint64_t *)dRem, (const uint32_t *)dRemCnt, (uint32_t)(max_edges * 2), l);
+            HIP_TRY_B(hipGetLastError());
+        }
+        if ((int)lvl[(size_t)(end - 1)] > cur_max) { cur_max = lvl[(size_t)(end - 1)]; entry = (int)(end - 1); } // :832-836
+        pos = end;
+        batch_no++;
+    }
+    hipLaunchKernelGGL(hnsw_dev::build_compact_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (int32_t *)idx->dNbr0, n, S0);
+    if (rowsU > 0)
+        hipLaunchKernelGGL(hnsw_dev::build_compact_kernel, dim3((unsigned)((rowsU + 3) / 4)), dim3(256), 0, st, (int32_t *)idx->dNbrU, rowsU, SU);
+    HIP_TRY_B(hipGetLastError());
+    HIP_TRY_B(hipStreamSynchronize(st));
+
+    idx->iv.max_layer = cur_max; idx->iv.entry_point = entry;
+    {
+        hnsw_index_info &inf = idx->info;
+        inf.n = n; inf.d = d; inf.metric = p->metric; inf.id_base = p->id_base; inf.max_degree0 = S0;
+        inf.max_degree = SU; inf.max_layer = cur_max; inf.entry_point = (int64_t)entry + p->id_base;
+        inf.device_bytes = (int64_t)(xbytes + (size_t)n * S0 * 4 + (size_t)std::max<int64_t>(rowsU, 1) * SU * 4 + (size_t)n * 5);
+        inf.row_stride_bytes = stride * 4; inf.device = device;
+    }
+done:
+    for (void *q : {dNodes, dRecOf, dRecNode, dCandId, dCandKey, dCandCnt, dEdges, dEdgesSorted, dRem, dRemCnt, dTemp}) if (q) (void)hipFree(q);
+    for (int k = 0; k < 2; ++k) {
+        if (hp_nodes[k]) (void)hipHostFree(hp_nodes[k]);
+        if (hp_rec_of[k]) (void)hipHostFree(hp_rec_of[k]);
+        if (hp_rec_node[k]) (void)hipHostFree(hp_rec_node[k]);
+        if (ev[k]) (void)hipEventDestroy(ev[k]);
+    }
+    if (st) (void)hipStreamDestroy(st);
+    if (rc) { hnsw_index_destroy(idx); return rc; }
+    *out = idx;
+    return HNSW_OK;
+}
+
+// ---- export (the inverse of hnsw_index_create's flatten) ------------------------------------------
+int32_t hnsw_index_export_layer0(const hnsw_index *idx, int32_t *deg0, int32_t *nbr0) {
+    if (!idx || !deg0 || !nbr0) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(idx->device));
+    const int64_t n = idx->iv.n; const int S0 = idx->iv.S0; const int base = idx->iv.id_base;
+    HIP_TRY(hipMemcpy(nbr0, idx->dNbr0, (size_t)n * S0 * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) {
+        int w = 0;
+        int32_t *row = nbr0 + i * S0;
+        for (int j = 0; j < S0; ++j) if (row[j] >= 0) row[w++] = row[j] + base;
+        deg0[i] = w;
+        for (int j = w; j < S0; ++j) row[j] = -1;
+    }
+    return HNSW_OK;
+}
+
+int32_t hnsw_index_export_upper_count(const hnsw_index *idx, int32_t layer, int64_t *n_nodes) {
+    if (!idx || !n_nodes) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    if (layer < 1 || layer > idx->iv.max_layer) return fail(HNSW_ERR_BAD_ARG, "layer %d out of range", layer);
+    HIP_TRY(hipSetDevice(idx->device));
+    std::vector<uint8_t> lvl((size_t)idx->iv.n);
+    HIP_TRY(hipMemcpy(lvl.data(), idx->dLvl, (size_t)idx->iv.n, hipMemcpyDeviceToHost));
+    int64_t c = 0;
+    for (int64_t i = 0; i < idx->iv.n; ++i) c += lvl[(size_t)i] >= layer;
+    *n_nodes = c;
+    return HNSW_OK;
+}
+
+int32_t hnsw_index_export_upper(const hnsw_index *idx, int32_t layer, int64_t *nodes, int32_t *deg, int32_t *nbr) {
+    if (!idx || !nodes || !deg || !nbr) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    if (layer < 1 || layer > idx->iv.max_layer) return fail(HNSW_ERR_BAD_ARG, "layer %d out of range", layer);
+    HIP_TRY(hipSetDevice(idx->device));
+    const int64_t n = idx->iv.n; const int SU = idx->iv.SU; const int base = idx->iv.id_base;
+    std::vector<uint8_t> lvl((size_t)n);
+    std::vector<int32_t> off((size_t)n), rows((size_t)std::max<int64_t>(idx->rowsU, 1) * SU);
+    HIP_TRY(hipMemcpy(lvl.data(), idx->dLvl, (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(off.data(), idx->dOff, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rows.data(), idx->dNbrU, rows.size() * 4, hipMemcpyDeviceToHost));
+    int64_t s = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (lvl[(size_t)i] < layer) continue;
+        const int32_t *row = &rows[((size_t)off[(size_t)i] + (layer - 1)) * SU];
+        int w = 0;
+        for (int j = 0; j < SU; ++j) if (row[j] >= 0) nbr[s * SU + w++] = row[j] + base;
+        for (int j = w; j < SU; ++j) nbr[s * SU + j] = -1;
+        nodes[s] = i + base; deg[s] = w;
+        s++;
+    }
+    return HNSW_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,327 @@
+// hnsw_build_device.hip.h -- gfx950 kernels of the batched graph builder.
+//
+// The reference builds one node at a time (Ohnsw.insert, lib/ohnsw.ml:766-837; Hnsw_algo
+// insert_knowing_node, lib/hnsw_algo.ml:629-713).  Here a batch of nodes is inserted against the
+// graph as it stood at batch start, with the same per-node steps:
+//   K1 build_search   descent with search_one to level+1 (:785-789), then search_k with
+//                     efConstruction on every layer <= level, each seeded with the whole W of the
+//                     layer above (:806-816)
+//   K2 build_select   select_neighbours (lib/ohnsw.ml:647-663; M on upper layers, 2M on layer 0,
+//                     :818-819) and set_connections_for_new_node's forward half (:198-199)
+//   (sort)            the back-links (neighbour, new node), grouped per neighbour
+//   K4 build_merge    back-links (:200-202) and, for a neighbour pushed past its cap, the shrink
+//                     by select_neighbours with the neighbour as base (:821-829)
+//   K5 build_unlink   the symmetric removals of Graph.set_connections (:190-192)
+// Rows may carry -1 holes between batches (the search kernels skip them); build_compact closes
+// them at the end.  Everything is deterministic: no result depends on atomic arrival order.
+#pragma once
+
+#include "hnsw_device.hip.h"
+
+namespace hnsw_dev {
+
+struct BuildView {
+    IndexView iv;            // tables being built (nbr0 / nbrU are written through the pointers below)
+    int32_t *nbr0_w;
+    int32_t *nbrU_w;
+    int32_t efc;             // efConstruction
+    int32_t cand_stride;     // >= efc
+    int32_t vt_bits;
+};
+
+struct BatchView {
+    const int32_t *nodes;    // [B] node ids of the batch
+    const int32_t *rec_of;   // [B][lcap] record index of (batch slot, layer) or -1
+    int32_t B, lcap;
+    int32_t cur_max_layer;   // graph state at batch start
+    int32_t entry;
+    int32_t *cand_id;        // [nrec][cand_stride]
+    uint32_t *cand_key;      // [nrec][cand_stride]
+    int32_t *cand_cnt;       // [nrec]
+};
+
+__device__ __forceinline__ int32_t *row_ptr_w(const BuildView &bv, int layer, int node, int &width) {
+    if (layer == 0) { width = bv.iv.S0; return bv.nbr0_w + (int64_t)node * bv.iv.S0; }
+    width = bv.iv.SU;
+    return bv.nbrU_w + ((int64_t)bv.iv.upper_off[node] + (layer - 1)) * bv.iv.SU;
+}
+
+// ---- K1: construction search ---------------------------------------------------------------------
+template <int NCH, int RB, int NSLOT, int METRIC>
+__global__ void __launch_bounds__(64)
+build_search_kernel(const BuildView bv, const BatchView bt) {
+    extern __shared__ uint32_t lds[];
+    const IndexView &iv = bv.iv;
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+    if (i >= bt.B) return;
+    const WaveCtx cx = make_ctx(lds, bv.vt_bits, lane);
+    const int q = bt.nodes[i];
+    const int lvl = iv.upper_lvl[q];
+
+    float4 qv[NCH];
+    load_row<NCH>(qv, iv, q, cx.l16);
+    visited_clear(cx);                                         // lib/ohnsw.ml:780
+    uint32_t n_dist = 0, n_hops = 0, status = 0;
+
+    int cur = bt.entry;
+    if (lane == 0) cx.cand_id[0] = cur;
+    __syncthreads();
+    eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, 1, cx.r, cx.l16);
+    __syncthreads();
+    uint32_t cur_key = cx.cand_key[0];
+
+    const int top = bt.cur_max_layer;
+    if (lvl < top) greedy_descend<NCH, RB, METRIC>(iv, qv, top, lvl + 1, cur, cur_key, cx, n_dist); // :785-789
+
+    WList<NSLOT> w;
+    wlist_init(w);
+    wlist_insert(w, cur_key, (uint32_t)cur, bv.efc, lane, cx.ovf, status);                 // :802
+    if (lane == 0) cx.vt[vt_slot(cx, (uint32_t)cur)] = (uint32_t)cur;
+    __syncthreads();
+
+    for (int layer = (lvl < top ? lvl : top); layer >= 0; --layer) {                         // :806
+        // the start queue of this layer is the whole W of the layer above (:814-816): every
+        // member becomes unexpanded again.  The visited cache is NOT cleared: a node evaluated
+        // on an upper layer is either in W or rejected for good (max(W) never grows).
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s)
+            if (w.hi[s] != KEY_INF || w.lo[s] != KEY_INF) w.lo[s] &= ~1u;
+        w.ovf_cnt = 0;
+        search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, layer, w, bv.efc, cx, n_dist, n_hops, status); // :811
+        const int rec = bt.rec_of[(int64_t)i * bt.lcap + layer];
+        if (rec >= 0) {
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const int idx = s * 64 + lane;
+                if (idx < w.count) {
+                    bt.cand_id[(int64_t)rec * bv.cand_stride + idx] = (int32_t)(w.lo[s] >> 1);
+                    bt.cand_key[(int64_t)rec * bv.cand_stride + idx] = w.hi[s];
+                }
+            }
+            if (lane == 0) bt.cand_cnt[rec] = w.count;
+        }
+    }
+}
+
+// ---- select_neighbours heuristic (lib/ohnsw.ml:647-663) -------------------------------------------
+// Candidates (LDS c_id / c_key, ascending by (distance to the base, id)) are popped nearest first;
+// e is kept iff e.d < distance(value kept, value e) for every kept neighbour (:657-659); stops at R
+// kept (:660).  Kept ids go to LDS k_id in selection order.  Returns the count.
+template <int NCH, int METRIC>
+__device__ __forceinline__ int select_heuristic(const IndexView &iv, const int32_t *c_id,
+                                                const uint32_t *c_key, int nc, int R, int32_t *k_id,
+                                                int lane) {
+    const int r = lane >> 4, l16 = lane & 15;
+    const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
+    const int64_t stride4 = iv.stride >> 2;
+    int kept = 0;
+    for (int i = 0; i < nc && kept < R; ++i) {
+        const int c = c_id[i];
+        const uint32_t ckey = c_key[i];
+        float4 cv[NCH];
+        load_row<NCH>(cv, iv, c, l16);
+        bool reject = false;
+        for (int base = 0; base < kept && !reject; base += 4) {
+            const int j = base + r;
+            const bool valid = j < kept;
+            const int s = valid ? k_id[j] : 0;
+            const float4 *row = X4 + (int64_t)s * stride4;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const int ch = t * 16 + l16;
+                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid && ch < iv.nchunks) z = row[ch];
+                if (METRIC == 0) {
+                    float dx = z.x - cv[t].x; acc = __builtin_fmaf(dx, dx, acc);
+                    float dy = z.y - cv[t].y; acc = __builtin_fmaf(dy, dy, acc);
+                    float dz = z.z - cv[t].z; acc = __builtin_fmaf(dz, dz, acc);
+                    float dw = z.w - cv[t].w; acc = __builtin_fmaf(dw, dw, acc);
+                } else {
+                    acc = __builtin_fmaf(z.x, cv[t].x, acc);
+                    acc = __builtin_fmaf(z.y, cv[t].y, acc);
+                    acc = __builtin_fmaf(z.z, cv[t].z, acc);
+                    acc = __builtin_fmaf(z.w, cv[t].w, acc);
+                }
+            }
+            acc = reduce16(acc);
+            const uint32_t key_cs = dist_to_key<METRIC>(acc);
+            reject = __ballot(valid && !(ckey < key_cs)) != 0ull;      // :657-659, strict
+        }
+        if (!reject) {
+            __syncthreads();
+            if (lane == 0) k_id[kept] = c;
+            __syncthreads();
+            kept++;
+        }
+    }
+    return kept;
+}
+
+// ---- K2: select for the new nodes, write their rows, emit back-link keys ---------------------------
+struct SelectArgs {
+    const int32_t *rec_node; // [nrec] node of each record
+    int32_t rec_begin, rec_end, layer, R;
+    uint64_t *edges;         // [(rec_end-rec_begin)][R] keys (neighbour << 32 | new node), ~0 = none
+};
+
+template <int NCH, int METRIC>
+__global__ void __launch_bounds__(64)
+build_select_kernel(const BuildView bv, const BatchView bt, const SelectArgs sa) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    const int rec = sa.rec_begin + blockIdx.x;
+    if (rec >= sa.rec_end) return;
+    int32_t *c_id = reinterpret_cast<int32_t *>(lds);                 // [cand_stride]
+    uint32_t *c_key = lds + bv.cand_stride;                           // [cand_stride]
+    int32_t *k_id = reinterpret_cast<int32_t *>(lds + 2 * bv.cand_stride); // [64]
+    const int q = sa.rec_node[rec];
+    const int nc = bt.cand_cnt[rec];
+    for (int j = lane; j < nc; j += 64) {
+        c_id[j] = bt.cand_id[(int64_t)rec * bv.cand_stride + j];
+        c_key[j] = bt.cand_key[(int64_t)rec * bv.cand_stride + j];
+    }
+    __syncthreads();
+    const int kept = select_heuristic<NCH, METRIC>(bv.iv, c_id, c_key, nc, sa.R, k_id, lane);
+    __syncthreads();
+    int width;
+    int32_t *row = row_ptr_w(bv, sa.layer, q, width);
+    // the reference conses: Neighbours.iter order is the reverse of the selection order
+    if (lane < width) row[lane] = lane < kept ? k_id[kept - 1 - lane] : -1;
+    uint64_t *e = sa.edges + (int64_t)(rec - sa.rec_begin) * sa.R;
+    if (lane < sa.R) e[lane] = lane < kept ? (((uint64_t)(uint32_t)k_id[lane] << 32) | (uint32_t)q) : ~0ull;
+}
+
+// ---- K4: back-links and shrink ----------------------------------------------------------------------
+struct MergeArgs {
+    const uint64_t *edges;   // sorted ascending; ~0 entries last
+    int32_t n_edges, layer, R;
+    uint64_t *removals;      // (node << 32 | neighbour to drop from node's row)
+    uint32_t *rem_cnt;
+    uint32_t rem_cap;
+};
+
+constexpr int PEND_CAP = 64;
+
+template <int NCH, int RB, int METRIC>
+__global__ void __launch_bounds__(64)
+build_merge_kernel(const BuildView bv, const MergeArgs ma) {
+    __shared__ int32_t u_id[128];     // union: pending new nodes + old row
+    __shared__ uint32_t u_key[128];
+    __shared__ int32_t s_id[128];     // sorted union
+    __shared__ uint32_t s_key[128];
+    __shared__ int32_t k_id[64];
+    const IndexView &iv = bv.iv;
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x;
+    if (e >= ma.n_edges) return;
+    const uint64_t key = ma.edges[e];
+    if (key == ~0ull) return;
+    const int nb = (int)(key >> 32);
+    if (e > 0 && (int)(ma.edges[e - 1] >> 32) == nb) return;          // not the head of its segment
+
+    // pending new links of nb (ascending new-node id); beyond PEND_CAP they are refused
+    int np = 0;
+    {
+        const int j = e + lane;
+        const bool mine = j < ma.n_edges && (int)(ma.edges[j] >> 32) == nb && ma.edges[j] != ~0ull;
+        const uint64_t m = __ballot(mine);
+        np = __popcll(m);                                               // contiguous from lane 0
+        if (mine) u_id[lane] = (int)(ma.edges[j] & 0xFFFFFFFFu);
+        for (int j2 = e + 64; j2 < ma.n_edges; ++j2) {                   // rare: hub with > 64 new links
+            const uint64_t k2 = ma.edges[j2];
+            if (k2 == ~0ull || (int)(k2 >> 32) != nb) break;
+            if (lane == 0) {
+                const uint32_t slot = atomicAdd(ma.rem_cnt, 1u);
+                if (slot < ma.rem_cap) ma.removals[slot] = ((k2 & 0xFFFFFFFFull) << 32) | (uint32_t)nb;
+            }
+        }
+    }
+    int width;
+    int32_t *row = row_ptr_w(bv, ma.layer, nb, width);
+    const int old = lane < width ? row[lane] : -1;
+    const bool ovalid = old >= 0;
+    const uint64_t om = __ballot(ovalid);
+    const int no = __popcll(om);
+    const int opos = __popcll(om & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (ovalid) u_id[np + opos] = old;
+    __syncthreads();
+    const int nu = np + no;
+
+    if (nu <= ma.R) {
+        // Neighbours.add conses (lib/ohnsw.ml:116-118): the latest link comes first
+        int v = -1;
+        if (lane < np) v = u_id[np - 1 - lane];
+        else if (lane < nu) v = u_id[lane];
+        __syncthreads();
+        if (lane < width) row[lane] = v;
+        return;
+    }
+
+    // shrink (lib/ohnsw.ml:823-828): distances of the union to nb, ascending (d, id), heuristic
+    float4 qv[NCH];
+    load_row<NCH>(qv, iv, nb, lane & 15);
+    eval_candidates<NCH, RB, METRIC>(iv, qv, u_id, u_key, nu, lane >> 4, lane & 15);
+    __syncthreads();
+    for (int j = lane; j < nu; j += 64) {                               // rank sort, nu <= 128
+        const uint64_t mk = ((uint64_t)u_key[j] << 32) | (uint32_t)u_id[j];
+        int rank = 0;
+        for (int t = 0; t < nu; ++t) {
+            const uint64_t ok = ((uint64_t)u_key[t] << 32) | (uint32_t)u_id[t];
+            rank += ok < mk;
+        }
+        s_id[rank] = u_id[j];
+        s_key[rank] = u_key[j];
+    }
+    __syncthreads();
+    const int kept = select_heuristic<NCH, METRIC>(iv, s_id, s_key, nu, ma.R, k_id, lane);
+    __syncthreads();
+    if (lane < width) row[lane] = lane < kept ? k_id[kept - 1 - lane] : -1;
+    // dropped members lose their link to nb (Graph.set_connections step 2, lib/ohnsw.ml:190-192)
+    for (int j = lane; j < nu; j += 64) {
+        const int x = s_id[j];
+        bool in = false;
+        for (int t = 0; t < kept; ++t) in = in || (k_id[t] == x);
+        if (!in) {
+            const uint32_t slot = atomicAdd(ma.rem_cnt, 1u);
+            if (slot < ma.rem_cap) ma.removals[slot] = ((uint64_t)(uint32_t)x << 32) | (uint32_t)nb;
+        }
+    }
+}
+
+// ---- K5: symmetric removals -------------------------------------------------------------------------
+__global__ void build_unlink_kernel(const BuildView bv, const uint64_t *removals, const uint32_t *rem_cnt,
+                                    uint32_t rem_cap, int layer) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = *rem_cnt;
+    if (n > rem_cap) n = rem_cap;
+    if (t >= n) return;
+    const uint64_t rk = removals[t];
+    const int x = (int)(rk >> 32), nb = (int)(rk & 0xFFFFFFFFu);
+    int width;
+    int32_t *row = row_ptr_w(bv, layer, x, width);
+    for (int j = 0; j < width; ++j)
+        if (row[j] == nb) row[j] = -1;
+}
+
+// ---- final: close the holes, keep row order ----------------------------------------------------------
+__global__ void __launch_bounds__(256) build_compact_kernel(int32_t *rows, int64_t nrows, int width) {
+    __shared__ int32_t tmp[4][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t rrow = (int64_t)blockIdx.x * 4 + wv;
+    if (rrow >= nrows) return;
+    int32_t *row = rows + rrow * width;
+    const int v = lane < width ? row[lane] : -1;
+    const uint64_t m = __ballot(v >= 0);
+    const int pos = __popcll(m & ((1ull << lane) - 1ull));
+    const int cnt = __popcll(m);
+    if (v >= 0) tmp[wv][pos] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < width) row[lane] = lane < cnt ? tmp[wv][lane] : -1;
+}
+
+} // namespace hnsw_dev

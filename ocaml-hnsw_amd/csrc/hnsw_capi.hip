@@ -4,21 +4,13 @@
 // Hnsw.Ba.Hgraph.t lib/hnsw.ml:342-348, as handed over by the OCaml shim) into HBM-resident
 // tables and launches the gfx950 kernels of hnsw_device.hip.h.  No CPU fallback: without a
 // usable device every compute entry point fails with HNSW_ERR_NO_DEVICE.
-#include "../../include/hnsw_mi355x.h"
-#include "hnsw_device.hip.h"
-
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
+#include "hnsw_internal.h"
 
 using hnsw_dev::IndexView;
 using hnsw_dev::SearchArgs;
+using namespace hnsw_host;
 
-namespace {
+namespace hnsw_host {
 
 thread_local std::string g_last_error;
 
@@ -32,49 +24,37 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e__ = (expr);                                                             \
-        if (e__ != hipSuccess)                                                               \
-            return fail(e__ == hipErrorOutOfMemory ? HNSW_ERR_OOM : HNSW_ERR_HIP,            \
-                        "%s failed: %s", #expr, hipGetErrorString(e__));                     \
-    } while (0)
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return HNSW_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        HIP_TRY(hipMalloc(&p, bytes));
-        cap = bytes;
+int upload_vectors(const float *vectors, int64_t n, int d, int64_t row_stride, void **dX, size_t *bytes) {
+    const int64_t stride = padded_stride(d);
+    const size_t xbytes = (size_t)std::max<int64_t>(n, 1) * stride * sizeof(float);
+    *bytes = xbytes;
+    if (hipMalloc(dX, xbytes) != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_OOM, "hipMalloc(%zu) for vectors failed", xbytes); }
+    if (n == 0) return HNSW_OK;
+    if (stride == row_stride) {
+        if (hipMemcpy(*dX, vectors, xbytes, hipMemcpyHostToDevice) != hipSuccess) return fail(HNSW_ERR_HIP, "vector upload failed");
         return HNSW_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-int env_int(const char *name, int dflt) {
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
+    const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / (stride * 4));
+    std::vector<float> stage((size_t)chunk_rows * stride);
+    for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+        const int64_t nr = std::min(chunk_rows, n - r0);
+        std::fill(stage.begin(), stage.begin() + (size_t)nr * stride, 0.0f);
+        for (int64_t i = 0; i < nr; ++i)
+            memcpy(&stage[(size_t)i * stride], vectors + (r0 + i) * row_stride, sizeof(float) * (size_t)d);
+        if (hipMemcpy((float *)*dX + r0 * stride, stage.data(), (size_t)nr * stride * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(HNSW_ERR_HIP, "vector upload failed");
+    }
+    return HNSW_OK;
 }
 
-} // namespace
-
-struct hnsw_index {
-    int device = -1;
-    IndexView iv{};
-    hnsw_index_info info{};
-    void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr;
-    DevBuf sQ, sIds, sDist, sNd, sNh, sSt; // scratch for the host-buffer entry points
-    int vt_bits_override = 0;
-};
+} // namespace hnsw_host
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
 namespace {
 
 template <int NCH, int RB, int NSLOT, int METRIC>
 hipError_t launch_search(const IndexView &iv, const SearchArgs &a, hipStream_t st) {
-    const size_t lds = ((size_t)(1u << a.vt_bits) + 128 + hnsw_dev::OVF_CAP) * sizeof(uint32_t);
+    const size_t lds = hnsw_dev::wave_lds_words(a.vt_bits) * sizeof(uint32_t);
     hipLaunchKernelGGL((hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, METRIC>), dim3((unsigned)a.nq),
                        dim3(64), lds, st, iv, a);
     return hipGetLastError();
@@ -102,15 +82,6 @@ hipError_t dispatch_nch(int nch, int nslot, const IndexView &iv, const SearchArg
     }
 }
 
-int pick_nch(int nchunks) {
-    const int per_lane = (nchunks + 15) / 16;
-    for (int c : {1, 2, 4, 8, 16}) if (per_lane <= c) return c;
-    return 0;
-}
-int pick_nslot(int ef) {
-    for (int s : {1, 2, 4, 8, 16}) if (ef <= 64 * s) return s;
-    return 0;
-}
 
 template <int METRIC>
 hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq,
@@ -157,7 +128,7 @@ int default_vt_bits(const hnsw_index *idx, int ef) {
 extern "C" {
 
 int32_t hnsw_abi_version(void) { return HNSW_ABI_VERSION; }
-const char *hnsw_last_error(void) { return g_last_error.c_str(); }
+const char *hnsw_last_error(void) { return hnsw_host::g_last_error.c_str(); }
 
 int32_t hnsw_device_count(int32_t *count) {
     if (!count) return fail(HNSW_ERR_BAD_ARG, "null count");
@@ -244,25 +215,9 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
     auto bail = [&](int code) { hnsw_index_destroy(idx); return code; };
 
     // ---- vectors: rows zero-padded to a multiple of 64 B so every float4 chunk is in bounds ----
-    const int64_t stride = ((int64_t)d->d + 15) / 16 * 16;
-    const size_t xbytes = (size_t)std::max<int64_t>(n, 1) * stride * sizeof(float);
-    if (hipMalloc(&idx->dX, xbytes) != hipSuccess) { (void)hipGetLastError(); return bail(fail(HNSW_ERR_OOM, "hipMalloc(%zu) for vectors failed", xbytes)); }
-    if (n > 0) {
-        if (stride == d->row_stride) {
-            if (hipMemcpy(idx->dX, d->vectors, xbytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(HNSW_ERR_HIP, "vector upload failed"));
-        } else {
-            const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / (stride * 4));
-            std::vector<float> stage((size_t)chunk_rows * stride);
-            for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
-                const int64_t nr = std::min(chunk_rows, n - r0);
-                std::fill(stage.begin(), stage.begin() + (size_t)nr * stride, 0.0f);
-                for (int64_t i = 0; i < nr; ++i)
-                    memcpy(&stage[(size_t)i * stride], d->vectors + (r0 + i) * d->row_stride, sizeof(float) * (size_t)d->d);
-                if (hipMemcpy((float *)idx->dX + r0 * stride, stage.data(), (size_t)nr * stride * 4, hipMemcpyHostToDevice) != hipSuccess)
-                    return bail(fail(HNSW_ERR_HIP, "vector upload failed"));
-            }
-        }
-    }
+    const int64_t stride = padded_stride(d->d);
+    size_t xbytes = 0;
+    { int rcv = upload_vectors(d->vectors, n, d->d, d->row_stride, &idx->dX, &xbytes); if (rcv) return bail(rcv); }
     auto upload = [&](void **dst, const void *src, size_t bytes) -> bool {
         if (hipMalloc(dst, std::max<size_t>(bytes, 16)) != hipSuccess) return false;
         return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
@@ -279,6 +234,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
     iv.nbrU = (const int32_t *)idx->dNbrU; iv.upper_off = (const int32_t *)idx->dOff;
     iv.upper_lvl = (const uint8_t *)idx->dLvl;
     iv.max_layer = d->max_layer; iv.entry_point = (int32_t)ep; iv.id_base = base;
+    idx->rowsU = rowsU;
 
     hnsw_index_info &inf = idx->info;
     inf.n = n; inf.d = d->d; inf.metric = d->metric; inf.id_base = base; inf.max_degree0 = S0;

@@ -237,126 +237,175 @@ __device__ __forceinline__ int wlist_pop_unexpanded(WList<NSLOT> &w, int lane) {
     return c;
 }
 
-// ---- the search kernel ---------------------------------------------------------------------
-template <int NCH, int RB, int NSLOT, int METRIC>
-__global__ void __launch_bounds__(64)
-hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
-    extern __shared__ uint32_t lds[];
-    const int vt_size = 1 << a.vt_bits;
-    uint32_t *vt = lds;                                        // visited cache
-    int32_t *cand_id = reinterpret_cast<int32_t *>(lds + vt_size); // [64]
-    uint32_t *cand_key = lds + vt_size + 64;                   // [64]
-    uint32_t *ovf = lds + vt_size + 128;                       // [OVF_CAP]
+// ---- per-wave scratch in LDS -------------------------------------------------------------------
+struct WaveCtx {
+    int lane, r, l16;
+    uint32_t *vt;        // visited cache, 1 << vt_bits entries
+    uint32_t vt_shift;   // 32 - vt_bits
+    int32_t *cand_id;    // [64]
+    uint32_t *cand_key;  // [64]
+    uint32_t *ovf;       // [OVF_CAP]
+};
+__host__ __device__ inline size_t wave_lds_words(int vt_bits) { return ((size_t)1 << vt_bits) + 128 + OVF_CAP; }
+__device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane) {
+    WaveCtx cx;
+    cx.lane = lane; cx.r = lane >> 4; cx.l16 = lane & 15;
+    cx.vt = lds; cx.vt_shift = 32u - (uint32_t)vt_bits;
+    cx.cand_id = reinterpret_cast<int32_t *>(lds + ((size_t)1 << vt_bits));
+    cx.cand_key = lds + ((size_t)1 << vt_bits) + 64;
+    cx.ovf = lds + ((size_t)1 << vt_bits) + 128;
+    return cx;
+}
+__device__ __forceinline__ void visited_clear(const WaveCtx &cx) { // Visited.clear, lib/ohnsw.ml:262
+    const int n = 1 << (32 - cx.vt_shift);
+    for (int i = cx.lane; i < n; i += 64) cx.vt[i] = 0xFFFFFFFFu;
+}
+__device__ __forceinline__ uint32_t vt_slot(const WaveCtx &cx, uint32_t id) { return (id * 0x9E3779B1u) >> cx.vt_shift; }
 
-    const int lane = threadIdx.x;
-    const int r = lane >> 4, l16 = lane & 15;
-    const int64_t q = blockIdx.x;
-    if (q >= a.nq) return;
+// neighbour row of node c on `layer` (Graph.adjacent, lib/ohnsw.ml:171); -1 = hole / padding
+__device__ __forceinline__ int adj_entry(const IndexView &iv, int layer, int c, int lane) {
+    if (layer == 0) return lane < iv.S0 ? iv.nbr0[(int64_t)c * iv.S0 + lane] : -1;
+    const int off = iv.upper_off[c];
+    const int lvl = iv.upper_lvl[c];
+    return (lane < iv.SU && layer <= lvl) ? iv.nbrU[((int64_t)off + (layer - 1)) * iv.SU + lane] : -1;
+}
 
-    // query -> registers (zero beyond d)
-    float4 qv[NCH];
-    {
-        const float *qp = a.Q + q * a.q_stride;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int e0 = 4 * (i * 16 + l16);
-            qv[i].x = (e0 + 0 < iv.d) ? qp[e0 + 0] : 0.f;
-            qv[i].y = (e0 + 1 < iv.d) ? qp[e0 + 1] : 0.f;
-            qv[i].z = (e0 + 2 < iv.d) ? qp[e0 + 2] : 0.f;
-            qv[i].w = (e0 + 3 < iv.d) ? qp[e0 + 3] : 0.f;
-        }
-    }
-    for (int i = lane; i < vt_size; i += 64) vt[i] = 0xFFFFFFFFu; // Visited.clear
-    const uint32_t vt_shift = 32u - (uint32_t)a.vt_bits;
-
-    uint32_t n_dist = 0, n_hops = 0, status = 0;
-
-    // ---- entry point ----
-    int cur = iv.entry_point;
-    if (lane == 0) cand_id[0] = cur;
-    __syncthreads();
-    eval_candidates<NCH, RB, METRIC>(iv, qv, cand_id, cand_key, 1, r, l16);
-    __syncthreads();
-    uint32_t cur_key = cand_key[0];
-    n_dist += 1;
-
-    // ---- descent: Ohnsw.search_one_simple on layers max_layer..1 (lib/ohnsw.ml:865-867) ----
-    for (int layer = iv.max_layer; layer >= 1; --layer) {
+// Ohnsw.search_one_simple (lib/ohnsw.ml:492-508) on layers `from` down to `to` (inclusive):
+// scan ALL neighbours of the current best, move to the first-in-row-order strictly closer one,
+// repeat until no change.  No visited set (argument ignored, :493).
+template <int NCH, int RB, int METRIC>
+__device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4 (&qv)[NCH], int from,
+                                               int to, int &cur, uint32_t &cur_key, const WaveCtx &cx,
+                                               uint32_t &n_dist) {
+    for (int layer = from; layer >= to; --layer) {
         for (;;) {
-            const int off = iv.upper_off[cur];
-            const int lvl = iv.upper_lvl[cur];
-            int nb = -1;
-            if (lane < iv.SU && layer <= lvl) nb = iv.nbrU[((int64_t)off + (layer - 1)) * iv.SU + lane];
+            const int nb = adj_entry(iv, layer, cur, cx.lane);
             const bool valid = nb >= 0;
             const uint64_t m = __ballot(valid);
             const int cnt = __popcll(m);
             if (cnt == 0) break;
-            const int pos = __popcll(m & ((1ull << lane) - 1ull));
+            const int pos = __popcll(m & ((1ull << cx.lane) - 1ull));
             __syncthreads();
-            if (valid) cand_id[pos] = nb;
+            if (valid) cx.cand_id[pos] = nb;
             __syncthreads();
-            eval_candidates<NCH, RB, METRIC>(iv, qv, cand_id, cand_key, cnt, r, l16);
+            eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cnt, cx.r, cx.l16);
             __syncthreads();
             n_dist += cnt;
-            // first-in-row-order minimum (strict '<' while scanning, lib/ohnsw.ml:502)
-            uint64_t best = (lane < cnt) ? (((uint64_t)cand_key[lane] << 32) | (uint32_t)lane) : ~0ull;
+            uint64_t best = (cx.lane < cnt) ? (((uint64_t)cx.cand_key[cx.lane] << 32) | (uint32_t)cx.lane) : ~0ull;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
                 const uint64_t other = __shfl_xor(best, o);
                 best = other < best ? other : best;
             }
             const uint32_t bkey = (uint32_t)(best >> 32);
-            if (bkey < cur_key) { cur = cand_id[(int)(best & 63u)]; cur_key = bkey; }
+            if (bkey < cur_key) { cur = cx.cand_id[(int)(best & 63u)]; cur_key = bkey; } // strict, :502
             else break;
         }
     }
+}
 
-    // ---- layer 0: Ohnsw.search_k (lib/ohnsw.ml:543-588) ----
-    WList<NSLOT> w;
-    wlist_init(w);
-    wlist_insert(w, cur_key, (uint32_t)cur, a.ef, lane, ovf, status);   // :555-557 seeds W
-    if (lane == 0) vt[((uint32_t)cur * 0x9E3779B1u) >> vt_shift] = (uint32_t)cur;
-    __syncthreads();
-
+// Ohnsw.search_k (lib/ohnsw.ml:543-588) on one layer.  On entry W holds the start nodes
+// (all unexpanded = the start queue, :555-559); on exit W is the ef nearest found.
+template <int NCH, int RB, int NSLOT, int METRIC>
+__device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (&qv)[NCH], int layer,
+                                             WList<NSLOT> &w, int ef, const WaveCtx &cx,
+                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+    const int lane = cx.lane;
     for (;;) {
         int c = wlist_pop_unexpanded(w, lane);                           // :565
         if (c < 0) {
             // no unexpanded member of W: only entries evicted while tied with max(W) can still
             // satisfy "not (c.d > max(W).d)" (:568)
-            if (w.ovf_cnt > 0 && w.count == a.ef && w.ovf_key == w.wmax) c = (int)ovf[--w.ovf_cnt];
+            if (w.ovf_cnt > 0 && w.count == ef && w.ovf_key == w.wmax) c = (int)cx.ovf[--w.ovf_cnt];
             else break;
         }
         n_hops++;
-        int nb = -1;
-        if (lane < iv.S0) nb = iv.nbr0[(int64_t)c * iv.S0 + lane];       // Graph.adjacent, :570
+        const int nb = adj_entry(iv, layer, c, lane);                    // Graph.adjacent, :570
         const bool valid = nb >= 0;
-        const uint32_t slot = ((uint32_t)nb * 0x9E3779B1u) >> vt_shift;
-        const bool seen = valid && (vt[slot] == (uint32_t)nb);           // Visited.mem, :571
+        const uint32_t slot = vt_slot(cx, (uint32_t)nb);
+        const bool seen = valid && (cx.vt[slot] == (uint32_t)nb);        // Visited.mem, :571
         const bool fresh = valid && !seen;
         const uint64_t m = __ballot(fresh);
         const int cnt = __popcll(m);
         if (cnt == 0) continue;
         const int pos = __popcll(m & ((1ull << lane) - 1ull));
         __syncthreads();
-        if (fresh) { vt[slot] = (uint32_t)nb; cand_id[pos] = nb; }       // Visited.add, :572
+        if (fresh) { cx.vt[slot] = (uint32_t)nb; cx.cand_id[pos] = nb; } // Visited.add, :572
         __syncthreads();
-        eval_candidates<NCH, RB, METRIC>(iv, qv, cand_id, cand_key, cnt, r, l16); // :573
+        eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cnt, cx.r, cx.l16); // :573
         __syncthreads();
         n_dist += cnt;
-        const uint32_t my_key = (lane < cnt) ? cand_key[lane] : KEY_INF;
-        const uint32_t my_id = (lane < cnt) ? (uint32_t)cand_id[lane] : 0u;
+        const uint32_t my_key = (lane < cnt) ? cx.cand_key[lane] : KEY_INF;
+        const uint32_t my_id = (lane < cnt) ? (uint32_t)cx.cand_id[lane] : 0u;
         // :574 accept iff |W| < ef or d < max(W).d -- tested in row order against the CURRENT W
-        uint64_t pass = __ballot(lane < cnt && (w.count < a.ef || my_key < w.wmax));
+        uint64_t pass = __ballot(lane < cnt && (w.count < ef || my_key < w.wmax));
         while (pass) {
             const int i = __builtin_ctzll(pass);
             pass &= pass - 1;
             const uint32_t kd = rdlane(my_key, i);
-            if (w.count == a.ef && !(kd < w.wmax)) continue;
-            wlist_insert(w, kd, rdlane(my_id, i), a.ef, lane, ovf, status);    // :575-577
+            if (w.count == ef && !(kd < w.wmax)) continue;
+            wlist_insert(w, kd, rdlane(my_id, i), ef, lane, cx.ovf, status);   // :575-577
         }
     }
+}
 
-    // ---- results: W[0..k) ascending (lib/ohnsw.ml:886-893) ----
+template <int NCH>
+__device__ __forceinline__ void load_query(float4 (&qv)[NCH], const float *qp, int d, int l16) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {   // zero beyond d
+        const int e0 = 4 * (i * 16 + l16);
+        qv[i].x = (e0 + 0 < d) ? qp[e0 + 0] : 0.f;
+        qv[i].y = (e0 + 1 < d) ? qp[e0 + 1] : 0.f;
+        qv[i].z = (e0 + 2 < d) ? qp[e0 + 2] : 0.f;
+        qv[i].w = (e0 + 3 < d) ? qp[e0 + 3] : 0.f;
+    }
+}
+// a database row as the query (rows are zero padded to the stride)
+template <int NCH>
+__device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv, int node, int l16) {
+    const float4 *row = reinterpret_cast<const float4 *>(iv.X) + (int64_t)node * (iv.stride >> 2);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 16 + l16;
+        qv[i] = (c < iv.nchunks) ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// ---- the search kernel: Ohnsw.knn (lib/ohnsw.ml:859-875) per query -------------------------------
+template <int NCH, int RB, int NSLOT, int METRIC>
+__global__ void __launch_bounds__(64)
+hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    if (q >= a.nq) return;
+    const WaveCtx cx = make_ctx(lds, a.vt_bits, lane);
+
+    float4 qv[NCH];
+    load_query<NCH>(qv, a.Q + q * a.q_stride, iv.d, cx.l16);
+    visited_clear(cx);
+
+    uint32_t n_dist = 0, n_hops = 0, status = 0;
+
+    // entry point
+    int cur = iv.entry_point;
+    if (lane == 0) cx.cand_id[0] = cur;
+    __syncthreads();
+    eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, 1, cx.r, cx.l16);
+    __syncthreads();
+    uint32_t cur_key = cx.cand_key[0];
+    n_dist += 1;
+
+    greedy_descend<NCH, RB, METRIC>(iv, qv, iv.max_layer, 1, cur, cur_key, cx, n_dist);   // :865-867
+
+    WList<NSLOT> w;
+    wlist_init(w);
+    wlist_insert(w, cur_key, (uint32_t)cur, a.ef, lane, cx.ovf, status);   // :871, seeds W :555-557
+    if (lane == 0) cx.vt[vt_slot(cx, (uint32_t)cur)] = (uint32_t)cur;
+    __syncthreads();
+    search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
+
+    // results: W[0..k) ascending (lib/ohnsw.ml:886-893)
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int idx = s * 64 + lane;
@@ -386,15 +435,7 @@ hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64
     const int64_t q = blockIdx.x;
     if (q >= nq) return;
     float4 qv[NCH];
-    const float *qp = Q + q * q_stride;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int e0 = 4 * (i * 16 + l16);
-        qv[i].x = (e0 + 0 < iv.d) ? qp[e0 + 0] : 0.f;
-        qv[i].y = (e0 + 1 < iv.d) ? qp[e0 + 1] : 0.f;
-        qv[i].z = (e0 + 2 < iv.d) ? qp[e0 + 2] : 0.f;
-        qv[i].w = (e0 + 3 < iv.d) ? qp[e0 + 3] : 0.f;
-    }
+    load_query<NCH>(qv, Q + q * q_stride, iv.d, l16);
     const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
     const int64_t stride4 = iv.stride >> 2;
     for (int base = blockIdx.y * 4; base < m; base += 4 * gridDim.y) {

@@ -1,0 +1,110 @@
+"""GPU graph builder (batched restatement of Ohnsw.build_batch_bigarray, lib/ohnsw.ml:766-857):
+structural invariants of the reference's graphs, search parity on the built graph, determinism,
+and quality next to the sequential CPU restatement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import ocaml_hnsw_amd as H
+    H.load()
+    assert H.device_count() >= 1
+    return H
+
+
+def _uniform(n, d, seed):
+    return np.random.default_rng(seed).uniform(-1, 1, size=(n, d)).astype(np.float32)
+
+
+def _oracle_graph(o, hg):
+    up = [(nodes, deg, nbr) for nodes, deg, nbr in hg.upper]
+    return o.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, up)
+
+
+@pytest.fixture(scope="module")
+def built(H, oracle):
+    X = _uniform(20000, 32, 1)
+    hg = H.Ohnsw.build_batch_bigarray(X, 8, 100, seed=7).export()
+    return X, hg
+
+
+def test_structure(H, oracle, built):
+    X, hg = built
+    M = 8
+    n = hg.n
+    assert hg.nbr0.shape == (n, 2 * M) and hg.deg0.max() <= 2 * M          # lib/ohnsw.ml:818
+    rows = [hg.nbr0[i, :hg.deg0[i]] for i in range(n)]
+    sets = [set(r.tolist()) for r in rows]
+    assert all(len(s) == len(r) for s, r in zip(sets, rows))                # no duplicate links
+    assert all(i not in s for i, s in enumerate(sets))                      # no self links
+    assert all(i in sets[j] for i in range(n) for j in sets[i])             # symmetric (:217-225)
+    assert (hg.deg0 > 0).mean() > 0.999
+    for nodes, deg, nbr in hg.upper:
+        assert deg.max() <= M
+        slot = {int(v): s for s, v in enumerate(nodes)}
+        for s, v in enumerate(nodes):
+            for u in nbr[s, :deg[s]]:
+                assert int(v) in nbr[slot[int(u)], :deg[slot[int(u)]]]
+    # same level law and RNG as the CPU restatement: identical layer membership for one seed
+    sp = oracle.Space.l2(X[:3000])
+    g = oracle.build_ohnsw(sp, M, 20, seed=7)
+    for l, (nodes, _, _) in enumerate(g.upper):
+        mine = hg.upper[l][0]
+        np.testing.assert_array_equal(nodes, mine[mine < 3000])
+
+
+def test_search_parity_on_built_graph(H, oracle, built):
+    X, hg = built
+    Q = _uniform(300, 32, 2)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    g = _oracle_graph(oracle, hg)
+    ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=64, counters=True)
+    oids, odist, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=10, ef=64, ties=oracle.TIES_CANONICAL, counters=True)
+    np.testing.assert_array_equal(ids, oids)
+    np.testing.assert_array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    np.testing.assert_array_equal(nh, onh)
+
+
+def test_quality_next_to_sequential_builder(H, oracle, built):
+    X, hg = built
+    Q = _uniform(300, 32, 3)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    gt, _ = oracle.brute_force_knn(sp, Q, 10)
+    ids, _ = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=64)
+    rec_gpu = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(ids.tolist(), gt.tolist())])
+    g = oracle.build_ohnsw(sp, 8, 100, seed=7)
+    oids, _ = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=10, ef=64)
+    rec_cpu = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(oids.tolist(), gt.tolist())])
+    print("recall@10 ef=64: gpu-built %.3f, sequential cpu-built %.3f; mean deg0 %.1f vs %.1f"
+          % (rec_gpu, rec_cpu, hg.deg0.mean(), g.deg0.mean()))
+    assert rec_gpu >= rec_cpu - 0.03
+
+
+def test_deterministic(H, built):
+    X, hg = built
+    again = H.Ohnsw.build_batch_bigarray(X, 8, 100, seed=7).export()
+    np.testing.assert_array_equal(hg.nbr0, again.nbr0)
+    for a, b in zip(hg.upper, again.upper):
+        np.testing.assert_array_equal(a[2], b[2])
+    assert hg.entry_point == again.entry_point
+
+
+@pytest.mark.parametrize("n,d,M,efc,metric", [(1, 8, 4, 10, 0), (2, 8, 4, 10, 0), (50, 5, 4, 16, 0),
+                                             (3000, 100, 16, 64, 1), (1500, 200, 6, 40, 0)])
+def test_small_and_odd_shapes(H, oracle, n, d, M, efc, metric):
+    X = _uniform(n, d, 4)
+    if metric:
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    hg = H.Ohnsw.build_batch_bigarray(X, M, efc, seed=1, metric=metric).export()
+    sets = [set(hg.nbr0[i, :hg.deg0[i]].tolist()) for i in range(n)]
+    assert all(i in sets[j] for i in range(n) for j in sets[i])
+    sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
+    g = _oracle_graph(oracle, hg)
+    k = min(5, n)
+    ids, dist = H.Ohnsw.knn_batch_bigarray(hg, k, X[:20], ef=max(k, 20))
+    oids, odist = oracle.Ohnsw.knn_batch_bigarray(g, sp, X[:20], k=k, ef=max(k, 20), ties=oracle.TIES_CANONICAL)
+    np.testing.assert_array_equal(ids, oids)
+    np.testing.assert_array_equal(dist.view(np.uint32), odist.view(np.uint32))
