@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/s of the MI355X HNSW search path on BASELINE.json's headline config.
+
+Workload (configs[1], "C2"): SIFT1M-shaped synthetic data -- n = 1,000,000 x d = 128 clustered
+integers 0..218 stored as fp32, M = 16, efConstruction = 200; search ef = 128, k = 10, a batch of
+10,000 queries per GPU.  One step = one pass of the hot path (Ohnsw.knn_batch_bigarray,
+lib/ohnsw.ml:877-897) over the batch, queries already resident in HBM; with N > 1 every rank
+holds a replica of the index, searches its own 10,000-query shard and the per-shard results are
+all-gathered over RCCL (weak scaling: per-GPU work fixed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  The oracle (oracle/) is used only as the checker and as the
+`cpu_baseline` leg (a single-thread C restatement of the reference's OCaml CPU path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured streaming)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def make_sift_like(n, d, seed, device, n_centres=4096, sigma=25.0):
+    """Clustered integers 0..218 as fp32: Gaussian blobs, clipped, rounded."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)   # centres shared by base and query sets
+    centres = torch.randint(20, 200, (n_centres, d), generator=g, device=device).float()
+    g.manual_seed(seed)
+    out = torch.empty((n, d), dtype=torch.float32, device=device)
+    step = 1 << 18
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        idx = torch.randint(0, n_centres, (m,), generator=g, device=device)
+        noise = torch.randn((m, d), generator=g, device=device) * sigma
+        out[s:s + m] = torch.clamp(torch.round(centres[idx] + noise), 0, 218)
+    return out
+
+
+def brute_force_topk(X, Q, k):
+    """exact ground truth on the GPU (ids), integer data => exact fp32 arithmetic"""
+    xn = (X * X).sum(1)
+    ids = []
+    for s in range(0, Q.shape[0], 256):
+        q = Q[s:s + 256]
+        d2 = xn[None, :] - 2.0 * (q @ X.T) + (q * q).sum(1)[:, None]
+        ids.append(torch.topk(d2, k, dim=1, largest=False).indices)
+    return torch.cat(ids).cpu().numpy()
+
+
+def recall_ids(got, gt):
+    return float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got.tolist(), gt.tolist())]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--nq", type=int, default=10_000, help="queries per GPU per step")
+    ap.add_argument("--M", type=int, default=16)
+    ap.add_argument("--efc", type=int, default=200)
+    ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--cpu-sample", type=int, default=4000, help="queries timed on the CPU restatement")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+    import ocaml_hnsw_amd as H
+    H.load()
+    if H.device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the search path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n, d, nq, k, ef = args.n, args.d, args.nq, args.k, args.ef
+    t0 = time.time()
+    Xd = make_sift_like(n, d, seed=1, device=dev)
+    # every rank searches its own shard of the global batch of world * nq queries
+    Qall = make_sift_like(world * nq, d, seed=2, device=dev)
+    Qd = Qall[rank * nq:(rank + 1) * nq].contiguous()
+    X = Xd.cpu().numpy()
+    log("data: n=%d d=%d nq/gpu=%d (%.1fs)" % (n, d, nq, time.time() - t0))
+
+    # ---- index: built on the GPU by rank 0, replicated to every rank ----
+    t0 = time.time()
+    if rank == 0:
+        hg = H.Ohnsw.build_batch_bigarray(X, args.M, args.efc, seed=1, device=local_rank)
+        build_s = time.time() - t0
+        log("graph built on the GPU in %.1fs (max_layer %d)" % (build_s, hg.max_layer))
+        if world > 1 or not args.no_cpu:
+            hg.export()
+    if world > 1:
+        meta = torch.zeros(3, dtype=torch.int64, device=dev)
+        if rank == 0:
+            meta[0], meta[1] = hg.max_layer, hg.entry_point
+        dist.broadcast(meta, 0)
+        max_layer, entry = int(meta[0]), int(meta[1])
+        deg0 = torch.from_numpy(hg.deg0).to(dev) if rank == 0 else torch.empty(n, dtype=torch.int32, device=dev)
+        nbr0 = torch.from_numpy(hg.nbr0).to(dev) if rank == 0 else torch.empty((n, 2 * args.M), dtype=torch.int32, device=dev)
+        dist.broadcast(deg0, 0)
+        dist.broadcast(nbr0, 0)
+        upper = []
+        for l in range(max_layer):
+            cnt = torch.tensor([len(hg.upper[l][0]) if rank == 0 else 0], dtype=torch.int64, device=dev)
+            dist.broadcast(cnt, 0)
+            c = int(cnt[0])
+            if rank == 0:
+                nodes, dg, nb = (torch.from_numpy(a).to(dev) for a in hg.upper[l])
+            else:
+                nodes = torch.empty(c, dtype=torch.int64, device=dev)
+                dg = torch.empty(c, dtype=torch.int32, device=dev)
+                nb = torch.empty((c, args.M), dtype=torch.int32, device=dev)
+            for t in (nodes, dg, nb):
+                dist.broadcast(t, 0)
+            upper.append((nodes.cpu().numpy(), dg.cpu().numpy(), nb.cpu().numpy()))
+        if rank != 0:
+            hg = H.Hgraph(X, deg0.cpu().numpy(), nbr0.cpu().numpy(), upper, entry_point=entry, id_base=0,
+                          max_degree=args.M).to_device(local_rank)
+        del deg0, nbr0
+
+    # ---- device buffers; the kernel is launched on torch's current stream ----
+    ids_d = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    dist_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    nd_d = torch.zeros(nq, dtype=torch.int32, device=dev)
+    nh_d = torch.zeros(nq, dtype=torch.int32, device=dev)
+    if world > 1:
+        all_ids = torch.empty((world * nq, k), dtype=torch.int32, device=dev)
+        all_dist = torch.empty((world * nq, k), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def search(ef_, counters=False):
+        H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef_, k, ids_d.data_ptr(), dist_d.data_ptr(),
+                              nd_d.data_ptr() if counters else 0, nh_d.data_ptr() if counters else 0,
+                              0, stream.cuda_stream)
+
+    def step(ef_):
+        search(ef_)
+        if world > 1:   # the exchange step: per-shard results -> every rank
+            dist.all_gather_into_tensor(all_ids, ids_d)
+            dist.all_gather_into_tensor(all_dist, dist_d)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(ef_, steps, warmup):
+        for _ in range(warmup):
+            step(ef_)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        sync()
+        t = time.perf_counter()
+        for i in range(steps):
+            ev[i][0].record(stream)
+            search(ef_)
+            ev[i][1].record(stream)
+            if world > 1:
+                dist.all_gather_into_tensor(all_ids, ids_d)
+                dist.all_gather_into_tensor(all_dist, dist_d)
+        sync()
+        wall = time.perf_counter() - t
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        if world > 1:
+            w = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            wall = float(w[0])
+        return wall, kern_ms
+
+    wall, kern_ms = timed(ef, args.steps, args.warmup)
+    qps = world * nq * args.steps / wall
+    log("ef=%d: %.0f q/s, %.3f ms/step, kernel %.3f ms" % (ef, qps, 1e3 * wall / args.steps, kern_ms))
+
+    # ---- recall@10 on rank 0 (exact ground truth on the GPU) ----
+    checks = {}
+    search(ef, counters=True)
+    torch.cuda.synchronize()
+    got = ids_d.cpu().numpy()
+    got_dist = dist_d.cpu().numpy()
+    gpu_nd = nd_d.cpu().numpy().astype(np.int64)
+    gpu_nh = nh_d.cpu().numpy().astype(np.int64)
+    ef_ok, qps_ok = None, None
+    if rank == 0:
+        ns = min(1000, nq)
+        gt = brute_force_topk(Xd, Qd[:ns], k)
+        rec = recall_ids(got[:ns], gt)
+        checks["recall_at_10"] = round(rec, 4)
+        log("recall@10 at ef=%d: %.4f" % (ef, rec))
+    if world == 1 and checks["recall_at_10"] < 0.95:
+        # do not tune the data to the gate -- report the ef that reaches it alongside
+        for ef2 in (160, 192, 256, 320, 384, 512, 768, 1024):
+            search(ef2)
+            torch.cuda.synchronize()
+            r2 = recall_ids(ids_d.cpu().numpy()[:ns], gt)
+            if r2 >= 0.95:
+                w2, _ = timed(ef2, max(3, args.steps // 2), 1)
+                ef_ok, qps_ok = ef2, nq * max(3, args.steps // 2) / w2
+                checks["ef_for_recall_0.95"] = ef2
+                checks["recall_at_that_ef"] = round(r2, 4)
+                checks["qps_at_that_ef"] = round(qps_ok, 1)
+                log("recall@10 >= 0.95 first reached at ef=%d (%.4f): %.0f q/s" % (ef2, r2, qps_ok))
+                break
+
+    # ---- algorithmic bytes from the CPU oracle's counters on the same graph/queries,
+    #      parity spot-check, and the CPU baseline (rank 0) ----
+    roofline, cpu_baseline = None, None
+    if rank == 0:
+        S = 2 * args.M
+        n_dist_mean, n_hops_mean = float(gpu_nd.mean()), float(gpu_nh.mean())
+        src = "gpu counters (include re-evaluations)"
+        if not args.no_cpu:
+            from oracle import oracle as o
+            sample = min(args.cpu_sample if world == 1 else 500, nq)
+            Qs = Qd[:sample].cpu().numpy()
+            sp = o.Space.l2(X, arith=o.TREE16)
+            g = o.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, hg.upper)
+            t = time.perf_counter()
+            oids, odist, ond, onh = o.Ohnsw.knn_batch_bigarray(g, sp, Qs, k=k, ef=ef, ties=o.TIES_CANONICAL, counters=True)
+            cpu_s = time.perf_counter() - t
+            n_dist_mean, n_hops_mean = float(ond.mean()), float(onh.mean())
+            src = "oracle counters on %d queries" % sample
+            checks["parity_queries"] = sample
+            checks["parity_ids_equal"] = bool(np.array_equal(oids, got[:sample]))
+            checks["parity_dist_bits_equal"] = bool(np.array_equal(odist.view(np.uint32), got_dist[:sample].view(np.uint32)))
+            checks["gpu_reevaluation_overhead"] = round(float(gpu_nd[:sample].mean() / max(ond.mean(), 1) - 1), 4)
+            if world == 1:
+                cpu_baseline = {"value": round(sample / cpu_s, 1), "unit": "queries/s", "cores": 1, "kind": "port",
+                                "sample": "%d of the %d queries, same graph, ef=%d k=%d, single-thread C restatement "
+                                          "of Ohnsw.knn_batch_bigarray (not OCaml)" % (sample, nq, ef, k)}
+            log("cpu restatement: %.1f q/s on %d queries; parity ids=%s dist=%s" %
+                (sample / cpu_s, sample, checks["parity_ids_equal"], checks["parity_dist_bits_equal"]))
+        # B_q = n_dist*(4d+4) + n_hops*4S + 4d + 8k   
+        bq = n_dist_mean * (4 * d + 4) + n_hops_mean * 4 * S + 4 * d + 8 * k
+        achieved = bq * nq / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                if tj.get("workload") == "C2" and tj.get("nq") == nq and tj.get("ef") == ef:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": "hnsw_search_kernel<2,4,2,0>", "kernel_ms": round(kern_ms, 4),
+                    "bytes_per_query": round(bq, 1), "n_dist_per_query": round(n_dist_mean, 1),
+                    "n_hops_per_query": round(n_hops_mean, 1), "counters": src}
+
+    if rank == 0:
+        out = {
+            "metric": "queries/sec at recall@10>=0.95, SIFT1M d=128 ef=128 k=10",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C2: SIFT1M-shaped synthetic (n=%d d=%d clustered ints 0..218), M=%d efConstruction=%d "
+                                   "(graph built on the GPU), ef=%d k=%d, %d queries per GPU per step, replicated index%s"
+                                   % (n, d, args.M, args.efc, ef, k, nq,
+                                      ", RCCL all-gather of results" if world > 1 else ""),
+                       "n": n, "d": d, "M": args.M, "ef_construction": args.efc, "ef": ef, "k": k,
+                       "queries_per_gpu": nq, "global_batch": world * nq, "parallelism": "replica x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "checks": checks,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

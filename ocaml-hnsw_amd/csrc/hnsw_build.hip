@@ -45,9 +45,9 @@ template <int METRIC>
 hipError_t dispatch_k1(int nch, int nslot, const BuildView &bv, const BatchView &bt, hipStream_t st) {
     switch (nch) {
     case 1: return launch_k1<1, 8, METRIC>(nslot, bv, bt, st);
-    case 2: return launch_k1<2, 8, METRIC>(nslot, bv, bt, st);
-    case 4: return launch_k1<4, 4, METRIC>(nslot, bv, bt, st);
-    case 8: return launch_k1<8, 2, METRIC>(nslot, bv, bt, st);
+    case 2: return launch_k1<2, 4, METRIC>(nslot, bv, bt, st);
+    case 4: return launch_k1<4, 2, METRIC>(nslot, bv, bt, st);
+    case 8: return launch_k1<8, 1, METRIC>(nslot, bv, bt, st);
     default: return launch_k1<16, 1, METRIC>(nslot, bv, bt, st);
     }
 }
@@ -69,9 +69,9 @@ hipError_t dispatch_k4(int nch, const BuildView &bv, const MergeArgs &ma, hipStr
     dim3 grid((unsigned)ma.n_edges), block(64);
     switch (nch) {
     case 1: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<1, 8, METRIC>), grid, block, 0, st, bv, ma); break;
-    case 2: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<2, 8, METRIC>), grid, block, 0, st, bv, ma); break;
-    case 4: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<4, 4, METRIC>), grid, block, 0, st, bv, ma); break;
-    case 8: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<8, 2, METRIC>), grid, block, 0, st, bv, ma); break;
+    case 2: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<2, 4, METRIC>), grid, block, 0, st, bv, ma); break;
+    case 4: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<4, 2, METRIC>), grid, block, 0, st, bv, ma); break;
+    case 8: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<8, 1, METRIC>), grid, block, 0, st, bv, ma); break;
     default: hipLaunchKernelGGL((hnsw_dev::build_merge_kernel<16, 1, METRIC>), grid, block, 0, st, bv, ma); break;
     }
     return hipGetLastError();
@@ -170,6 +170,7 @@ int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_strid
     bv.efc = efc; bv.cand_stride = cand_stride;
     bv.vt_bits = 8;
     while ((1 << bv.vt_bits) < 16 * efc && bv.vt_bits < 13) ++bv.vt_bits;
+    while (bv.vt_bits < 15 && ((int64_t)1 << (bv.vt_bits + 16)) < n) ++bv.vt_bits;
 
     HIP_TRY_B(hipStreamCreate(&st));
     HIP_TRY_B(hipMalloc(&dNodes, (size_t)bmax * 4));

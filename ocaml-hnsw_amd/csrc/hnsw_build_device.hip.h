@@ -77,7 +77,7 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
     WList<NSLOT> w;
     wlist_init(w);
     wlist_insert(w, cur_key, (uint32_t)cur, bv.efc, lane, cx.ovf, status);                 // :802
-    if (lane == 0) cx.vt[vt_slot(cx, (uint32_t)cur)] = (uint32_t)cur;
+    if (lane == 0) visited_add(cx, vt_hash(cx, (uint32_t)cur));
     __syncthreads();
 
     for (int layer = (lvl < top ? lvl : top); layer >= 0; --layer) {                         // :806

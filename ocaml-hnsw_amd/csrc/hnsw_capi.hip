@@ -75,9 +75,9 @@ template <int METRIC>
 hipError_t dispatch_nch(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st) {
     switch (nch) {
     case 1: return dispatch_slot<1, 8, METRIC>(nslot, iv, a, st);
-    case 2: return dispatch_slot<2, 8, METRIC>(nslot, iv, a, st);
-    case 4: return dispatch_slot<4, 4, METRIC>(nslot, iv, a, st);
-    case 8: return dispatch_slot<8, 2, METRIC>(nslot, iv, a, st);
+    case 2: return dispatch_slot<2, 4, METRIC>(nslot, iv, a, st);
+    case 4: return dispatch_slot<4, 2, METRIC>(nslot, iv, a, st);
+    case 8: return dispatch_slot<8, 1, METRIC>(nslot, iv, a, st);
     default: return dispatch_slot<16, 1, METRIC>(nslot, iv, a, st);
     }
 }
@@ -114,12 +114,14 @@ int check_params(const hnsw_index *idx, const hnsw_search_params *p) {
 int default_vt_bits(const hnsw_index *idx, int ef) {
     int b = idx->vt_bits_override ? idx->vt_bits_override : env_int("HNSW_VT_BITS", 0);
     if (b <= 0) {
-        // ~25 evaluations per unit of ef; a cache of about half of them keeps the
-        // re-evaluation rate low at 8 KiB/wave for ef = 128
+        // ~25 evaluations per unit of ef; 16 * ef two-byte tags = 4 KiB/wave at
+        // ef = 128, small enough for 32 waves per CU
         b = 8;
         while ((1 << b) < 16 * ef && b < 13) ++b;
     }
-    return std::max(4, std::min(14, b));
+    b = std::max(4, std::min(15, b));
+    while (b < 15 && ((int64_t)1 << (b + 16)) < idx->iv.n) ++b;   // tags must identify ids exactly
+    return b;
 }
 
 } // namespace

@@ -99,51 +99,83 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // ---- row evaluation ------------------------------------------------------------------------
 // Distances of the cnt candidates listed in LDS cand_id[] to the query held in qv; the ordered
 // key of candidate ci is written to LDS cand_key[ci].
+//
+// NB batches of 4 rows, straight-line: all ids are read from LDS first, then all NB*NCH
+// global_load_dwordx4 are issued, then consumed.  A group whose candidate index is past cnt
+// re-reads the row of group 0 of its batch (same addresses: coalesced, no extra traffic) and its
+// result is dropped, so no load sits behind an exec-mask branch.  Row offsets are 32-bit in
+// float4 units (tables up to 64 GiB).
+template <int NCH, int NB, int METRIC, bool FULL>
+__device__ __forceinline__ void eval_nb(const IndexView &iv, const float4 (&qv)[NCH],
+                                        const int32_t *cand_id, uint32_t *cand_key, int base,
+                                        int cnt, int r, int l16) {
+    const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
+    const uint32_t stride4 = (uint32_t)(iv.stride >> 2);
+    uint32_t row4[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int ci = base + 4 * b + r;
+        const int ce = ci < cnt ? ci : base + 4 * b;
+        row4[b] = (uint32_t)cand_id[ce] * stride4;
+    }
+    float4 v[NB][NCH];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 16 + l16;
+            if (FULL) v[b][i] = X4[row4[b] + (uint32_t)c];
+            else v[b][i] = X4[row4[b] + (uint32_t)(c < iv.nchunks ? c : 0)];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float4 z = v[b][i];
+            if (!FULL) {  // lanes past the row end: make them add exactly 0 (their qv is 0)
+                const bool cv = (i * 16 + l16) < iv.nchunks;
+                z.x = cv ? z.x : 0.f; z.y = cv ? z.y : 0.f; z.z = cv ? z.z : 0.f; z.w = cv ? z.w : 0.f;
+            }
+            if (METRIC == 0) {
+                float dx = z.x - qv[i].x; acc = __builtin_fmaf(dx, dx, acc);
+                float dy = z.y - qv[i].y; acc = __builtin_fmaf(dy, dy, acc);
+                float dz = z.z - qv[i].z; acc = __builtin_fmaf(dz, dz, acc);
+                float dw = z.w - qv[i].w; acc = __builtin_fmaf(dw, dw, acc);
+            } else {
+                acc = __builtin_fmaf(z.x, qv[i].x, acc);
+                acc = __builtin_fmaf(z.y, qv[i].y, acc);
+                acc = __builtin_fmaf(z.z, qv[i].z, acc);
+                acc = __builtin_fmaf(z.w, qv[i].w, acc);
+            }
+        }
+        acc = reduce16(acc);
+        const int ci = base + 4 * b + r;
+        if (l16 == 0 && ci < cnt) cand_key[ci] = dist_to_key<METRIC>(acc);
+    }
+}
+
+template <int NCH, int RB, int METRIC, bool FULL>
+__device__ __forceinline__ void eval_full(const IndexView &iv, const float4 (&qv)[NCH],
+                                          const int32_t *cand_id, uint32_t *cand_key, int cnt,
+                                          int r, int l16) {
+    for (int base = 0; base < cnt;) {
+        const int nbb = (cnt - base + 3) >> 2;   // wave-uniform
+        if (RB >= 8 && nbb >= 8) { eval_nb<NCH, (RB >= 8 ? 8 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 32; }
+        else if (RB >= 4 && nbb >= 4) { eval_nb<NCH, (RB >= 4 ? 4 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 16; }
+        else if (RB >= 4 && nbb == 3) { eval_nb<NCH, (RB >= 4 ? 3 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 12; }
+        else if (RB >= 2 && nbb >= 2) { eval_nb<NCH, (RB >= 2 ? 2 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 8; }
+        else { eval_nb<NCH, 1, METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 4; }
+    }
+}
+
 template <int NCH, int RB, int METRIC>
 __device__ __forceinline__ void eval_candidates(const IndexView &iv, const float4 (&qv)[NCH],
                                                 const int32_t *cand_id, uint32_t *cand_key,
                                                 int cnt, int r, int l16) {
-    const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
-    const int64_t stride4 = iv.stride >> 2;
-    for (int base = 0; base < cnt; base += 4 * RB) {
-        float4 v[RB][NCH];
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int ci = base + 4 * b + r;
-            const bool valid = ci < cnt;
-            const int id = valid ? cand_id[ci] : 0;
-            const float4 *row = X4 + (int64_t)id * stride4;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = i * 16 + l16;
-                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid && c < iv.nchunks) z = row[c];
-                v[b][i] = z;
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                // lanes past the row end hold v == 0 and qv == 0: they add exactly 0
-                if (METRIC == 0) {
-                    float dx = v[b][i].x - qv[i].x; acc = __builtin_fmaf(dx, dx, acc);
-                    float dy = v[b][i].y - qv[i].y; acc = __builtin_fmaf(dy, dy, acc);
-                    float dz = v[b][i].z - qv[i].z; acc = __builtin_fmaf(dz, dz, acc);
-                    float dw = v[b][i].w - qv[i].w; acc = __builtin_fmaf(dw, dw, acc);
-                } else {
-                    acc = __builtin_fmaf(v[b][i].x, qv[i].x, acc);
-                    acc = __builtin_fmaf(v[b][i].y, qv[i].y, acc);
-                    acc = __builtin_fmaf(v[b][i].z, qv[i].z, acc);
-                    acc = __builtin_fmaf(v[b][i].w, qv[i].w, acc);
-                }
-            }
-            acc = reduce16(acc);
-            const int ci = base + 4 * b + r;
-            if (l16 == 0 && ci < cnt) cand_key[ci] = dist_to_key<METRIC>(acc);
-        }
-    }
+    if (iv.nchunks == 16 * NCH) eval_full<NCH, RB, METRIC, true>(iv, qv, cand_id, cand_key, cnt, r, l16);
+    else eval_full<NCH, RB, METRIC, false>(iv, qv, cand_id, cand_key, cnt, r, l16);
 }
 
 // ---- W: sorted register-resident list ------------------------------------------------------
@@ -238,29 +270,43 @@ __device__ __forceinline__ int wlist_pop_unexpanded(WList<NSLOT> &w, int lane) {
 }
 
 // ---- per-wave scratch in LDS -------------------------------------------------------------------
+// Visited cache: 1 << vt_bits 16-bit tags.  h = (id * odd) mod 2^(vt_bits+16) is a bijection on
+// ids below 2^(vt_bits+16); slot = h >> 16, tag = h & 0xFFFF, so (slot, tag) identifies the id
+// exactly: a hit is never a false positive.  Tag 0xFFFF marks an empty slot; ids that hash to it
+// are simply never cached (a false negative, which is harmless -- see the header comment).
 struct WaveCtx {
     int lane, r, l16;
-    uint32_t *vt;        // visited cache, 1 << vt_bits entries
-    uint32_t vt_shift;   // 32 - vt_bits
+    uint16_t *vt;        // visited cache, 1 << vt_bits entries
+    uint32_t vt_mask;    // 2^(vt_bits+16) - 1
+    int vt_entries;
     int32_t *cand_id;    // [64]
     uint32_t *cand_key;  // [64]
     uint32_t *ovf;       // [OVF_CAP]
 };
-__host__ __device__ inline size_t wave_lds_words(int vt_bits) { return ((size_t)1 << vt_bits) + 128 + OVF_CAP; }
+__host__ __device__ inline size_t wave_lds_words(int vt_bits) { return (((size_t)1 << vt_bits) >> 1) + 128 + OVF_CAP; }
 __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane) {
     WaveCtx cx;
     cx.lane = lane; cx.r = lane >> 4; cx.l16 = lane & 15;
-    cx.vt = lds; cx.vt_shift = 32u - (uint32_t)vt_bits;
-    cx.cand_id = reinterpret_cast<int32_t *>(lds + ((size_t)1 << vt_bits));
-    cx.cand_key = lds + ((size_t)1 << vt_bits) + 64;
-    cx.ovf = lds + ((size_t)1 << vt_bits) + 128;
+    cx.vt = reinterpret_cast<uint16_t *>(lds);
+    cx.vt_mask = (vt_bits + 16 >= 32) ? 0xFFFFFFFFu : ((1u << (vt_bits + 16)) - 1u);
+    cx.vt_entries = 1 << vt_bits;
+    uint32_t *rest = lds + (((size_t)1 << vt_bits) >> 1);
+    cx.cand_id = reinterpret_cast<int32_t *>(rest);
+    cx.cand_key = rest + 64;
+    cx.ovf = rest + 128;
     return cx;
 }
 __device__ __forceinline__ void visited_clear(const WaveCtx &cx) { // Visited.clear, lib/ohnsw.ml:262
-    const int n = 1 << (32 - cx.vt_shift);
-    for (int i = cx.lane; i < n; i += 64) cx.vt[i] = 0xFFFFFFFFu;
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(cx.vt);
+    for (int i = cx.lane; i < (cx.vt_entries >> 1); i += 64) w32[i] = 0xFFFFFFFFu;
 }
-__device__ __forceinline__ uint32_t vt_slot(const WaveCtx &cx, uint32_t id) { return (id * 0x9E3779B1u) >> cx.vt_shift; }
+__device__ __forceinline__ uint32_t vt_hash(const WaveCtx &cx, uint32_t id) { return (id * 0x9E3779B1u) & cx.vt_mask; }
+__device__ __forceinline__ bool visited_mem(const WaveCtx &cx, uint32_t h) {       // Visited.mem
+    return cx.vt[h >> 16] == (uint16_t)(h & 0xFFFFu) && (h & 0xFFFFu) != 0xFFFFu;
+}
+__device__ __forceinline__ void visited_add(const WaveCtx &cx, uint32_t h) {       // Visited.add
+    if ((h & 0xFFFFu) != 0xFFFFu) cx.vt[h >> 16] = (uint16_t)(h & 0xFFFFu);
+}
 
 // neighbour row of node c on `layer` (Graph.adjacent, lib/ohnsw.ml:171); -1 = hole / padding
 __device__ __forceinline__ int adj_entry(const IndexView &iv, int layer, int c, int lane) {
@@ -304,13 +350,31 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
     }
 }
 
+// Nearest unexpanded member of W without marking it (the likely next pop): -1 if none.
+template <int NSLOT>
+__device__ __forceinline__ int wlist_peek_unexpanded(const WList<NSLOT> &w) {
+    int c = -1;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        if (c < 0) {
+            const uint64_t m = __ballot((w.lo[s] & 1u) == 0u);
+            if (m) c = (int)(rdlane(w.lo[s], __builtin_ctzll(m)) >> 1);
+        }
+    }
+    return c;
+}
+
 // Ohnsw.search_k (lib/ohnsw.ml:543-588) on one layer.  On entry W holds the start nodes
 // (all unexpanded = the start queue, :555-559); on exit W is the ef nearest found.
+// While the rows of a hop are in flight, the adjacency row of the currently nearest unexpanded
+// candidate is fetched too: if it is still the nearest after this hop's insertions (the common
+// case once the search has converged) the next hop starts without a dependent round trip.
 template <int NCH, int RB, int NSLOT, int METRIC>
 __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (&qv)[NCH], int layer,
                                              WList<NSLOT> &w, int ef, const WaveCtx &cx,
                                              uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
     const int lane = cx.lane;
+    int pref_id = -1, pref_nb = -1;
     for (;;) {
         int c = wlist_pop_unexpanded(w, lane);                           // :565
         if (c < 0) {
@@ -320,17 +384,20 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             else break;
         }
         n_hops++;
-        const int nb = adj_entry(iv, layer, c, lane);                    // Graph.adjacent, :570
+        int nb;
+        if (c == pref_id) nb = pref_nb;                                  // Graph.adjacent, :570
+        else nb = adj_entry(iv, layer, c, lane);
+        pref_id = wlist_peek_unexpanded(w);
+        if (pref_id >= 0) pref_nb = adj_entry(iv, layer, pref_id, lane); // in flight during this hop
         const bool valid = nb >= 0;
-        const uint32_t slot = vt_slot(cx, (uint32_t)nb);
-        const bool seen = valid && (cx.vt[slot] == (uint32_t)nb);        // Visited.mem, :571
-        const bool fresh = valid && !seen;
+        const uint32_t h = vt_hash(cx, (uint32_t)nb);
+        const bool fresh = valid && !visited_mem(cx, h);                 // Visited.mem, :571
         const uint64_t m = __ballot(fresh);
         const int cnt = __popcll(m);
         if (cnt == 0) continue;
         const int pos = __popcll(m & ((1ull << lane) - 1ull));
         __syncthreads();
-        if (fresh) { cx.vt[slot] = (uint32_t)nb; cx.cand_id[pos] = nb; } // Visited.add, :572
+        if (fresh) { visited_add(cx, h); cx.cand_id[pos] = nb; }         // Visited.add, :572
         __syncthreads();
         eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cnt, cx.r, cx.l16); // :573
         __syncthreads();
@@ -401,7 +468,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     WList<NSLOT> w;
     wlist_init(w);
     wlist_insert(w, cur_key, (uint32_t)cur, a.ef, lane, cx.ovf, status);   // :871, seeds W :555-557
-    if (lane == 0) cx.vt[vt_slot(cx, (uint32_t)cur)] = (uint32_t)cur;
+    if (lane == 0) visited_add(cx, vt_hash(cx, (uint32_t)cur));
     __syncthreads();
     search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
 
