@@ -118,33 +118,11 @@ def main():
         if world > 1 or not args.no_cpu:
             hg.export()
     if world > 1:
-        meta = torch.zeros(3, dtype=torch.int64, device=dev)
-        if rank == 0:
-            meta[0], meta[1] = hg.max_layer, hg.entry_point
-        dist.broadcast(meta, 0)
-        max_layer, entry = int(meta[0]), int(meta[1])
-        deg0 = torch.from_numpy(hg.deg0).to(dev) if rank == 0 else torch.empty(n, dtype=torch.int32, device=dev)
-        nbr0 = torch.from_numpy(hg.nbr0).to(dev) if rank == 0 else torch.empty((n, 2 * args.M), dtype=torch.int32, device=dev)
-        dist.broadcast(deg0, 0)
-        dist.broadcast(nbr0, 0)
-        upper = []
-        for l in range(max_layer):
-            cnt = torch.tensor([len(hg.upper[l][0]) if rank == 0 else 0], dtype=torch.int64, device=dev)
-            dist.broadcast(cnt, 0)
-            c = int(cnt[0])
-            if rank == 0:
-                nodes, dg, nb = (torch.from_numpy(a).to(dev) for a in hg.upper[l])
-            else:
-                nodes = torch.empty(c, dtype=torch.int64, device=dev)
-                dg = torch.empty(c, dtype=torch.int32, device=dev)
-                nb = torch.empty((c, args.M), dtype=torch.int32, device=dev)
-            for t in (nodes, dg, nb):
-                dist.broadcast(t, 0)
-            upper.append((nodes.cpu().numpy(), dg.cpu().numpy(), nb.cpu().numpy()))
+        import ocaml_hnsw_amd.sharding as sharding
+        deg0, nbr0, upper, entry = sharding.replicate_graph(dist, dev, hg if rank == 0 else None, args.M)
         if rank != 0:
-            hg = H.Hgraph(X, deg0.cpu().numpy(), nbr0.cpu().numpy(), upper, entry_point=entry, id_base=0,
-                          max_degree=args.M).to_device(local_rank)
-        del deg0, nbr0
+            hg = H.Hgraph(X, deg0, nbr0, upper, entry_point=entry, id_base=0, max_degree=args.M).to_device(local_rank)
+        del deg0, nbr0, upper
 
     # ---- device buffers; the kernel is launched on torch's current stream ----
     ids_d = torch.empty((nq, k), dtype=torch.int32, device=dev)

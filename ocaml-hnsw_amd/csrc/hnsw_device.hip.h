@@ -387,13 +387,14 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         int nb;
         if (c == pref_id) nb = pref_nb;                                  // Graph.adjacent, :570
         else nb = adj_entry(iv, layer, c, lane);
-        pref_id = wlist_peek_unexpanded(w);
-        if (pref_id >= 0) pref_nb = adj_entry(iv, layer, pref_id, lane); // in flight during this hop
         const bool valid = nb >= 0;
         const uint32_t h = vt_hash(cx, (uint32_t)nb);
         const bool fresh = valid && !visited_mem(cx, h);                 // Visited.mem, :571
         const uint64_t m = __ballot(fresh);
         const int cnt = __popcll(m);
+        // issued only now so that it shares its flight with this hop's rows (loads return in order)
+        pref_id = wlist_peek_unexpanded(w);
+        if (pref_id >= 0) pref_nb = adj_entry(iv, layer, pref_id, lane);
         if (cnt == 0) continue;
         const int pos = __popcll(m & ((1ull << lane) - 1ull));
         __syncthreads();
