@@ -1,0 +1,133 @@
+// hnsw_front.hpp -- C++ host-side mirror of the reference's module interface for the search path,
+// over the C ABI of include/hnsw_mi355x.h (header only; link with libhnsw_mi355x.so).
+//
+//   Hnsw::Ohnsw::knn / knn_batch_bigarray / build_batch_bigarray / distance_l2   lib/ohnsw.ml:840-899
+//   Hnsw::Ba::knn / knn_batch                                                    lib/hnsw.ml:763-777
+//
+// Same names, argument meaning and error behaviour: OCaml Invalid_argument -> std::invalid_argument
+// ("knn: empty hgraph", lib/ohnsw.ml:862), Failure -> std::runtime_error.  A `Mat` is a
+// Lacaml.S.mat (dim x n, Fortran layout): in memory n rows of dim contiguous floats.
+#pragma once
+#include "../../include/hnsw_mi355x.h"
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace Hnsw {
+
+struct Mat {
+    const float *data;
+    int64_t dim2; // number of vectors (Lacaml.S.Mat.dim2)
+    int32_t dim1; // dimension (Lacaml.S.Mat.dim1)
+};
+
+inline void check(int rc) {
+    if (rc == HNSW_OK) return;
+    const std::string msg = hnsw_last_error();
+    if (rc == HNSW_ERR_BAD_ARG || rc == HNSW_ERR_EMPTY_INDEX || rc == HNSW_ERR_DEGREE_OVERFLOW) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);
+}
+
+// Flattened Ohnsw.Hgraph.t / Hnsw.Ba.Hgraph.t resident on the device.
+class Hgraph {
+public:
+    Hgraph() = default;
+    Hgraph(const Hgraph &) = delete;
+    Hgraph &operator=(const Hgraph &) = delete;
+    Hgraph(Hgraph &&o) noexcept : h_(o.h_), id_base_(o.id_base_), d_(o.d_) { o.h_ = nullptr; }
+    ~Hgraph() { if (h_) hnsw_index_destroy(h_); }
+
+    // flatten + upload (hnsw_index_create)
+    static Hgraph create(const hnsw_index_desc &desc, int device = 0) {
+        Hgraph g;
+        check(hnsw_index_create(&desc, device, &g.h_));
+        g.id_base_ = desc.id_base; g.d_ = desc.d;
+        return g;
+    }
+    hnsw_index *handle() const { return h_; }
+    int id_base() const { return id_base_; }
+    int dim() const { return d_; }
+
+private:
+    friend struct Builder;
+    hnsw_index *h_ = nullptr;
+    int id_base_ = 0, d_ = 0;
+public:
+    static Hgraph adopt(hnsw_index *h, int id_base, int d) { Hgraph g; g.h_ = h; g.id_base_ = id_base; g.d_ = d; return g; }
+};
+
+struct value_distance { int node; float distance_to_target; }; // lib/hnsw_algo.ml:85
+
+namespace detail {
+inline void search(const Hgraph &g, const Mat &batch, int ef, int k, int fill, std::vector<int32_t> &ids, std::vector<float> &dist) {
+    ids.assign((size_t)batch.dim2 * k, -1);
+    dist.assign((size_t)batch.dim2 * k, 0.f);
+    hnsw_search_params p{ef, k, fill, 0};
+    check(hnsw_search_batch(g.handle(), batch.data, batch.dim2, batch.dim1, &p, ids.data(), dist.data(), nullptr, nullptr));
+}
+} // namespace detail
+
+namespace Ohnsw {
+
+// Ohnsw.build_batch_bigarray distance batch ~num_connections ~num_nodes_search_construction
+// (lib/ohnsw.ml:840-857), batched on the device.
+inline Hgraph build_batch_bigarray(const Mat &batch, int num_connections, int num_nodes_search_construction,
+                                   uint64_t seed = 0, int metric = HNSW_METRIC_L2, int device = 0) {
+    hnsw_build_params p{num_connections, num_nodes_search_construction, metric, 0, seed, 0, 0};
+    hnsw_index *h = nullptr;
+    check(hnsw_build(batch.data, batch.dim2, batch.dim1, batch.dim1, &p, device, &h));
+    return Hgraph::adopt(h, 0, batch.dim1);
+}
+
+// Ohnsw.knn hgraph visited ~k target (lib/ohnsw.ml:859-875): the MinQueue popped ascending.
+inline std::vector<value_distance> knn(const Hgraph &g, int k, const float *target) {
+    std::vector<int32_t> ids; std::vector<float> dist;
+    detail::search(g, Mat{target, 1, g.dim()}, k, k, HNSW_FILL_OHNSW, ids, dist);
+    std::vector<value_distance> out;
+    for (int i = 0; i < k && ids[(size_t)i] >= g.id_base(); ++i) out.push_back({ids[(size_t)i], dist[(size_t)i]});
+    return out;
+}
+
+// Ohnsw.knn_batch_bigarray hgraph ~k batch -> (ids, distances) (lib/ohnsw.ml:877-897):
+// ids nq x k (-1 filled), distances k x nq Fortran = [nq][k] (NaN filled).
+inline std::pair<std::vector<std::vector<int>>, std::vector<float>> knn_batch_bigarray(const Hgraph &g, int k, const Mat &batch) {
+    std::vector<int32_t> ids; std::vector<float> dist;
+    detail::search(g, batch, k, k, HNSW_FILL_OHNSW, ids, dist);
+    std::vector<std::vector<int>> out((size_t)batch.dim2, std::vector<int>((size_t)k));
+    for (int64_t j = 0; j < batch.dim2; ++j) for (int i = 0; i < k; ++i) out[(size_t)j][(size_t)i] = ids[(size_t)(j * k + i)];
+    return {std::move(out), std::move(dist)};
+}
+
+// Ohnsw.distance_l2 a b (lib/ohnsw.ml:899), batched: out[q][j] = distance(batch[q], value ids[q][j])
+inline std::vector<float> distance_l2(const Hgraph &g, const Mat &batch, const int32_t *ids, int m) {
+    std::vector<float> out((size_t)batch.dim2 * m);
+    check(hnsw_distance_batch(g.handle(), batch.data, batch.dim2, batch.dim1, ids, m, out.data()));
+    return out;
+}
+
+} // namespace Ohnsw
+
+namespace Ba {
+
+// Hnsw.Ba.knn hgraph point ~num_neighbours_search ~num_neighbours (lib/hnsw.ml:763-767)
+inline std::vector<value_distance> knn(const Hgraph &g, const float *point, int num_neighbours_search, int num_neighbours) {
+    std::vector<int32_t> ids; std::vector<float> dist;
+    detail::search(g, Mat{point, 1, g.dim()}, num_neighbours_search, num_neighbours, HNSW_FILL_BA, ids, dist);
+    std::vector<value_distance> out;
+    for (int i = 0; i < num_neighbours && ids[(size_t)i] >= g.id_base(); ++i) out.push_back({ids[(size_t)i], dist[(size_t)i]});
+    return out;
+}
+
+// Hnsw.Ba.knn_batch hgraph batch ~num_neighbours_search ~num_neighbours -> distances
+// (lib/hnsw.ml:769-777): k x nq, +inf filled.
+inline std::vector<float> knn_batch(const Hgraph &g, const Mat &batch, int num_neighbours_search, int num_neighbours) {
+    std::vector<int32_t> ids; std::vector<float> dist;
+    detail::search(g, batch, num_neighbours_search, num_neighbours, HNSW_FILL_BA, ids, dist);
+    return dist;
+}
+
+} // namespace Ba
+} // namespace Hnsw

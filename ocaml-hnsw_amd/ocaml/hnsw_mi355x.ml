@@ -1,0 +1,180 @@
+(* hnsw_mi355x.ml -- OCaml side of the drop-in: ctypes-foreign binding of libhnsw_mi355x.so
+   (include/hnsw_mi355x.h) plus the flatten shims that turn the reference's own graph containers
+   into the tables the C ABI takes.
+
+   SOURCE ONLY in this repository: the build image has no OCaml toolchain (no ocaml / opam / dune),
+   so this file is not compiled or tested here; the identical ABI is exercised from Python ctypes
+   (tests/) and C++ (host/hnsw_front.hpp).  It is written against the reference's modules as they
+   are: Ohnsw (lib/ohnsw.ml) and Hnsw.Ba (lib/hnsw.ml:817-819).
+
+   What stays OCaml: the graph builder (Ohnsw.build_batch_bigarray, Hnsw.Ba.build) and every
+   signature.  What moves: the bodies of knn / knn_batch*, i.e. the search_one + search_k loops. *)
+open Ctypes
+open Foreign
+
+let lib = Dl.dlopen ~filename:"libhnsw_mi355x.so" ~flags:[ Dl.RTLD_NOW ]
+
+(* ---- C structs ---------------------------------------------------------------------------- *)
+type layer_desc
+let layer_desc : layer_desc structure typ = structure "hnsw_layer_desc"
+let ld_n_nodes = field layer_desc "n_nodes" int64_t
+let ld_nodes = field layer_desc "nodes" (ptr int64_t)
+let ld_deg = field layer_desc "deg" (ptr int32_t)
+let ld_nbr = field layer_desc "nbr" (ptr int32_t)
+let () = seal layer_desc
+
+type index_desc
+let index_desc : index_desc structure typ = structure "hnsw_index_desc"
+let d_vectors = field index_desc "vectors" (ptr float)
+let d_n = field index_desc "n" int64_t
+let d_d = field index_desc "d" int32_t
+let d_row_stride = field index_desc "row_stride" int64_t
+let d_metric = field index_desc "metric" int32_t
+let d_id_base = field index_desc "id_base" int32_t
+let d_max_degree0 = field index_desc "max_degree0" int32_t
+let d_max_degree = field index_desc "max_degree" int32_t
+let d_max_layer = field index_desc "max_layer" int32_t
+let d_entry_point = field index_desc "entry_point" int64_t
+let d_deg0 = field index_desc "deg0" (ptr int32_t)
+let d_nbr0 = field index_desc "nbr0" (ptr int32_t)
+let d_upper = field index_desc "upper" (ptr layer_desc)
+let () = seal index_desc
+
+type search_params
+let search_params : search_params structure typ = structure "hnsw_search_params"
+let p_ef = field search_params "ef" int32_t
+let p_k = field search_params "k" int32_t
+let p_fill = field search_params "fill" int32_t
+let _p_reserved = field search_params "reserved" int32_t
+let () = seal search_params
+
+type index = unit ptr
+let index : index typ = ptr void
+
+(* ---- entry points (the OCaml 4.x runtime lock is released around the blocking calls) -------- *)
+let hnsw_last_error = foreign ~from:lib "hnsw_last_error" (void @-> returning string)
+let hnsw_index_create =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_index_create"
+    (ptr index_desc @-> int32_t @-> ptr index @-> returning int32_t)
+let hnsw_index_destroy = foreign ~from:lib "hnsw_index_destroy" (index @-> returning int32_t)
+let hnsw_search_batch =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_search_batch"
+    (index @-> ptr float @-> int64_t @-> int64_t @-> ptr search_params @-> ptr int32_t @-> ptr float
+     @-> ptr uint32_t @-> ptr uint32_t @-> returning int32_t)
+
+(* Error convention -> the reference's exceptions (lib/ohnsw.ml:25,343,862) *)
+let check rc =
+  match Int32.to_int rc with
+  | 0 -> ()
+  | -1 | -2 | -3 -> invalid_arg (hnsw_last_error ())   (* BAD_ARG | EMPTY_INDEX | DEGREE_OVERFLOW *)
+  | _ -> failwith (hnsw_last_error ())
+
+(* ---- flatten ------------------------------------------------------------------------------- *)
+module A1 = Bigarray.Array1
+module A2 = Bigarray.Array2
+
+type flat = {
+  deg0 : (int32, Bigarray.int32_elt, Bigarray.c_layout) A1.t;
+  nbr0 : (int32, Bigarray.int32_elt, Bigarray.c_layout) A2.t;   (* n x 2M, iteration order *)
+  upper : ((int64, Bigarray.int64_elt, Bigarray.c_layout) A1.t
+           * (int32, Bigarray.int32_elt, Bigarray.c_layout) A1.t
+           * (int32, Bigarray.int32_elt, Bigarray.c_layout) A2.t) array;
+  entry_point : int;
+  max_layer : int;
+}
+
+(* Ohnsw.Hgraph.t (lib/ohnsw.ml:307-312): every layer is dense over all n nodes (:328-330);
+   Graph.iter_neighbours (:176-180) walks nodes, Neighbours.iter (:127) walks a list head first --
+   exactly the order search_k folds over (:570).  A list longer than its row raises: the C side
+   would refuse it too (HNSW_ERR_DEGREE_OVERFLOW); nothing is ever truncated. *)
+let flatten_ohnsw (h : _ Ohnsw.Hgraph.t) ~num_connections:m : flat =
+  let n = Ohnsw.Hgraph.num_nodes h in
+  let max_layer = Ohnsw.Hgraph.max_layer h in
+  let row g node width (dst : (int32, _, _) A2.t) r =
+    let nb = Ohnsw.Graph.adjacent g node in
+    if Ohnsw.Neighbours.length nb > width then invalid_arg "flatten: degree exceeds row width";
+    let j = ref 0 in
+    Ohnsw.Neighbours.iter nb ~f:(fun e -> dst.{r, !j} <- Int32.of_int e; incr j);
+    !j
+  in
+  let deg0 = A1.create Bigarray.int32 Bigarray.c_layout n in
+  let nbr0 = A2.create Bigarray.int32 Bigarray.c_layout n (2 * m) in
+  A2.fill nbr0 (-1l);
+  let g0 = Ohnsw.Hgraph.layer h 0 in
+  for i = 0 to n - 1 do deg0.{i} <- Int32.of_int (row g0 i (2 * m) nbr0 i) done;
+  let upper =
+    Array.init max_layer (fun l ->
+        let g = Ohnsw.Hgraph.layer h (l + 1) in
+        (* nodes present on the layer: those with links there, plus the entry point *)
+        let present i =
+          Ohnsw.Neighbours.length (Ohnsw.Graph.adjacent g i) > 0
+          || Ohnsw.Hgraph.entry_point h = Some i in
+        let ids = List.filter present (List.init n (fun i -> i)) in
+        let c = List.length ids in
+        let nodes = A1.create Bigarray.int64 Bigarray.c_layout c in
+        let deg = A1.create Bigarray.int32 Bigarray.c_layout c in
+        let nbr = A2.create Bigarray.int32 Bigarray.c_layout c m in
+        A2.fill nbr (-1l);
+        List.iteri (fun s i ->
+            nodes.{s} <- Int64.of_int i;
+            deg.{s} <- Int32.of_int (row g i m nbr s)) ids;
+        (nodes, deg, nbr))
+  in
+  { deg0; nbr0; upper; max_layer;
+    entry_point = (match Ohnsw.Hgraph.entry_point h with Some e -> e | None -> -1) }
+
+(* ---- device-resident index ------------------------------------------------------------------ *)
+type t = { handle : index; k_base : int; dim : int }
+
+let create ?(device = 0) ?(metric = 0) ~id_base ~num_connections:m (vectors : Lacaml.S.mat) (f : flat) : t =
+  (* a Lacaml.S.mat is a Fortran-layout dim x n Bigarray: in memory, n rows of dim floats *)
+  let dim = A2.dim1 vectors and n = A2.dim2 vectors in
+  let layers = CArray.make layer_desc (max 1 f.max_layer) in
+  Array.iteri (fun l (nodes, deg, nbr) ->
+      let ld = CArray.get layers l in
+      setf ld ld_n_nodes (Int64.of_int (A1.dim nodes));
+      setf ld ld_nodes (bigarray_start array1 nodes);
+      setf ld ld_deg (bigarray_start array1 deg);
+      setf ld ld_nbr (bigarray_start array2 nbr)) f.upper;
+  let d = make index_desc in
+  setf d d_vectors (bigarray_start array2 vectors);
+  setf d d_n (Int64.of_int n); setf d d_d (Int32.of_int dim);
+  setf d d_row_stride (Int64.of_int dim);
+  setf d d_metric (Int32.of_int metric); setf d d_id_base (Int32.of_int id_base);
+  setf d d_max_degree0 (Int32.of_int (2 * m)); setf d d_max_degree (Int32.of_int m);
+  setf d d_max_layer (Int32.of_int f.max_layer);
+  setf d d_entry_point (Int64.of_int f.entry_point);
+  setf d d_deg0 (bigarray_start array1 f.deg0); setf d d_nbr0 (bigarray_start array2 f.nbr0);
+  setf d d_upper (CArray.start layers);
+  let out = allocate index null in
+  check (hnsw_index_create (addr d) (Int32.of_int device) out);
+  let t = { handle = !@out; k_base = id_base; dim } in
+  Gc.finalise (fun t -> ignore (hnsw_index_destroy t.handle)) t;
+  t
+
+let search t (batch : Lacaml.S.mat) ~ef ~k ~fill =
+  let nq = A2.dim2 batch in
+  (* results as the reference lays them out: k x nq Fortran = [nq][k] in memory *)
+  let distances = Lacaml.S.Mat.create k nq in
+  let ids = A2.create Bigarray.int32 Bigarray.fortran_layout k nq in
+  let p = make search_params in
+  setf p p_ef (Int32.of_int ef); setf p p_k (Int32.of_int k); setf p p_fill (Int32.of_int fill);
+  check (hnsw_search_batch t.handle (bigarray_start array2 batch) (Int64.of_int nq)
+           (Int64.of_int t.dim) (addr p) (bigarray_start array2 ids)
+           (bigarray_start array2 distances) (from_voidp uint32_t null) (from_voidp uint32_t null));
+  ids, distances
+
+(* ---- the drop-in bodies ---------------------------------------------------------------------- *)
+
+(* Ohnsw.knn_batch_bigarray : 'a Hgraph.t -> k:int -> Lacaml.S.mat -> int array array * Lacaml.S.mat
+   (lib/ohnsw.ml:877-897): same signature once the index handle is cached next to the hgraph. *)
+let ohnsw_knn_batch_bigarray (t : t) ~k (batch : Lacaml.S.mat) =
+  let ids32, distances = search t batch ~ef:k ~k ~fill:0 (* NaN / -1, :880-881 *) in
+  let nq = A2.dim2 batch in
+  let ids = Array.init nq (fun j -> Array.init k (fun i -> Int32.to_int ids32.{i + 1, j + 1})) in
+  ids, distances
+
+(* Hnsw.Ba.knn_batch : t -> Lacaml.S.mat -> num_neighbours_search:int -> num_neighbours:int
+   -> Lacaml.S.mat (lib/hnsw.ml:769-777): distances only, +inf filled (:771). *)
+let ba_knn_batch (t : t) (batch : Lacaml.S.mat) ~num_neighbours_search ~num_neighbours =
+  snd (search t batch ~ef:num_neighbours_search ~k:num_neighbours ~fill:1)

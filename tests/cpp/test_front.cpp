@@ -1,0 +1,67 @@
+// C++ front-end over the C ABI, checked against the reference's own search_k known answers
+// (lib/ohnsw.ml:617-643: ring of 5 nodes, values [0;1;2;3;5], |a-b| distance == L2 at d = 1).
+#include "../../ocaml-hnsw_amd/host/hnsw_front.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+static int fails = 0;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
+
+static Hnsw::Hgraph ring5(const float *vals, int entry, int id_base) {
+    static int32_t deg0[5]; static int32_t nbr0[5 * 2];
+    // Graph.Test.create_loop (lib/ohnsw.ml:205-212), lists in Neighbours.iter order
+    const int lists[5][2] = {{4, 1}, {0, 2}, {1, 3}, {2, 4}, {3, 0}};
+    for (int i = 0; i < 5; ++i) { deg0[i] = 2; nbr0[2 * i] = lists[i][0] + id_base; nbr0[2 * i + 1] = lists[i][1] + id_base; }
+    hnsw_index_desc d{};
+    d.vectors = vals; d.n = 5; d.d = 1; d.row_stride = 1; d.metric = HNSW_METRIC_L2; d.id_base = id_base;
+    d.max_degree0 = 2; d.max_degree = 1; d.max_layer = 0; d.entry_point = entry + id_base; d.deg0 = deg0; d.nbr0 = nbr0; d.upper = nullptr;
+    return Hnsw::Hgraph::create(d);
+}
+
+int main() {
+    const float vals[5] = {0, 1, 2, 3, 5};
+    {   // test 4.5 ~start_node:1 ~k:2 -> ((4,0.5),(3,1.5))   lib/ohnsw.ml:634-635
+        auto g = ring5(vals, 1, 0);
+        const float t = 4.5f;
+        auto r = Hnsw::Ohnsw::knn(g, 2, &t);
+        EXPECT(r.size() == 2 && r[0].node == 4 && r[1].node == 3);
+        EXPECT(std::fabs(r[0].distance_to_target - 0.5f) < 1e-6 && std::fabs(r[1].distance_to_target - 1.5f) < 1e-6);
+    }
+    {   // test 0. ~start_node:2 ~k:42 -> all five, ascending   lib/ohnsw.ml:640-643
+        auto g = ring5(vals, 2, 0);
+        const float t = 0.f;
+        auto r = Hnsw::Ohnsw::knn(g, 42, &t);
+        EXPECT(r.size() == 5);
+        const int want[5] = {0, 1, 2, 3, 4};
+        for (size_t i = 0; i < r.size(); ++i) EXPECT(r[i].node == want[i]);
+        auto br = Hnsw::Ohnsw::knn_batch_bigarray(g, 7, Hnsw::Mat{&t, 1, 1});
+        EXPECT(br.first[0][5] == -1 && std::isnan(br.second[5]));            // lib/ohnsw.ml:880-881
+    }
+    {   // Hnsw.Ba: 1-based ids, +inf fill   lib/hnsw.ml:325,771
+        auto g = ring5(vals, 2, 1);
+        const float t = 0.f;
+        auto r = Hnsw::Ba::knn(g, &t, 6, 3);
+        EXPECT(r.size() == 3 && r[0].node == 1 && r[1].node == 2 && r[2].node == 3);
+        auto d = Hnsw::Ba::knn_batch(g, Hnsw::Mat{&t, 1, 1}, 8, 8);
+        EXPECT(std::isinf(d[7]));
+    }
+    {   // error behaviour: empty hgraph -> Invalid_argument "knn: empty hgraph"   lib/ohnsw.ml:862
+        auto g = ring5(vals, -1, 0);
+        const float t = 0.f;
+        bool threw = false;
+        try { Hnsw::Ohnsw::knn(g, 1, &t); } catch (const std::invalid_argument &e) { threw = std::string(e.what()).find("empty hgraph") != std::string::npos; }
+        EXPECT(threw);
+    }
+    {   // device-side build + search through the mirror
+        std::vector<float> X(2000 * 8);
+        unsigned s = 1;
+        for (auto &x : X) { s = s * 1664525u + 1013904223u; x = (float)(s >> 8) / (float)(1 << 24); }
+        auto g = Hnsw::Ohnsw::build_batch_bigarray(Hnsw::Mat{X.data(), 2000, 8}, 6, 40, 1);
+        auto r = Hnsw::Ohnsw::knn(g, 5, X.data() + 8 * 17);
+        EXPECT(r.size() == 5 && r[0].node == 17 && r[0].distance_to_target == 0.f);
+    }
+    std::printf(fails ? "FAILED (%d)\n" : "front-end ok\n", fails);
+    return fails ? 1 : 0;
+}

@@ -276,3 +276,15 @@ def test_large_batch_property(H, oracle, tiny):
     assert (dist[:, 0] == 0).mean() > 0.99
     np.testing.assert_array_equal(ids[:500], ids[500:1000])
     np.testing.assert_array_equal(ids[:500], ids[-500:])
+
+
+def test_cpp_front_end_mirror(H):
+    """host/hnsw_front.hpp (C++ mirror of Ohnsw / Hnsw.Ba over the C ABI) against the reference's
+    search_k known answers; built by __graft_entry__.build()."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "test_front")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "front-end ok" in out.stdout, out.stdout + out.stderr
