@@ -86,7 +86,8 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
         // on an upper layer is either in W or rejected for good (max(W) never grows).
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s)
-            if (w.hi[s] != KEY_INF || w.lo[s] != KEY_INF) w.lo[s] &= ~1u;
+            if (w.key[s] != KEY64_INF) w.key[s] &= ~1ull;
+        if (w.count == bv.efc) w.wmax64 &= ~1ull;
         w.ovf_cnt = 0;
         search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, layer, w, bv.efc, cx, n_dist, n_hops, status); // :811
         const int rec = bt.rec_of[(int64_t)i * bt.lcap + layer];
@@ -95,8 +96,8 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
             for (int s = 0; s < NSLOT; ++s) {
                 const int idx = s * 64 + lane;
                 if (idx < w.count) {
-                    bt.cand_id[(int64_t)rec * bv.cand_stride + idx] = (int32_t)(w.lo[s] >> 1);
-                    bt.cand_key[(int64_t)rec * bv.cand_stride + idx] = w.hi[s];
+                    bt.cand_id[(int64_t)rec * bv.cand_stride + idx] = (int32_t)((uint32_t)w.key[s] >> 1);
+                    bt.cand_key[(int64_t)rec * bv.cand_stride + idx] = (uint32_t)(w.key[s] >> 32);
                 }
             }
             if (lane == 0) bt.cand_cnt[rec] = w.count;

@@ -152,7 +152,8 @@ __device__ __forceinline__ void eval_nb(const IndexView &iv, const float4 (&qv)[
         }
         acc = reduce16(acc);
         const int ci = base + 4 * b + r;
-        if (l16 == 0 && ci < cnt) cand_key[ci] = dist_to_key<METRIC>(acc);
+        // one lane per group stores; the others (and groups past cnt) hit scratch entries
+        cand_key[(l16 == 0 && ci < cnt) ? ci : 64 + (l16 << 2) + r] = dist_to_key<METRIC>(acc);
     }
 }
 
@@ -179,94 +180,125 @@ __device__ __forceinline__ void eval_candidates(const IndexView &iv, const float
 }
 
 // ---- W: sorted register-resident list ------------------------------------------------------
+// 64-bit keys: (ordered distance bits << 32) | id << 1 | expanded.  Entry j lives in slot j / 64,
+// lane j % 64; unused entries hold ~0 (which also reads as "expanded").
+constexpr uint64_t KEY64_INF = ~0ull;
+
 template <int NSLOT> struct WList {
-    uint32_t hi[NSLOT], lo[NSLOT]; // entry j lives in slot j/64, lane j%64
-    int count;                     // wave-uniform
-    uint32_t wmax;                 // key.hi of entry ef-1 once full, KEY_INF before
-    // tied-at-max evicted-but-unexpanded entries (still poppable, lib/ohnsw.ml:568): a stack
+    uint64_t key[NSLOT];
+    int count;            // wave-uniform
+    uint64_t wmax64;      // key of entry ef-1 (= max(W)) once full, ~0 before; flag bit kept in sync
+    uint32_t wmax;        // its distance part: the accept threshold (KEY_INF while |W| < ef)
+    // entries evicted while tied with max(W) and not yet expanded (still poppable, lib/ohnsw.ml:568)
     int ovf_cnt;
     uint32_t ovf_key;
 };
 
 constexpr int OVF_CAP = 64; // LDS entries
 
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, int lane) {
+    const uint32_t lo = rdlane((uint32_t)v, lane), hi = rdlane((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v, uint64_t carry) {
+    const uint32_t lo = wave_shr1((uint32_t)v, (uint32_t)carry);
+    const uint32_t hi = wave_shr1((uint32_t)(v >> 32), (uint32_t)(carry >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <int NSLOT>
 __device__ __forceinline__ void wlist_init(WList<NSLOT> &w) {
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) { w.hi[s] = KEY_INF; w.lo[s] = KEY_INF; }
-    w.count = 0; w.wmax = KEY_INF; w.ovf_cnt = 0; w.ovf_key = 0;
+    for (int s = 0; s < NSLOT; ++s) w.key[s] = KEY64_INF;
+    w.count = 0; w.wmax64 = KEY64_INF; w.wmax = KEY_INF; w.ovf_cnt = 0; w.ovf_key = 0;
+}
+
+// entry ef-1 (uniform position): slot chosen by a scalar select chain
+template <int NSLOT>
+__device__ __forceinline__ uint64_t wlist_last(const WList<NSLOT> &w, int ef) {
+    const int SL = (ef - 1) >> 6, LL = (ef - 1) & 63;
+    uint64_t r = 0;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const uint64_t v = rdlane64(w.key[s], LL);
+        r = (s == SL) ? v : r;
+    }
+    return r;
 }
 
 // Insert (kd, kid) -- both wave-uniform.  Mirrors lib/ohnsw.ml:575-577: push W, pop the
-// farthest if |W| > ef.  Returns nothing; duplicates (same id already in W) are ignored.
+// farthest if |W| > ef.  Duplicates (same id already in W: a re-evaluated node) are ignored.
 template <int NSLOT>
 __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint32_t kid, int ef,
                                              int lane, uint32_t *ovf_lds, uint32_t &status) {
-    const uint32_t klo = kid << 1;
-    int p = 0;
-    bool dup = false;
+    const uint64_t K = ((uint64_t)kd << 32) | ((uint64_t)kid << 1);
+    const uint64_t K2 = K + 2;
+    int p = 0, q = 0;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        const bool lt = (w.hi[s] < kd) || (w.hi[s] == kd && w.lo[s] < klo);
-        const bool eq = (w.hi[s] == kd) && ((w.lo[s] >> 1) == kid);
-        p += __popcll(__ballot(lt));
-        dup = dup || (__ballot(eq) != 0ull);
+        p += __popcll(__ballot(w.key[s] < K));
+        q += __popcll(__ballot(w.key[s] < K2));   // counts K and K|1 too
     }
-    if (dup) return;
+    if (p != q) return;                           // already in W
     const bool full = (w.count == ef);
     if (full && p >= ef) return;
-    const int SL = (ef - 1) >> 6, LL = (ef - 1) & 63;
-    uint32_t ev_hi = KEY_INF, ev_lo = KEY_INF;
-    if (full) {
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s)
-            if (s == SL) { ev_hi = rdlane(w.hi[s], LL); ev_lo = rdlane(w.lo[s], LL); }
-    }
+    const uint64_t ev = w.wmax64;                 // the entry pushed out when full
 #pragma unroll
     for (int s = NSLOT - 1; s >= 0; --s) {
-        uint32_t chi = 0, clo = 0;
-        if (s > 0) { chi = rdlane(w.hi[s - 1], 63); clo = rdlane(w.lo[s - 1], 63); }
-        const uint32_t shi = wave_shr1(w.hi[s], chi);
-        const uint32_t slo = wave_shr1(w.lo[s], clo);
+        uint64_t carry = 0;
+        if (s > 0) carry = rdlane64(w.key[s - 1], 63);
+        const uint64_t sh = wave_shr1_64(w.key[s], carry);
         const int idx = s * 64 + lane;
-        uint32_t nhi = idx < p ? w.hi[s] : (idx == p ? kd : shi);
-        uint32_t nlo = idx < p ? w.lo[s] : (idx == p ? klo : slo);
-        if (idx >= ef) { nhi = KEY_INF; nlo = KEY_INF; }
-        w.hi[s] = nhi; w.lo[s] = nlo;
+        uint64_t nk = idx < p ? w.key[s] : (idx == p ? K : sh);
+        if (idx >= ef) nk = KEY64_INF;
+        w.key[s] = nk;
     }
-    if (!full) w.count++;
-    if (w.count == ef) {
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s)
-            if (s == SL) w.wmax = rdlane(w.hi[s], LL);
+    if (!full) {
+        w.count++;
+        if (w.count == ef) { w.wmax64 = wlist_last(w, ef); w.wmax = (uint32_t)(w.wmax64 >> 32); }
+        return;
     }
-    if (full) {
-        if (w.ovf_cnt > 0 && w.ovf_key != w.wmax) w.ovf_cnt = 0; // max(W).d dropped: all dead
-        if (!(ev_lo & 1u) && ev_hi == w.wmax) {                   // evicted, tied, unexpanded
-            if (w.ovf_cnt < OVF_CAP) { if (lane == 0) ovf_lds[w.ovf_cnt] = ev_lo >> 1; w.ovf_cnt++; }
-            else status |= 1u;
-            w.ovf_key = ev_hi;
-        }
+    w.wmax64 = wlist_last(w, ef);
+    w.wmax = (uint32_t)(w.wmax64 >> 32);
+    if (w.ovf_cnt > 0 && w.ovf_key != w.wmax) w.ovf_cnt = 0;          // max(W).d dropped: all dead
+    if (!(ev & 1ull) && (uint32_t)(ev >> 32) == w.wmax) {              // evicted, tied, unexpanded
+        if (w.ovf_cnt < OVF_CAP) { if (lane == 0) ovf_lds[w.ovf_cnt] = (uint32_t)ev >> 1; w.ovf_cnt++; }
+        else status |= 1u;
+        w.ovf_key = w.wmax;
     }
 }
 
-// Nearest unexpanded member of W (= pop_min of the reference's visit_me, lib/ohnsw.ml:565),
-// marking it expanded; -1 if none.
+// Unexpanded-member masks of W, one ballot per slot.
 template <int NSLOT>
-__device__ __forceinline__ int wlist_pop_unexpanded(WList<NSLOT> &w, int lane) {
+__device__ __forceinline__ void wlist_unexpanded_masks(const WList<NSLOT> &w, uint64_t (&m)[NSLOT]) {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) m[s] = __ballot(((uint32_t)w.key[s] & 1u) == 0u);
+}
+// First set position over the slot masks: returns the node id there (or -1) and clears that bit.
+// Branch-free: one readlane per slot, scalar selects.
+template <int NSLOT>
+__device__ __forceinline__ int wlist_take_first(const WList<NSLOT> &w, uint64_t (&m)[NSLOT], int &index) {
     int c = -1;
+    index = -1;
+    bool found = false;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        if (c < 0) {
-            const uint64_t m = __ballot((w.lo[s] & 1u) == 0u);
-            if (m) {
-                const int L = __builtin_ctzll(m);
-                c = (int)(rdlane(w.lo[s], L) >> 1);
-                if (lane == L) w.lo[s] |= 1u;
-            }
-        }
+        const bool here = !found && (m[s] != 0ull);
+        const int L = __builtin_ctzll(m[s] | (1ull << 63));
+        const int v = (int)(rdlane((uint32_t)w.key[s], L) >> 1);
+        c = here ? v : c;
+        index = here ? s * 64 + L : index;
+        m[s] = here ? (m[s] & (m[s] - 1)) : m[s];
+        found = found || here;
     }
     return c;
+}
+// mark entry `index` expanded
+template <int NSLOT>
+__device__ __forceinline__ void wlist_mark_expanded(WList<NSLOT> &w, int index, int ef, int lane) {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) w.key[s] |= (uint64_t)((s * 64 + lane) == index);
+    if (index == ef - 1) w.wmax64 |= 1ull;
 }
 
 // ---- per-wave scratch in LDS -------------------------------------------------------------------
@@ -277,13 +309,14 @@ __device__ __forceinline__ int wlist_pop_unexpanded(WList<NSLOT> &w, int lane) {
 struct WaveCtx {
     int lane, r, l16;
     uint16_t *vt;        // visited cache, 1 << vt_bits entries
+    uint16_t *vt_trash;  // [64] sink for masked-off lanes
     uint32_t vt_mask;    // 2^(vt_bits+16) - 1
     int vt_entries;
-    int32_t *cand_id;    // [64]
-    uint32_t *cand_key;  // [64]
+    int32_t *cand_id;    // [128]: 64 live + 64 scratch
+    uint32_t *cand_key;  // [128]
     uint32_t *ovf;       // [OVF_CAP]
 };
-__host__ __device__ inline size_t wave_lds_words(int vt_bits) { return (((size_t)1 << vt_bits) >> 1) + 128 + OVF_CAP; }
+__host__ __device__ inline size_t wave_lds_words(int vt_bits) { return (((size_t)1 << vt_bits) >> 1) + 256 + OVF_CAP + 32; }
 __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane) {
     WaveCtx cx;
     cx.lane = lane; cx.r = lane >> 4; cx.l16 = lane & 15;
@@ -292,8 +325,9 @@ __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane
     cx.vt_entries = 1 << vt_bits;
     uint32_t *rest = lds + (((size_t)1 << vt_bits) >> 1);
     cx.cand_id = reinterpret_cast<int32_t *>(rest);
-    cx.cand_key = rest + 64;
-    cx.ovf = rest + 128;
+    cx.cand_key = rest + 128;
+    cx.ovf = rest + 256;
+    cx.vt_trash = reinterpret_cast<uint16_t *>(rest + 256 + OVF_CAP);
     return cx;
 }
 __device__ __forceinline__ void visited_clear(const WaveCtx &cx) { // Visited.clear, lib/ohnsw.ml:262
@@ -306,6 +340,13 @@ __device__ __forceinline__ bool visited_mem(const WaveCtx &cx, uint32_t h) {    
 }
 __device__ __forceinline__ void visited_add(const WaveCtx &cx, uint32_t h) {       // Visited.add
     if ((h & 0xFFFFu) != 0xFFFFu) cx.vt[h >> 16] = (uint16_t)(h & 0xFFFFu);
+}
+// same, for all lanes at once: lanes with on == false rewrite the slot's current tag (no branch)
+__device__ __forceinline__ void visited_add_masked(const WaveCtx &cx, uint32_t h, bool on) {
+    const uint32_t tag = h & 0xFFFFu;
+    const bool wr = on && tag != 0xFFFFu;
+    uint16_t *slot = wr ? &cx.vt[h >> 16] : &cx.vt_trash[cx.lane];
+    *slot = (uint16_t)tag;
 }
 
 // neighbour row of node c on `layer` (Graph.adjacent, lib/ohnsw.ml:171); -1 = hole / padding
@@ -350,23 +391,9 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
     }
 }
 
-// Nearest unexpanded member of W without marking it (the likely next pop): -1 if none.
-template <int NSLOT>
-__device__ __forceinline__ int wlist_peek_unexpanded(const WList<NSLOT> &w) {
-    int c = -1;
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        if (c < 0) {
-            const uint64_t m = __ballot((w.lo[s] & 1u) == 0u);
-            if (m) c = (int)(rdlane(w.lo[s], __builtin_ctzll(m)) >> 1);
-        }
-    }
-    return c;
-}
-
 // Ohnsw.search_k (lib/ohnsw.ml:543-588) on one layer.  On entry W holds the start nodes
 // (all unexpanded = the start queue, :555-559); on exit W is the ef nearest found.
-// While the rows of a hop are in flight, the adjacency row of the currently nearest unexpanded
+// While the rows of a hop are in flight, the adjacency row of the then-nearest unexpanded
 // candidate is fetched too: if it is still the nearest after this hop's insertions (the common
 // case once the search has converged) the next hop starts without a dependent round trip.
 template <int NCH, int RB, int NSLOT, int METRIC>
@@ -376,8 +403,12 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     const int lane = cx.lane;
     int pref_id = -1, pref_nb = -1;
     for (;;) {
-        int c = wlist_pop_unexpanded(w, lane);                           // :565
-        if (c < 0) {
+        uint64_t um[NSLOT];
+        wlist_unexpanded_masks(w, um);
+        int cidx;
+        int c = wlist_take_first(w, um, cidx);                           // pop_min, :565
+        if (c >= 0) wlist_mark_expanded(w, cidx, ef, lane);
+        else {
             // no unexpanded member of W: only entries evicted while tied with max(W) can still
             // satisfy "not (c.d > max(W).d)" (:568)
             if (w.ovf_cnt > 0 && w.count == ef && w.ovf_key == w.wmax) c = (int)cx.ovf[--w.ovf_cnt];
@@ -393,25 +424,28 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         const uint64_t m = __ballot(fresh);
         const int cnt = __popcll(m);
         // issued only now so that it shares its flight with this hop's rows (loads return in order)
-        pref_id = wlist_peek_unexpanded(w);
+        int pidx;
+        pref_id = wlist_take_first(w, um, pidx);                         // the next nearest unexpanded
         if (pref_id >= 0) pref_nb = adj_entry(iv, layer, pref_id, lane);
         if (cnt == 0) continue;
         const int pos = __popcll(m & ((1ull << lane) - 1ull));
         __syncthreads();
-        if (fresh) { visited_add(cx, h); cx.cand_id[pos] = nb; }         // Visited.add, :572
+        // lanes without a fresh neighbour write to scratch entries past the live ones (no branch)
+        visited_add_masked(cx, h, fresh);                                // Visited.add, :572
+        cx.cand_id[fresh ? pos : 64 + lane] = nb;
         __syncthreads();
         eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cnt, cx.r, cx.l16); // :573
         __syncthreads();
         n_dist += cnt;
-        const uint32_t my_key = (lane < cnt) ? cx.cand_key[lane] : KEY_INF;
-        const uint32_t my_id = (lane < cnt) ? (uint32_t)cx.cand_id[lane] : 0u;
+        const uint32_t my_key = cx.cand_key[lane];
+        const uint32_t my_id = (uint32_t)cx.cand_id[lane];
         // :574 accept iff |W| < ef or d < max(W).d -- tested in row order against the CURRENT W
-        uint64_t pass = __ballot(lane < cnt && (w.count < ef || my_key < w.wmax));
+        uint64_t pass = __ballot(lane < cnt && my_key < w.wmax);
         while (pass) {
             const int i = __builtin_ctzll(pass);
             pass &= pass - 1;
             const uint32_t kd = rdlane(my_key, i);
-            if (w.count == ef && !(kd < w.wmax)) continue;
+            if (!(kd < w.wmax)) continue;
             wlist_insert(w, kd, rdlane(my_id, i), ef, lane, cx.ovf, status);   // :575-577
         }
     }
@@ -480,7 +514,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
         if (idx < a.k) {
             int32_t oid = -1;
             float od = a.fill == 0 ? __uint_as_float(0x7FC00000u) : __uint_as_float(0x7F800000u);
-            if (idx < w.count) { oid = (int32_t)(w.lo[s] >> 1) + iv.id_base; od = key_to_dist<METRIC>(w.hi[s]); }
+            if (idx < w.count) { oid = (int32_t)((uint32_t)w.key[s] >> 1) + iv.id_base; od = key_to_dist<METRIC>((uint32_t)(w.key[s] >> 32)); }
             a.out_ids[q * a.k + idx] = oid;
             a.out_dist[q * a.k + idx] = od;
         }
