@@ -19,7 +19,7 @@ import numpy as _np
 _PKG_DIR = _os.path.dirname(_os.path.abspath(__file__)) if "__file__" in globals() and \
     _os.path.basename(_os.path.dirname(_os.path.abspath(__file__))) == "ocaml-hnsw_amd" else \
     _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "ocaml-hnsw_amd")
-LIB_PATH = _os.path.join(_PKG_DIR, "libhnsw_mi355x.so")
+LIB_PATH = _os.environ.get("HNSW_LIB_PATH") or _os.path.join(_PKG_DIR, "libhnsw_mi355x.so")
 
 OK, ERR_BAD_ARG, ERR_EMPTY_INDEX, ERR_DEGREE_OVERFLOW = 0, -1, -2, -3
 ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = -4, -5, -6, -7

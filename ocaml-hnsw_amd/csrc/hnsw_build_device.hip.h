@@ -75,8 +75,8 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
     if (lvl < top) greedy_descend<NCH, RB, METRIC>(iv, qv, top, lvl + 1, cur, cur_key, cx, n_dist); // :785-789
 
     WList<NSLOT> w;
-    wlist_init(w);
-    wlist_insert(w, cur_key, (uint32_t)cur, bv.efc, lane, cx.ovf, status);                 // :802
+    wlist_init(w, bv.efc, lane);
+    wlist_insert(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);                         // :802
     if (lane == 0) visited_add(cx, vt_hash(cx, (uint32_t)cur));
     __syncthreads();
 
@@ -86,21 +86,24 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
         // on an upper layer is either in W or rejected for good (max(W) never grows).
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s)
-            if (w.key[s] != KEY64_INF) w.key[s] &= ~1ull;
-        if (w.count == bv.efc) w.wmax64 &= ~1ull;
+            if ((uint32_t)(w.key[s] >> 32) < DUMMY_HI && w.key[s] != KEY64_PAD) w.key[s] &= ~1ull;
+        if (wlist_full(w)) w.wmax64 &= ~1ull;
         w.ovf_cnt = 0;
         search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, layer, w, bv.efc, cx, n_dist, n_hops, status); // :811
         const int rec = bt.rec_of[(int64_t)i * bt.lcap + layer];
         if (rec >= 0) {
+            const int wbase = NSLOT * 64 - bv.efc;
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
-                const int idx = s * 64 + lane;
-                if (idx < w.count) {
-                    bt.cand_id[(int64_t)rec * bv.cand_stride + idx] = (int32_t)((uint32_t)w.key[s] >> 1);
-                    bt.cand_key[(int64_t)rec * bv.cand_stride + idx] = (uint32_t)(w.key[s] >> 32);
+                const int idx = s * 64 + lane - wbase;
+                const uint32_t hi = (uint32_t)(w.key[s] >> 32);
+                if (idx >= 0 && hi < DUMMY_HI) {
+                    bt.cand_id[(int64_t)rec * bv.cand_stride + idx] = (int32_t)key_id(w.key[s]);
+                    bt.cand_key[(int64_t)rec * bv.cand_stride + idx] = hi;
                 }
             }
-            if (lane == 0) bt.cand_cnt[rec] = w.count;
+            const int cntw = wlist_count(w);
+            if (lane == 0) bt.cand_cnt[rec] = cntw;
         }
     }
 }

@@ -180,15 +180,23 @@ __device__ __forceinline__ void eval_candidates(const IndexView &iv, const float
 }
 
 // ---- W: sorted register-resident list ------------------------------------------------------
-// 64-bit keys: (ordered distance bits << 32) | id << 1 | expanded.  Entry j lives in slot j / 64,
-// lane j % 64; unused entries hold ~0 (which also reads as "expanded").
-constexpr uint64_t KEY64_INF = ~0ull;
+// 64-bit keys: (ordered distance bits << 32) | (id + 1) << 1 | expanded, ascending, slot-major across the
+// wave (position j = slot j / 64, lane j % 64).  W always holds exactly ef entries in the TOP ef
+// positions of its NSLOT*64-position capacity: before ef real nodes have been found the upper ones
+// are +inf dummies (flagged expanded), so "|W| < ef or d < max(W).d" (lib/ohnsw.ml:574) is the
+// single test d < max(W).d, the maximum always sits in the last lane of the last slot, and an
+// insertion is always "shift right from the rank position, the old maximum falls off".
+// Positions below the window hold key 1 (smaller than every real key, flagged expanded).
+constexpr uint32_t DUMMY_HI = 0xFFFFFFFEu;
+constexpr uint64_t KEY64_DUMMY = ((uint64_t)DUMMY_HI << 32) | 0xFFFFFFFFull;
+constexpr uint64_t KEY64_PAD = 1ull;
+// the id field stores id + 1, so every real key is >= 2 > KEY64_PAD even at distance 0, node 0
+__device__ __forceinline__ uint32_t key_id(uint64_t k) { return ((uint32_t)k >> 1) - 1u; }
 
 template <int NSLOT> struct WList {
     uint64_t key[NSLOT];
-    int count;            // wave-uniform
-    uint64_t wmax64;      // key of entry ef-1 (= max(W)) once full, ~0 before; flag bit kept in sync
-    uint32_t wmax;        // its distance part: the accept threshold (KEY_INF while |W| < ef)
+    uint64_t wmax64;      // key of the top entry = max(W); flag bit kept in sync
+    uint32_t wmax;        // its distance part: the accept threshold (DUMMY_HI while |W| < ef)
     // entries evicted while tied with max(W) and not yet expanded (still poppable, lib/ohnsw.ml:568)
     int ovf_cnt;
     uint32_t ovf_key;
@@ -207,31 +215,30 @@ __device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v, uint64_t carry) {
 }
 
 template <int NSLOT>
-__device__ __forceinline__ void wlist_init(WList<NSLOT> &w) {
+__device__ __forceinline__ void wlist_init(WList<NSLOT> &w, int ef, int lane) {
+    const int base = NSLOT * 64 - ef;
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) w.key[s] = KEY64_INF;
-    w.count = 0; w.wmax64 = KEY64_INF; w.wmax = KEY_INF; w.ovf_cnt = 0; w.ovf_key = 0;
+    for (int s = 0; s < NSLOT; ++s) w.key[s] = (s * 64 + lane) < base ? KEY64_PAD : KEY64_DUMMY;
+    w.wmax64 = KEY64_DUMMY; w.wmax = DUMMY_HI; w.ovf_cnt = 0; w.ovf_key = 0;
 }
-
-// entry ef-1 (uniform position): slot chosen by a scalar select chain
-template <int NSLOT>
-__device__ __forceinline__ uint64_t wlist_last(const WList<NSLOT> &w, int ef) {
-    const int SL = (ef - 1) >> 6, LL = (ef - 1) & 63;
-    uint64_t r = 0;
+template <int NSLOT> __device__ __forceinline__ bool wlist_full(const WList<NSLOT> &w) { return w.wmax != DUMMY_HI; }
+// number of real entries
+template <int NSLOT> __device__ __forceinline__ int wlist_count(const WList<NSLOT> &w) {
+    int c = 0;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        const uint64_t v = rdlane64(w.key[s], LL);
-        r = (s == SL) ? v : r;
+        const uint32_t hi = (uint32_t)(w.key[s] >> 32);
+        c += __popcll(__ballot(w.key[s] != KEY64_PAD && hi < DUMMY_HI));
     }
-    return r;
+    return c;
 }
 
-// Insert (kd, kid) -- both wave-uniform.  Mirrors lib/ohnsw.ml:575-577: push W, pop the
-// farthest if |W| > ef.  Duplicates (same id already in W: a re-evaluated node) are ignored.
+// Insert (kd, kid) -- both wave-uniform, kd < w.wmax.  Mirrors lib/ohnsw.ml:575-577: push W, pop
+// the farthest.  Duplicates (same id already in W: a re-evaluated node) are ignored.
 template <int NSLOT>
-__device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint32_t kid, int ef,
-                                             int lane, uint32_t *ovf_lds, uint32_t &status) {
-    const uint64_t K = ((uint64_t)kd << 32) | ((uint64_t)kid << 1);
+__device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint32_t kid, int lane,
+                                             uint32_t *ovf_lds, uint32_t &status) {
+    const uint64_t K = ((uint64_t)kd << 32) | ((uint64_t)(kid + 1u) << 1);
     const uint64_t K2 = K + 2;
     int p = 0, q = 0;
 #pragma unroll
@@ -240,29 +247,20 @@ __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint3
         q += __popcll(__ballot(w.key[s] < K2));   // counts K and K|1 too
     }
     if (p != q) return;                           // already in W
-    const bool full = (w.count == ef);
-    if (full && p >= ef) return;
-    const uint64_t ev = w.wmax64;                 // the entry pushed out when full
+    const uint64_t ev = w.wmax64;                 // the entry that falls off
 #pragma unroll
     for (int s = NSLOT - 1; s >= 0; --s) {
         uint64_t carry = 0;
         if (s > 0) carry = rdlane64(w.key[s - 1], 63);
         const uint64_t sh = wave_shr1_64(w.key[s], carry);
         const int idx = s * 64 + lane;
-        uint64_t nk = idx < p ? w.key[s] : (idx == p ? K : sh);
-        if (idx >= ef) nk = KEY64_INF;
-        w.key[s] = nk;
+        w.key[s] = idx < p ? w.key[s] : (idx == p ? K : sh);
     }
-    if (!full) {
-        w.count++;
-        if (w.count == ef) { w.wmax64 = wlist_last(w, ef); w.wmax = (uint32_t)(w.wmax64 >> 32); }
-        return;
-    }
-    w.wmax64 = wlist_last(w, ef);
+    w.wmax64 = rdlane64(w.key[NSLOT - 1], 63);
     w.wmax = (uint32_t)(w.wmax64 >> 32);
     if (w.ovf_cnt > 0 && w.ovf_key != w.wmax) w.ovf_cnt = 0;          // max(W).d dropped: all dead
     if (!(ev & 1ull) && (uint32_t)(ev >> 32) == w.wmax) {              // evicted, tied, unexpanded
-        if (w.ovf_cnt < OVF_CAP) { if (lane == 0) ovf_lds[w.ovf_cnt] = (uint32_t)ev >> 1; w.ovf_cnt++; }
+        if (w.ovf_cnt < OVF_CAP) { if (lane == 0) ovf_lds[w.ovf_cnt] = key_id(ev); w.ovf_cnt++; }
         else status |= 1u;
         w.ovf_key = w.wmax;
     }
@@ -275,7 +273,6 @@ __device__ __forceinline__ void wlist_unexpanded_masks(const WList<NSLOT> &w, ui
     for (int s = 0; s < NSLOT; ++s) m[s] = __ballot(((uint32_t)w.key[s] & 1u) == 0u);
 }
 // First set position over the slot masks: returns the node id there (or -1) and clears that bit.
-// Branch-free: one readlane per slot, scalar selects.
 template <int NSLOT>
 __device__ __forceinline__ int wlist_take_first(const WList<NSLOT> &w, uint64_t (&m)[NSLOT], int &index) {
     int c = -1;
@@ -285,7 +282,7 @@ __device__ __forceinline__ int wlist_take_first(const WList<NSLOT> &w, uint64_t 
     for (int s = 0; s < NSLOT; ++s) {
         const bool here = !found && (m[s] != 0ull);
         const int L = __builtin_ctzll(m[s] | (1ull << 63));
-        const int v = (int)(rdlane((uint32_t)w.key[s], L) >> 1);
+        const int v = (int)(rdlane((uint32_t)w.key[s], L) >> 1) - 1;
         c = here ? v : c;
         index = here ? s * 64 + L : index;
         m[s] = here ? (m[s] & (m[s] - 1)) : m[s];
@@ -295,10 +292,10 @@ __device__ __forceinline__ int wlist_take_first(const WList<NSLOT> &w, uint64_t 
 }
 // mark entry `index` expanded
 template <int NSLOT>
-__device__ __forceinline__ void wlist_mark_expanded(WList<NSLOT> &w, int index, int ef, int lane) {
+__device__ __forceinline__ void wlist_mark_expanded(WList<NSLOT> &w, int index, int lane) {
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) w.key[s] |= (uint64_t)((s * 64 + lane) == index);
-    if (index == ef - 1) w.wmax64 |= 1ull;
+    if (index == NSLOT * 64 - 1) w.wmax64 |= 1ull;
 }
 
 // ---- per-wave scratch in LDS -------------------------------------------------------------------
@@ -407,11 +404,11 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         wlist_unexpanded_masks(w, um);
         int cidx;
         int c = wlist_take_first(w, um, cidx);                           // pop_min, :565
-        if (c >= 0) wlist_mark_expanded(w, cidx, ef, lane);
+        if (c >= 0) wlist_mark_expanded(w, cidx, lane);
         else {
             // no unexpanded member of W: only entries evicted while tied with max(W) can still
             // satisfy "not (c.d > max(W).d)" (:568)
-            if (w.ovf_cnt > 0 && w.count == ef && w.ovf_key == w.wmax) c = (int)cx.ovf[--w.ovf_cnt];
+            if (w.ovf_cnt > 0 && w.ovf_key == w.wmax) c = (int)cx.ovf[--w.ovf_cnt];
             else break;
         }
         n_hops++;
@@ -446,7 +443,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             pass &= pass - 1;
             const uint32_t kd = rdlane(my_key, i);
             if (!(kd < w.wmax)) continue;
-            wlist_insert(w, kd, rdlane(my_id, i), ef, lane, cx.ovf, status);   // :575-577
+            wlist_insert(w, kd, rdlane(my_id, i), lane, cx.ovf, status);       // :575-577
         }
     }
 }
@@ -474,8 +471,11 @@ __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv,
 }
 
 // ---- the search kernel: Ohnsw.knn (lib/ohnsw.ml:859-875) per query -------------------------------
+#ifndef HNSW_SEARCH_MIN_WAVES
+#define HNSW_SEARCH_MIN_WAVES 1
+#endif
 template <int NCH, int RB, int NSLOT, int METRIC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES)
 hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
@@ -501,20 +501,22 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     greedy_descend<NCH, RB, METRIC>(iv, qv, iv.max_layer, 1, cur, cur_key, cx, n_dist);   // :865-867
 
     WList<NSLOT> w;
-    wlist_init(w);
-    wlist_insert(w, cur_key, (uint32_t)cur, a.ef, lane, cx.ovf, status);   // :871, seeds W :555-557
+    wlist_init(w, a.ef, lane);
+    wlist_insert(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);         // :871, seeds W :555-557
     if (lane == 0) visited_add(cx, vt_hash(cx, (uint32_t)cur));
     __syncthreads();
     search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
 
     // results: W[0..k) ascending (lib/ohnsw.ml:886-893)
+    const int wbase = NSLOT * 64 - a.ef;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        const int idx = s * 64 + lane;
-        if (idx < a.k) {
+        const int idx = s * 64 + lane - wbase;
+        if (idx >= 0 && idx < a.k) {
             int32_t oid = -1;
             float od = a.fill == 0 ? __uint_as_float(0x7FC00000u) : __uint_as_float(0x7F800000u);
-            if (idx < w.count) { oid = (int32_t)((uint32_t)w.key[s] >> 1) + iv.id_base; od = key_to_dist<METRIC>((uint32_t)(w.key[s] >> 32)); }
+            const uint32_t hi = (uint32_t)(w.key[s] >> 32);
+            if (hi < DUMMY_HI) { oid = (int32_t)key_id(w.key[s]) + iv.id_base; od = key_to_dist<METRIC>(hi); }
             a.out_ids[q * a.k + idx] = oid;
             a.out_dist[q * a.k + idx] = od;
         }
