@@ -35,6 +35,8 @@ def build(force=False, verbose=False, resource_log=None):
     if not force and up_to_date():
         return LIB
     base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include")]
+    if os.environ.get("HNSW_RB_NCH2"):
+        base += ["-DHNSW_RB_NCH2=" + os.environ["HNSW_RB_NCH2"]]
     if os.environ.get("HNSW_SEARCH_MIN_WAVES"):
         base += ["-DHNSW_SEARCH_MIN_WAVES=" + os.environ["HNSW_SEARCH_MIN_WAVES"]]
     if resource_log:

@@ -45,7 +45,7 @@ template <int METRIC>
 hipError_t dispatch_k1(int nch, int nslot, const BuildView &bv, const BatchView &bt, hipStream_t st) {
     switch (nch) {
     case 1: return launch_k1<1, 8, METRIC>(nslot, bv, bt, st);
-    case 2: return launch_k1<2, 4, METRIC>(nslot, bv, bt, st);
+    case 2: return launch_k1<2, HNSW_RB_NCH2, METRIC>(nslot, bv, bt, st);
     case 4: return launch_k1<4, 2, METRIC>(nslot, bv, bt, st);
     case 8: return launch_k1<8, 1, METRIC>(nslot, bv, bt, st);
     default: return launch_k1<16, 1, METRIC>(nslot, bv, bt, st);
@@ -170,7 +170,7 @@ int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_strid
     bv.efc = efc; bv.cand_stride = cand_stride;
     bv.vt_bits = 8;
     while ((1 << bv.vt_bits) < 16 * efc && bv.vt_bits < 13) ++bv.vt_bits;
-    while (bv.vt_bits < 15 && ((int64_t)1 << (bv.vt_bits + 16)) < n) ++bv.vt_bits;
+    while (bv.vt_bits < 16 && ((int64_t)1 << (bv.vt_bits + 15)) < n) ++bv.vt_bits;
 
     HIP_TRY_B(hipStreamCreate(&st));
     HIP_TRY_B(hipMalloc(&dNodes, (size_t)bmax * 4));

@@ -67,7 +67,7 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
     int cur = bt.entry;
     if (lane == 0) cx.cand_id[0] = cur;
     __syncthreads();
-    eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, 1, cx.r, cx.l16);
+    eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, 1, cx.r, cx.l16);
     __syncthreads();
     uint32_t cur_key = cx.cand_key[0];
 
@@ -77,7 +77,7 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
     WList<NSLOT> w;
     wlist_init(w, bv.efc, lane);
     wlist_insert(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);                         // :802
-    if (lane == 0) visited_add(cx, vt_hash(cx, (uint32_t)cur));
+    { uint32_t hw; const uint32_t hc = vt_hash(cx, (uint32_t)cur); (void)visited_mem(cx, hc, hw); visited_add_masked(cx, hc, hw, lane == 0); }
     __syncthreads();
 
     for (int layer = (lvl < top ? lvl : top); layer >= 0; --layer) {                         // :806
@@ -216,6 +216,7 @@ build_merge_kernel(const BuildView bv, const MergeArgs ma) {
     __shared__ int32_t s_id[128];     // sorted union
     __shared__ uint32_t s_key[128];
     __shared__ int32_t k_id[64];
+    __shared__ uint32_t trash[64];
     const IndexView &iv = bv.iv;
     const int lane = threadIdx.x;
     const int e = blockIdx.x;
@@ -267,7 +268,7 @@ build_merge_kernel(const BuildView bv, const MergeArgs ma) {
     // shrink (lib/ohnsw.ml:823-828): distances of the union to nb, ascending (d, id), heuristic
     float4 qv[NCH];
     load_row<NCH>(qv, iv, nb, lane & 15);
-    eval_candidates<NCH, RB, METRIC>(iv, qv, u_id, u_key, nu, lane >> 4, lane & 15);
+    eval_candidates<NCH, RB, METRIC>(iv, qv, u_id, u_key, trash, nu, lane >> 4, lane & 15);
     __syncthreads();
     for (int j = lane; j < nu; j += 64) {                               // rank sort, nu <= 128
         const uint64_t mk = ((uint64_t)u_key[j] << 32) | (uint32_t)u_id[j];

@@ -75,7 +75,7 @@ template <int METRIC>
 hipError_t dispatch_nch(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st) {
     switch (nch) {
     case 1: return dispatch_slot<1, 8, METRIC>(nslot, iv, a, st);
-    case 2: return dispatch_slot<2, 4, METRIC>(nslot, iv, a, st);
+    case 2: return dispatch_slot<2, HNSW_RB_NCH2, METRIC>(nslot, iv, a, st);
     case 4: return dispatch_slot<4, 2, METRIC>(nslot, iv, a, st);
     case 8: return dispatch_slot<8, 1, METRIC>(nslot, iv, a, st);
     default: return dispatch_slot<16, 1, METRIC>(nslot, iv, a, st);
@@ -119,8 +119,8 @@ int default_vt_bits(const hnsw_index *idx, int ef) {
         b = 8;
         while ((1 << b) < 16 * ef && b < 13) ++b;
     }
-    b = std::max(4, std::min(15, b));
-    while (b < 15 && ((int64_t)1 << (b + 16)) < idx->iv.n) ++b;   // tags must identify ids exactly
+    b = std::max(4, std::min(16, b));
+    while (b < 16 && ((int64_t)1 << (b + 15)) < idx->iv.n) ++b;   // tags must identify ids exactly
     return b;
 }
 

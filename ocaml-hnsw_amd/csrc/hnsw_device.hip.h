@@ -107,8 +107,8 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // float4 units (tables up to 64 GiB).
 template <int NCH, int NB, int METRIC, bool FULL>
 __device__ __forceinline__ void eval_nb(const IndexView &iv, const float4 (&qv)[NCH],
-                                        const int32_t *cand_id, uint32_t *cand_key, int base,
-                                        int cnt, int r, int l16) {
+                                        const int32_t *cand_id, uint32_t *cand_key,
+                                        uint32_t *trash, int base, int cnt, int r, int l16) {
     const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
     const uint32_t stride4 = (uint32_t)(iv.stride >> 2);
     uint32_t row4[NB];
@@ -153,30 +153,30 @@ __device__ __forceinline__ void eval_nb(const IndexView &iv, const float4 (&qv)[
         acc = reduce16(acc);
         const int ci = base + 4 * b + r;
         // one lane per group stores; the others (and groups past cnt) hit scratch entries
-        cand_key[(l16 == 0 && ci < cnt) ? ci : 64 + (l16 << 2) + r] = dist_to_key<METRIC>(acc);
+        *((l16 == 0 && ci < cnt) ? &cand_key[ci] : &trash[(l16 << 2) + r]) = dist_to_key<METRIC>(acc);
     }
 }
 
 template <int NCH, int RB, int METRIC, bool FULL>
 __device__ __forceinline__ void eval_full(const IndexView &iv, const float4 (&qv)[NCH],
-                                          const int32_t *cand_id, uint32_t *cand_key, int cnt,
-                                          int r, int l16) {
+                                          const int32_t *cand_id, uint32_t *cand_key,
+                                          uint32_t *trash, int cnt, int r, int l16) {
     for (int base = 0; base < cnt;) {
         const int nbb = (cnt - base + 3) >> 2;   // wave-uniform
-        if (RB >= 8 && nbb >= 8) { eval_nb<NCH, (RB >= 8 ? 8 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 32; }
-        else if (RB >= 4 && nbb >= 4) { eval_nb<NCH, (RB >= 4 ? 4 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 16; }
-        else if (RB >= 4 && nbb == 3) { eval_nb<NCH, (RB >= 4 ? 3 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 12; }
-        else if (RB >= 2 && nbb >= 2) { eval_nb<NCH, (RB >= 2 ? 2 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 8; }
-        else { eval_nb<NCH, 1, METRIC, FULL>(iv, qv, cand_id, cand_key, base, cnt, r, l16); base += 4; }
+        if (RB >= 8 && nbb >= 8) { eval_nb<NCH, (RB >= 8 ? 8 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, trash, base, cnt, r, l16); base += 32; }
+        else if (RB >= 4 && nbb >= 4) { eval_nb<NCH, (RB >= 4 ? 4 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, trash, base, cnt, r, l16); base += 16; }
+        else if (RB >= 3 && nbb >= 3) { eval_nb<NCH, (RB >= 3 ? 3 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, trash, base, cnt, r, l16); base += 12; }
+        else if (RB >= 2 && nbb >= 2) { eval_nb<NCH, (RB >= 2 ? 2 : 1), METRIC, FULL>(iv, qv, cand_id, cand_key, trash, base, cnt, r, l16); base += 8; }
+        else { eval_nb<NCH, 1, METRIC, FULL>(iv, qv, cand_id, cand_key, trash, base, cnt, r, l16); base += 4; }
     }
 }
 
 template <int NCH, int RB, int METRIC>
 __device__ __forceinline__ void eval_candidates(const IndexView &iv, const float4 (&qv)[NCH],
                                                 const int32_t *cand_id, uint32_t *cand_key,
-                                                int cnt, int r, int l16) {
-    if (iv.nchunks == 16 * NCH) eval_full<NCH, RB, METRIC, true>(iv, qv, cand_id, cand_key, cnt, r, l16);
-    else eval_full<NCH, RB, METRIC, false>(iv, qv, cand_id, cand_key, cnt, r, l16);
+                                                uint32_t *trash, int cnt, int r, int l16) {
+    if (iv.nchunks == 16 * NCH) eval_full<NCH, RB, METRIC, true>(iv, qv, cand_id, cand_key, trash, cnt, r, l16);
+    else eval_full<NCH, RB, METRIC, false>(iv, qv, cand_id, cand_key, trash, cnt, r, l16);
 }
 
 // ---- W: sorted register-resident list ------------------------------------------------------
@@ -299,51 +299,53 @@ __device__ __forceinline__ void wlist_mark_expanded(WList<NSLOT> &w, int index, 
 }
 
 // ---- per-wave scratch in LDS -------------------------------------------------------------------
-// Visited cache: 1 << vt_bits 16-bit tags.  h = (id * odd) mod 2^(vt_bits+16) is a bijection on
-// ids below 2^(vt_bits+16); slot = h >> 16, tag = h & 0xFFFF, so (slot, tag) identifies the id
-// exactly: a hit is never a false positive.  Tag 0xFFFF marks an empty slot; ids that hash to it
-// are simply never cached (a false negative, which is harmless -- see the header comment).
+// Visited cache: 2^(vt_bits-1) sets of two 16-bit tags (one 32-bit word per set, newest tag in the
+// low half).  h = (id * odd) mod 2^(vt_bits+15) is a bijection on ids below 2^(vt_bits+15);
+// set = h >> 16, tag = h & 0xFFFF, so (set, tag) identifies the id exactly: a hit is never a false
+// positive.  Tag 0xFFFF marks an empty way; ids that hash to it are simply never cached (a false
+// negative, which is harmless -- see the header comment).
 struct WaveCtx {
     int lane, r, l16;
-    uint16_t *vt;        // visited cache, 1 << vt_bits entries
-    uint16_t *vt_trash;  // [64] sink for masked-off lanes
-    uint32_t vt_mask;    // 2^(vt_bits+16) - 1
-    int vt_entries;
-    int32_t *cand_id;    // [128]: 64 live + 64 scratch
-    uint32_t *cand_key;  // [128]
+    uint32_t *vt;        // visited cache, 1 << (vt_bits - 1) words
+    uint32_t vt_mask;    // 2^(vt_bits+15) - 1
+    int vt_words;
+    int32_t *cand_id;    // [64]
+    uint32_t *cand_key;  // [64]
+    uint32_t *trash;     // [64] write-only sink shared by every masked-off store
     uint32_t *ovf;       // [OVF_CAP]
 };
-__host__ __device__ inline size_t wave_lds_words(int vt_bits) { return (((size_t)1 << vt_bits) >> 1) + 256 + OVF_CAP + 32; }
+// 4 KiB of tags at vt_bits = 11 plus 1 KiB: 32 waves per CU fit the 160 KiB LDS
+__host__ __device__ inline size_t wave_lds_words(int vt_bits) { return (((size_t)1 << vt_bits) >> 1) + 192 + OVF_CAP; }
 __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane) {
     WaveCtx cx;
     cx.lane = lane; cx.r = lane >> 4; cx.l16 = lane & 15;
-    cx.vt = reinterpret_cast<uint16_t *>(lds);
-    cx.vt_mask = (vt_bits + 16 >= 32) ? 0xFFFFFFFFu : ((1u << (vt_bits + 16)) - 1u);
-    cx.vt_entries = 1 << vt_bits;
-    uint32_t *rest = lds + (((size_t)1 << vt_bits) >> 1);
+    cx.vt = lds;
+    cx.vt_mask = (vt_bits + 15 >= 32) ? 0xFFFFFFFFu : ((1u << (vt_bits + 15)) - 1u);
+    cx.vt_words = 1 << (vt_bits - 1);
+    uint32_t *rest = lds + cx.vt_words;
     cx.cand_id = reinterpret_cast<int32_t *>(rest);
-    cx.cand_key = rest + 128;
-    cx.ovf = rest + 256;
-    cx.vt_trash = reinterpret_cast<uint16_t *>(rest + 256 + OVF_CAP);
+    cx.cand_key = rest + 64;
+    cx.trash = rest + 128;
+    cx.ovf = rest + 192;
     return cx;
 }
 __device__ __forceinline__ void visited_clear(const WaveCtx &cx) { // Visited.clear, lib/ohnsw.ml:262
-    uint32_t *w32 = reinterpret_cast<uint32_t *>(cx.vt);
-    for (int i = cx.lane; i < (cx.vt_entries >> 1); i += 64) w32[i] = 0xFFFFFFFFu;
+    for (int i = cx.lane; i < cx.vt_words; i += 64) cx.vt[i] = 0xFFFFFFFFu;
 }
 __device__ __forceinline__ uint32_t vt_hash(const WaveCtx &cx, uint32_t id) { return (id * 0x9E3779B1u) & cx.vt_mask; }
-__device__ __forceinline__ bool visited_mem(const WaveCtx &cx, uint32_t h) {       // Visited.mem
-    return cx.vt[h >> 16] == (uint16_t)(h & 0xFFFFu) && (h & 0xFFFFu) != 0xFFFFu;
+// Visited.mem (lib/ohnsw.ml:259); `word` returns the set's current content for the add that follows
+__device__ __forceinline__ bool visited_mem(const WaveCtx &cx, uint32_t h, uint32_t &word) {
+    word = cx.vt[h >> 16];
+    const uint32_t tag = h & 0xFFFFu;
+    return ((word & 0xFFFFu) == tag || (word >> 16) == tag) && tag != 0xFFFFu;
 }
-__device__ __forceinline__ void visited_add(const WaveCtx &cx, uint32_t h) {       // Visited.add
-    if ((h & 0xFFFFu) != 0xFFFFu) cx.vt[h >> 16] = (uint16_t)(h & 0xFFFFu);
-}
-// same, for all lanes at once: lanes with on == false rewrite the slot's current tag (no branch)
-__device__ __forceinline__ void visited_add_masked(const WaveCtx &cx, uint32_t h, bool on) {
+// Visited.add (lib/ohnsw.ml:260) for all lanes at once: the new tag enters way 0, way 0 moves to
+// way 1; lanes with on == false store to the scratch sink (no branch)
+__device__ __forceinline__ void visited_add_masked(const WaveCtx &cx, uint32_t h, uint32_t word, bool on) {
     const uint32_t tag = h & 0xFFFFu;
     const bool wr = on && tag != 0xFFFFu;
-    uint16_t *slot = wr ? &cx.vt[h >> 16] : &cx.vt_trash[cx.lane];
-    *slot = (uint16_t)tag;
+    uint32_t *slot = wr ? &cx.vt[h >> 16] : &cx.trash[cx.lane];
+    *slot = (word << 16) | tag;
 }
 
 // neighbour row of node c on `layer` (Graph.adjacent, lib/ohnsw.ml:171); -1 = hole / padding
@@ -372,7 +374,7 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
             __syncthreads();
             if (valid) cx.cand_id[pos] = nb;
             __syncthreads();
-            eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cnt, cx.r, cx.l16);
+            eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, cnt, cx.r, cx.l16);
             __syncthreads();
             n_dist += cnt;
             uint64_t best = (cx.lane < cnt) ? (((uint64_t)cx.cand_key[cx.lane] << 32) | (uint32_t)cx.lane) : ~0ull;
@@ -413,11 +415,12 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         }
         n_hops++;
         int nb;
-        if (c == pref_id) nb = pref_nb;                                  // Graph.adjacent, :570
+        if (c == pref_id) { nb = pref_nb; status += 256u; }              // Graph.adjacent, :570 (bits 8..: prefetch hits)
         else nb = adj_entry(iv, layer, c, lane);
         const bool valid = nb >= 0;
         const uint32_t h = vt_hash(cx, (uint32_t)nb);
-        const bool fresh = valid && !visited_mem(cx, h);                 // Visited.mem, :571
+        uint32_t vword;
+        const bool fresh = valid && !visited_mem(cx, h, vword);          // Visited.mem, :571
         const uint64_t m = __ballot(fresh);
         const int cnt = __popcll(m);
         // issued only now so that it shares its flight with this hop's rows (loads return in order)
@@ -428,10 +431,10 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         const int pos = __popcll(m & ((1ull << lane) - 1ull));
         __syncthreads();
         // lanes without a fresh neighbour write to scratch entries past the live ones (no branch)
-        visited_add_masked(cx, h, fresh);                                // Visited.add, :572
-        cx.cand_id[fresh ? pos : 64 + lane] = nb;
+        visited_add_masked(cx, h, vword, fresh);                         // Visited.add, :572
+        (fresh ? &cx.cand_id[pos] : reinterpret_cast<int32_t *>(&cx.trash[lane]))[0] = nb;
         __syncthreads();
-        eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cnt, cx.r, cx.l16); // :573
+        eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, cnt, cx.r, cx.l16); // :573
         __syncthreads();
         n_dist += cnt;
         const uint32_t my_key = cx.cand_key[lane];
@@ -493,7 +496,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     int cur = iv.entry_point;
     if (lane == 0) cx.cand_id[0] = cur;
     __syncthreads();
-    eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, 1, cx.r, cx.l16);
+    eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, 1, cx.r, cx.l16);
     __syncthreads();
     uint32_t cur_key = cx.cand_key[0];
     n_dist += 1;
@@ -503,7 +506,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     WList<NSLOT> w;
     wlist_init(w, a.ef, lane);
     wlist_insert(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);         // :871, seeds W :555-557
-    if (lane == 0) visited_add(cx, vt_hash(cx, (uint32_t)cur));
+    { uint32_t hw; const uint32_t hc = vt_hash(cx, (uint32_t)cur); (void)visited_mem(cx, hc, hw); visited_add_masked(cx, hc, hw, lane == 0); }
     __syncthreads();
     search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
 

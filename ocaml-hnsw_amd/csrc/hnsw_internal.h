@@ -11,6 +11,11 @@
 #include <string>
 #include <vector>
 
+// 4-row batches in flight per wave for d <= 128 (NCH = 2): measured on C2: 4 (6 waves/SIMD) >= 3 (7) >= 2 (8): the batch is memory-bound, not occupancy-bound
+#ifndef HNSW_RB_NCH2
+#define HNSW_RB_NCH2 4
+#endif
+
 namespace hnsw_host {
 
 int fail(int code, const char *fmt, ...);

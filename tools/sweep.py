@@ -39,3 +39,22 @@ def run(nq, ef, k=10, vt=0, reps=5):
 for spec in sys.argv[1:]:
     nq, ef, vt = (int(x) for x in spec.split(","))
     run(nq, ef, vt=vt)
+
+if os.environ.get("PREF_STATS"):
+    nq, ef, k = 10000, 128, 10
+    Qd = bench.make_sift_like(nq, d, 2, dev, centres, sigma)
+    ids = torch.empty((nq, k), dtype=torch.int32, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    nh = torch.zeros(nq, dtype=torch.int32, device=dev); st = torch.zeros(nq, dtype=torch.int32, device=dev)
+    H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(), 0, nh.data_ptr(), st.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    hits = (st >> 8).float().sum().item(); hops = nh.float().sum().item()
+    print("prefetch hit rate: %.3f (%d hits / %d hops)" % (hits / hops, hits, hops))
+    # host-buffer (PCIe-inclusive) entry point
+    Qh = Qd.cpu().numpy()
+    import time
+    H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef)
+    t = time.perf_counter()
+    for _ in range(5):
+        H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef)
+    dt = (time.perf_counter() - t) / 5
+    print("host-buffer hnsw_search_batch (H2D + kernel + D2H + sync): %.3f ms/batch = %.0f q/s" % (dt * 1e3, nq / dt))
