@@ -169,6 +169,17 @@ typedef struct hnsw_build_params {
 int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_stride,
                    const hnsw_build_params *params, int32_t device, hnsw_index **out);
 
+/* select_neighbours as a batched operator (Ohnsw.select_neighbours lib/ohnsw.ml:647-663;
+ * keep_all_if_few = 1 adds the functor path's "#candidates <= M returns them all" shortcut,
+ * lib/hnsw_algo.ml:596-599).  For each of nb target vectors: the candidates (ids, id_base-based)
+ * are ordered by (distance to the target, id) and kept iff strictly closer to the target than
+ * to every neighbour kept so far; at most num_neighbours are kept.  out [nb][num_neighbours] in
+ * selection order (nearest first), -1 padded. */
+int32_t hnsw_select_neighbours_batch(hnsw_index *idx, const float *targets, int64_t nb, int64_t t_stride,
+                                     const int32_t *cand, const int32_t *cand_cnt, int32_t cand_stride,
+                                     int32_t num_neighbours, int32_t keep_all_if_few, int32_t *out,
+                                     int32_t *out_cnt);
+
 /* Export of the flattened graph held by an index (inverse of hnsw_index_create): ids
  * id_base-based, rows compacted, -1 padded. */
 int32_t hnsw_index_export_layer0(const hnsw_index *idx, int32_t *deg0, int32_t *nbr0);

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "hnsw_abi_version", "hnsw_last_error", "hnsw_device_count", "hnsw_index_create",
     "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_search_batch",
     "hnsw_search_batch_device", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
-    "hnsw_build", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
+    "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
 ]
 
 
@@ -99,10 +99,12 @@ def load():
     L.hnsw_distance_batch.argtypes = [vp, vp, i64, i64, vp, i32, vp]
     L.hnsw_distance_batch_device.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp]
     L.hnsw_build.argtypes = [vp, i64, i32, i64, vp, i32, vp]
+    L.hnsw_select_neighbours_batch.argtypes = [vp, vp, i64, i64, vp, vp, i32, i32, i32, vp, vp]
+    L.hnsw_select_neighbours_batch.restype = i32
     L.hnsw_index_export_layer0.argtypes = [vp, vp, vp]
     L.hnsw_index_export_upper_count.argtypes = [vp, i32, vp]
     L.hnsw_index_export_upper.argtypes = [vp, i32, vp, vp, vp]
-    for f in ("hnsw_build", "hnsw_index_export_layer0", "hnsw_index_export_upper_count",
+    for f in ("hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count",
               "hnsw_index_export_upper"):
         getattr(L, f).restype = i32
     for f in ("hnsw_device_count", "hnsw_index_create", "hnsw_index_destroy", "hnsw_index_get_info",
@@ -305,6 +307,25 @@ class Ohnsw:
         h = _C.c_void_p()
         _check(load().hnsw_build(_ptr(X), X.shape[0], X.shape[1], X.shape[1], _C.byref(p), device, _C.byref(h)))
         return Hgraph._from_handle(h, device, X, 0, metric)
+
+    @staticmethod
+    def select_neighbours(hgraph, targets, candidates, num_neighbours, keep_all_if_few=False):
+        """Batched Ohnsw.select_neighbours distance value queue num_neighbours (lib/ohnsw.ml:647-663):
+        candidates = list of id lists (one per target); returns the kept ids per target in selection
+        order.  keep_all_if_few=True gives Hnsw_algo.SelectNeighbours' shortcut (hnsw_algo.ml:596-599)."""
+        T = _np.ascontiguousarray(targets, dtype=_np.float32)
+        nb = T.shape[0]
+        stride = max([len(c) for c in candidates] + [1])
+        cand = _np.zeros((nb, stride), _np.int32)
+        cnt = _np.zeros(nb, _np.int32)
+        for i, c in enumerate(candidates):
+            cand[i, :len(c)] = c
+            cnt[i] = len(c)
+        out = _np.empty((nb, num_neighbours), _np.int32)
+        ocnt = _np.empty(nb, _np.int32)
+        _check(load().hnsw_select_neighbours_batch(hgraph.handle, _ptr(T), nb, T.shape[1], _ptr(cand), _ptr(cnt),
+                                                   stride, num_neighbours, int(keep_all_if_few), _ptr(out), _ptr(ocnt)))
+        return [out[i, :ocnt[i]].tolist() for i in range(nb)]
 
     @staticmethod
     def distance_l2(hgraph, queries, ids):

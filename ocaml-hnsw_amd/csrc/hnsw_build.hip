@@ -18,6 +18,7 @@ using hnsw_dev::BuildView;
 using hnsw_dev::IndexView;
 using hnsw_dev::MergeArgs;
 using hnsw_dev::SelectArgs;
+using hnsw_dev::SelectOpArgs;
 
 namespace {
 
@@ -276,6 +277,64 @@ done:
     if (st) (void)hipStreamDestroy(st);
     if (rc) { hnsw_index_destroy(idx); return rc; }
     *out = idx;
+    return HNSW_OK;
+}
+
+// ---- select_neighbours operator ----------------------------------------------------------------------
+int32_t hnsw_select_neighbours_batch(hnsw_index *idx, const float *targets, int64_t nb, int64_t t_stride,
+                                     const int32_t *cand, const int32_t *cand_cnt, int32_t cand_stride,
+                                     int32_t num_neighbours, int32_t keep_all_if_few, int32_t *out,
+                                     int32_t *out_cnt) {
+    if (!idx) return fail(HNSW_ERR_BAD_ARG, "null index");
+    if (nb == 0) return HNSW_OK;
+    if (nb < 0 || !targets || !cand || !cand_cnt || !out || !out_cnt) return fail(HNSW_ERR_BAD_ARG, "bad buffers");
+    if (t_stride < idx->iv.d) return fail(HNSW_ERR_BAD_ARG, "t_stride < d");
+    if (num_neighbours < 1 || num_neighbours > 64) return fail(HNSW_ERR_UNSUPPORTED, "num_neighbours must be in 1..64");
+    if (cand_stride < 1 || cand_stride > 1024) return fail(HNSW_ERR_UNSUPPORTED, "cand_stride must be in 1..1024");
+    const int base = idx->iv.id_base;
+    std::vector<int32_t> c0((size_t)nb * cand_stride, 0);
+    for (int64_t b = 0; b < nb; ++b) {
+        if (cand_cnt[b] < 0 || cand_cnt[b] > cand_stride) return fail(HNSW_ERR_BAD_ARG, "cand_cnt out of range");
+        if (keep_all_if_few && cand_cnt[b] <= num_neighbours && cand_cnt[b] > 64) return fail(HNSW_ERR_UNSUPPORTED, "keep-all needs <= 64 candidates");
+        for (int j = 0; j < cand_cnt[b]; ++j) {
+            const int64_t v = (int64_t)cand[b * cand_stride + j] - base;
+            if (v < 0 || v >= idx->iv.n) return fail(HNSW_ERR_BAD_ARG, "Vector.get: candidate id out of range");
+            c0[(size_t)(b * cand_stride + j)] = (int32_t)v;
+        }
+    }
+    HIP_TRY(hipSetDevice(idx->device));
+    DevBuf dT, dC, dN, dO, dOc;
+    int rc;
+    const size_t tbytes = ((size_t)(nb - 1) * t_stride + idx->iv.d) * 4;
+    if ((rc = dT.ensure(tbytes)) || (rc = dC.ensure(c0.size() * 4)) || (rc = dN.ensure((size_t)nb * 4)) ||
+        (rc = dO.ensure((size_t)nb * num_neighbours * 4)) || (rc = dOc.ensure((size_t)nb * 4))) {
+        dT.release(); dC.release(); dN.release(); dO.release(); dOc.release();
+        return rc;
+    }
+    auto cleanup = [&]() { dT.release(); dC.release(); dN.release(); dO.release(); dOc.release(); };
+    if (hipMemcpy(dT.p, targets, tbytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dC.p, c0.data(), c0.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dN.p, cand_cnt, (size_t)nb * 4, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(HNSW_ERR_HIP, "upload failed"); }
+    SelectOpArgs sa{};
+    sa.targets = (const float *)dT.p; sa.t_stride = t_stride; sa.cand = (const int32_t *)dC.p; sa.cand_cnt = (const int32_t *)dN.p;
+    sa.cand_stride = cand_stride; sa.nb = (int32_t)nb; sa.R = num_neighbours; sa.keep_all_if_few = keep_all_if_few;
+    sa.out = (int32_t *)dO.p; sa.out_cnt = (int32_t *)dOc.p;
+    const size_t lds = ((size_t)4 * cand_stride + 128) * 4;
+    const int nch = pick_nch(idx->iv.nchunks);
+    dim3 grid((unsigned)nb), block(64);
+#define LAUNCH_SEL(N, R_, M_) hipLaunchKernelGGL((hnsw_dev::select_neighbours_kernel<N, R_, M_>), grid, block, lds, 0, idx->iv, sa)
+    if (idx->info.metric == HNSW_METRIC_L2) {
+        switch (nch) { case 1: LAUNCH_SEL(1, 8, 0); break; case 2: LAUNCH_SEL(2, 4, 0); break; case 4: LAUNCH_SEL(4, 2, 0); break; case 8: LAUNCH_SEL(8, 1, 0); break; default: LAUNCH_SEL(16, 1, 0); }
+    } else {
+        switch (nch) { case 1: LAUNCH_SEL(1, 8, 1); break; case 2: LAUNCH_SEL(2, 4, 1); break; case 4: LAUNCH_SEL(4, 2, 1); break; case 8: LAUNCH_SEL(8, 1, 1); break; default: LAUNCH_SEL(16, 1, 1); }
+    }
+#undef LAUNCH_SEL
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, dO.p, (size_t)nb * num_neighbours * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_cnt, dOc.p, (size_t)nb * 4, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(HNSW_ERR_HIP, "select_neighbours failed: %s", hipGetErrorString(e));
+    for (int64_t i = 0; i < nb * num_neighbours; ++i) if (out[i] >= 0) out[i] += base;
     return HNSW_OK;
 }
 

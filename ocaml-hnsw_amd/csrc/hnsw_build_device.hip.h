@@ -296,6 +296,64 @@ build_merge_kernel(const BuildView bv, const MergeArgs ma) {
     }
 }
 
+// ---- select_neighbours as an operator (lib/ohnsw.ml:647-663; lib/hnsw_algo.ml:572-609) ------------
+// One wave per base value: distances of the candidates to the target, ascending (distance, id)
+// order (the MinQueue pop order under the canonical tie rule), then the heuristic.
+struct SelectOpArgs {
+    const float *targets;   // [nb][t_stride]
+    int64_t t_stride;
+    const int32_t *cand;    // [nb][cand_stride] 0-based ids
+    const int32_t *cand_cnt;// [nb]
+    int32_t cand_stride, nb, R;
+    int32_t keep_all_if_few; // functor path: #candidates <= R returns them all (hnsw_algo.ml:596-599)
+    int32_t *out;           // [nb][R] selection order, -1 padded (0-based)
+    int32_t *out_cnt;       // [nb]
+};
+
+template <int NCH, int RB, int METRIC>
+__global__ void __launch_bounds__(64)
+select_neighbours_kernel(const IndexView iv, const SelectOpArgs sa) {
+    extern __shared__ uint32_t lds[];
+    const int cs = sa.cand_stride;
+    int32_t *c_id = reinterpret_cast<int32_t *>(lds);
+    uint32_t *c_key = lds + cs;
+    int32_t *s_id = reinterpret_cast<int32_t *>(lds + 2 * cs);
+    uint32_t *s_key = lds + 3 * cs;
+    int32_t *k_id = reinterpret_cast<int32_t *>(lds + 4 * cs);
+    uint32_t *trash = lds + 4 * cs + 64;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    if (b >= sa.nb) return;
+    const int nc = sa.cand_cnt[b];
+    for (int j = lane; j < nc; j += 64) c_id[j] = sa.cand[(int64_t)b * cs + j];
+    float4 qv[NCH];
+    load_query<NCH>(qv, sa.targets + (int64_t)b * sa.t_stride, iv.d, lane & 15);
+    __syncthreads();
+    for (int base = 0; base < nc; base += 64) {   // eval works on lists of <= 64
+        const int m = nc - base < 64 ? nc - base : 64;
+        eval_candidates<NCH, RB, METRIC>(iv, qv, c_id + base, c_key + base, trash, m, lane >> 4, lane & 15);
+    }
+    __syncthreads();
+    for (int j = lane; j < nc; j += 64) {         // rank sort by (key, id)
+        const uint64_t mk = ((uint64_t)c_key[j] << 32) | (uint32_t)c_id[j];
+        int rank = 0;
+        for (int t = 0; t < nc; ++t) rank += ((((uint64_t)c_key[t] << 32) | (uint32_t)c_id[t]) < mk);
+        s_id[rank] = c_id[j];
+        s_key[rank] = c_key[j];
+    }
+    __syncthreads();
+    int kept;
+    if (sa.keep_all_if_few && nc <= sa.R) {
+        kept = nc;
+        if (lane < nc) k_id[lane] = s_id[lane];
+    } else {
+        kept = select_heuristic<NCH, METRIC>(iv, s_id, s_key, nc, sa.R, k_id, lane);
+    }
+    __syncthreads();
+    if (lane < sa.R) sa.out[(int64_t)b * sa.R + lane] = lane < kept ? k_id[lane] : -1;
+    if (lane == 0) sa.out_cnt[b] = kept;
+}
+
 // ---- K5: symmetric removals -------------------------------------------------------------------------
 __global__ void build_unlink_kernel(const BuildView bv, const uint64_t *removals, const uint32_t *rem_cnt,
                                     uint32_t rem_cap, int layer) {

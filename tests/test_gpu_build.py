@@ -108,3 +108,24 @@ def test_small_and_odd_shapes(H, oracle, n, d, M, efc, metric):
     oids, odist = oracle.Ohnsw.knn_batch_bigarray(g, sp, X[:20], k=k, ef=max(k, 20), ties=oracle.TIES_CANONICAL)
     np.testing.assert_array_equal(ids, oids)
     np.testing.assert_array_equal(dist.view(np.uint32), odist.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric,d,M,nc", [(0, 24, 8, 60), (0, 128, 32, 200), (1, 100, 16, 40), (0, 5, 4, 3)])
+def test_select_neighbours_operator_matches_oracle(H, oracle, metric, d, M, nc):
+    """hnsw_select_neighbours_batch vs Ohnsw.select_neighbours (lib/ohnsw.ml:647-663) of the oracle,
+    canonical tie order, on random candidate sets; plus the functor path's keep-all shortcut."""
+    rng = np.random.default_rng(d)
+    X = rng.integers(0, 30, size=(3000, d)).astype(np.float32) if metric == 0 else _uniform(3000, d, 5)
+    if metric:
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    hg = H.Hgraph(X, np.zeros(3000, np.int32), np.full((3000, 2), -1, np.int32), entry_point=0, metric=metric)
+    sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
+    T = X[rng.integers(0, 3000, 40)] + (0 if metric else rng.integers(0, 2, size=(40, d))).astype(np.float32) if not metric else X[rng.integers(0, 3000, 40)]
+    cands = [rng.choice(3000, size=rng.integers(1, nc + 1), replace=False).tolist() for _ in range(40)]
+    got = H.Ohnsw.select_neighbours(hg, T, cands, M)
+    for t, c, g in zip(T, cands, got):
+        want = oracle.Ohnsw.select_neighbours(sp, c, t, M, ties=oracle.TIES_CANONICAL)
+        assert g == want
+    got2 = H.Ohnsw.select_neighbours(hg, T, [c[:M] for c in cands], M, keep_all_if_few=True)
+    for c, g in zip(cands, got2):
+        assert sorted(g) == sorted(c[:M])

@@ -288,3 +288,14 @@ def test_cpp_front_end_mirror(H):
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "front-end ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("case", G["select_neighbours"], ids=lambda c: c["ref"])
+def test_reference_select_neighbours_kats(H, case):
+    """lib/ohnsw.ml:665-764 through the device operator (d = 1: L2 is |a-b|)."""
+    vals = np.array(case["values"], np.float32)[:, None]
+    n = len(vals)
+    hg = H.Hgraph(vals, np.zeros(n, np.int32), np.full((n, 2), -1, np.int32), entry_point=0)
+    M = min(case["M"], 64)
+    got = H.Ohnsw.select_neighbours(hg, np.array([[case["target"]]], np.float32), [case["candidates"]], M)
+    assert sorted(got[0]) == case["expect"]

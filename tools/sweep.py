@@ -8,15 +8,34 @@ import ocaml_hnsw_amd as H
 import bench
 
 dev = torch.device("cuda", 0)
-n, d, M, efc = int(os.environ.get("N", 1000000)), 128, 16, 200
+n, d, M, efc = int(os.environ.get("N", 1000000)), int(os.environ.get("D", 128)), int(os.environ.get("M", 16)), int(os.environ.get("EFC", 200))
+K = int(os.environ.get("K", 10)); METRIC = int(os.environ.get("METRIC", 0)); KIND = os.environ.get("KIND", "sift")
 sigma = float(os.environ.get("SIGMA", 25)); centres = int(os.environ.get("CENTRES", 4096))
-Xd = bench.make_sift_like(n, d, 1, dev, centres, sigma)
+
+def make(nn, seed):
+    if KIND == "sift":
+        return bench.make_sift_like(nn, d, seed, dev, centres, sigma)
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    if KIND == "uniform":
+        return torch.rand((nn, d), generator=g, device=dev) * 2 - 1
+    x = torch.randn((nn, d), generator=g, device=dev)      # "unit": N(0,1) normalised (GloVe/DEEP-like)
+    return x / x.norm(dim=1, keepdim=True)
+
+def truth(Xd_, Q, k):
+    if METRIC == 0:
+        return bench.brute_force_topk(Xd_, Q, k)
+    ids = []
+    for s0 in range(0, Q.shape[0], 128):
+        ids.append(torch.topk(Q[s0:s0 + 128] @ Xd_.T, k, dim=1, largest=True).indices)
+    return torch.cat(ids).cpu().numpy()
+
+Xd = make(n, 1)
 X = Xd.cpu().numpy()
-t = time.time(); hg = H.Ohnsw.build_batch_bigarray(X, M, efc, seed=1); print("build %.2fs" % (time.time() - t), flush=True)
+t = time.time(); hg = H.Ohnsw.build_batch_bigarray(X, M, efc, seed=1, metric=METRIC); print("build %.2fs (n=%d d=%d M=%d efC=%d metric=%d %s)" % (time.time() - t, n, d, M, efc, METRIC, KIND), flush=True)
 stream = torch.cuda.current_stream()
 
-def run(nq, ef, k=10, vt=0, reps=5):
-    Qd = bench.make_sift_like(nq, d, 2, dev, centres, sigma)
+def run(nq, ef, k=K, vt=0, reps=5):
+    Qd = make(nq, 2)
     ids = torch.empty((nq, k), dtype=torch.int32, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
     nd = torch.zeros(nq, dtype=torch.int32, device=dev); nh = torch.zeros(nq, dtype=torch.int32, device=dev)
     hg.set_option("vt_bits", vt)
@@ -30,11 +49,29 @@ def run(nq, ef, k=10, vt=0, reps=5):
         a.record(stream); go(); b.record(stream); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     ms = float(np.median(ts))
     bq = ndm * (4 * d + 4) + nhm * 4 * 2 * M + 4 * d + 8 * k   # uses GPU n_dist (incl. re-evals)
-    ns = min(500, nq)
-    gt = bench.brute_force_topk(Xd, Qd[:ns], k)
+    ns = min(200, nq)
+    gt = truth(Xd, Qd[:ns], k)
     rec = bench.recall_ids(ids.cpu().numpy()[:ns], gt)
     print("nq=%7d ef=%4d vt=%2d: %8.3f ms  %10.0f q/s  n_dist(gpu)=%.0f hops=%.0f  gpu-bytes %.2f TB/s  recall %.3f" %
           (nq, ef, vt, ms, nq / ms * 1e3, ndm, nhm, bq * nq / ms / 1e9, rec), flush=True)
+
+_orc = {}
+def oracle_ndist(ef, k, ns=200):
+    """exact-visited-set evaluation count from the CPU oracle (checker) on the same graph"""
+    from oracle import oracle as o
+    if "g" not in _orc:
+        hg.export()
+        _orc["sp"] = (o.Space.ip if METRIC else o.Space.l2)(X, arith=o.TREE16)
+        _orc["g"] = o.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, hg.upper)
+    Qs = make(max(ns, 64), 2)[:ns].cpu().numpy()
+    r = o.Ohnsw.knn_batch_bigarray(_orc["g"], _orc["sp"], Qs, k=k, ef=ef, ties=o.TIES_CANONICAL, counters=True)
+    return float(r[2].mean()), float(r[3].mean())
+
+if os.environ.get("ORACLE"):
+    for spec in sys.argv[1:]:
+        nq, ef, vt = (int(x) for x in spec.split(","))
+        nd, nh = oracle_ndist(ef, K)
+        print("oracle (exact visited set) ef=%d: n_dist=%.0f n_hops=%.0f" % (ef, nd, nh), flush=True)
 
 for spec in sys.argv[1:]:
     nq, ef, vt = (int(x) for x in spec.split(","))
@@ -42,7 +79,7 @@ for spec in sys.argv[1:]:
 
 if os.environ.get("PREF_STATS"):
     nq, ef, k = 10000, 128, 10
-    Qd = bench.make_sift_like(nq, d, 2, dev, centres, sigma)
+    Qd = make(nq, 2)
     ids = torch.empty((nq, k), dtype=torch.int32, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
     nh = torch.zeros(nq, dtype=torch.int32, device=dev); st = torch.zeros(nq, dtype=torch.int32, device=dev)
     H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(), 0, nh.data_ptr(), st.data_ptr(), stream.cuda_stream)
