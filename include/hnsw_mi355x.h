@@ -187,6 +187,23 @@ int32_t hnsw_index_export_upper_count(const hnsw_index *idx, int32_t layer, int6
 int32_t hnsw_index_export_upper(const hnsw_index *idx, int32_t layer, int64_t *nodes, int32_t *deg,
                                 int32_t *nbr);
 
+/* Per-layer degree statistics: Hgraph.Stats.compute (lib/hnsw.ml:353-375; printed by
+ * benchmark/benchmark.ml:70-71): layer size and min / max / mean / isolated of the degrees. */
+typedef struct hnsw_layer_stats {
+    int64_t num_nodes;     /* layer_sizes */
+    int32_t min_degree, max_degree;
+    double mean_degree;
+    int64_t num_isolated;  /* length of mima.isolated */
+} hnsw_layer_stats;
+int32_t hnsw_index_layer_stats(const hnsw_index *idx, int32_t layer, hnsw_layer_stats *out);
+
+/* Flattened-index file (new: the reference has no persistence; its types derive sexp but values
+ * are sexp_opaque and nothing reads one back, lib/hnsw.ml:348, lib/ohnsw.ml:312).  Little-endian
+ * header + vectors + layer 0 + upper layers; hnsw_index_load re-validates everything through
+ * hnsw_index_create. */
+int32_t hnsw_index_save(const hnsw_index *idx, const char *path);
+int32_t hnsw_index_load(const char *path, int32_t device, hnsw_index **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_search_batch",
     "hnsw_search_batch_device", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
+    "hnsw_index_layer_stats", "hnsw_index_save", "hnsw_index_load",
 ]
 
 
@@ -64,6 +65,11 @@ class _BuildParams(_C.Structure):
     _fields_ = [("num_connections", _C.c_int32), ("num_nodes_search_construction", _C.c_int32),
                 ("metric", _C.c_int32), ("id_base", _C.c_int32), ("seed", _C.c_uint64),
                 ("max_batch", _C.c_int32), ("batch_div", _C.c_int32)]
+
+
+class LayerStats(_C.Structure):
+    _fields_ = [("num_nodes", _C.c_int64), ("min_degree", _C.c_int32), ("max_degree", _C.c_int32),
+                ("mean_degree", _C.c_double), ("num_isolated", _C.c_int64)]
 
 
 class IndexInfo(_C.Structure):
@@ -101,6 +107,11 @@ def load():
     L.hnsw_build.argtypes = [vp, i64, i32, i64, vp, i32, vp]
     L.hnsw_select_neighbours_batch.argtypes = [vp, vp, i64, i64, vp, vp, i32, i32, i32, vp, vp]
     L.hnsw_select_neighbours_batch.restype = i32
+    L.hnsw_index_layer_stats.argtypes = [vp, i32, vp]
+    L.hnsw_index_save.argtypes = [vp, _C.c_char_p]
+    L.hnsw_index_load.argtypes = [_C.c_char_p, i32, vp]
+    for f in ("hnsw_index_layer_stats", "hnsw_index_save", "hnsw_index_load"):
+        getattr(L, f).restype = i32
     L.hnsw_index_export_layer0.argtypes = [vp, vp, vp]
     L.hnsw_index_export_upper_count.argtypes = [vp, i32, vp]
     L.hnsw_index_export_upper.argtypes = [vp, i32, vp, vp, vp]
@@ -200,6 +211,38 @@ class Hgraph:
             nbr = _np.empty((c.value, self.max_degree), _np.int32)
             _check(L.hnsw_index_export_upper(self.handle, l, _ptr(nodes), _ptr(deg), _ptr(nbr)))
             self.upper.append((nodes, deg, nbr))
+        return self
+
+    def stats(self):
+        """Hgraph.Stats.compute (lib/hnsw.ml:353-375): {num_nodes, layer_sizes, layer_connectivity}."""
+        out = {"num_nodes": self.n, "layer_sizes": {}, "layer_connectivity": {}}
+        for l in range(self.max_layer + 1):
+            st = LayerStats()
+            _check(load().hnsw_index_layer_stats(self.handle, l, _C.byref(st)))
+            out["layer_sizes"][l] = int(st.num_nodes)
+            out["layer_connectivity"][l] = {"min": st.min_degree, "max": st.max_degree,
+                                            "mean": st.mean_degree, "isolated": int(st.num_isolated)}
+        return out
+
+    def save(self, path):
+        """Write the flattened index (vectors + graph) to `path` (hnsw_index_save)."""
+        _check(load().hnsw_index_save(self.handle, str(path).encode()))
+
+    @classmethod
+    def load(cls, path, device=0):
+        """Read a flattened index file straight into HBM (hnsw_index_load)."""
+        h = _C.c_void_p()
+        _check(load().hnsw_index_load(str(path).encode(), device, _C.byref(h)))
+        inf = IndexInfo()
+        _check(load().hnsw_index_get_info(h, _C.byref(inf)))
+        self = cls.__new__(cls)
+        self.vectors = None
+        self.n, self.d = int(inf.n), int(inf.d)
+        self._index, self._device = h, device
+        self.id_base, self.metric = int(inf.id_base), int(inf.metric)
+        self.max_degree0, self.max_degree, self.max_layer = inf.max_degree0, inf.max_degree, inf.max_layer
+        self.entry_point = int(inf.entry_point) if inf.entry_point >= inf.id_base else None
+        self.deg0 = self.nbr0 = self.upper = None
         return self
 
     def to_device(self, device=0):

@@ -389,4 +389,120 @@ int32_t hnsw_index_export_upper(const hnsw_index *idx, int32_t layer, int64_t *n
     return HNSW_OK;
 }
 
+
+// ---- per-layer degree statistics: Hgraph.Stats (lib/hnsw.ml:353-375) -----------------------------
+int32_t hnsw_index_layer_stats(const hnsw_index *idx, int32_t layer, hnsw_layer_stats *out) {
+    if (!idx || !out) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    if (layer < 0 || layer > idx->iv.max_layer) return fail(HNSW_ERR_BAD_ARG, "layer %d out of range", layer);
+    HIP_TRY(hipSetDevice(idx->device));
+    const int64_t n = idx->iv.n;
+    int64_t cnt = 0, isolated = 0, sum = 0;
+    int mi = 1000000, ma = -1;
+    auto add = [&](const int32_t *row, int w) {
+        int dg = 0;
+        for (int j = 0; j < w; ++j) dg += row[j] >= 0;
+        mi = std::min(mi, dg); ma = std::max(ma, dg); sum += dg; cnt++; isolated += dg == 0;
+    };
+    if (layer == 0) {
+        std::vector<int32_t> rows((size_t)std::max<int64_t>(n, 1) * idx->iv.S0);
+        HIP_TRY(hipMemcpy(rows.data(), idx->dNbr0, (size_t)n * idx->iv.S0 * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) add(&rows[(size_t)i * idx->iv.S0], idx->iv.S0);
+    } else {
+        std::vector<uint8_t> lvl((size_t)std::max<int64_t>(n, 1));
+        std::vector<int32_t> off((size_t)std::max<int64_t>(n, 1)), rows((size_t)std::max<int64_t>(idx->rowsU, 1) * idx->iv.SU);
+        HIP_TRY(hipMemcpy(lvl.data(), idx->dLvl, (size_t)n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(off.data(), idx->dOff, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rows.data(), idx->dNbrU, rows.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i)
+            if (lvl[(size_t)i] >= layer) add(&rows[((size_t)off[(size_t)i] + (layer - 1)) * idx->iv.SU], idx->iv.SU);
+    }
+    out->num_nodes = cnt; out->min_degree = cnt ? mi : 0; out->max_degree = cnt ? ma : 0;
+    out->mean_degree = cnt ? (double)sum / (double)cnt : 0.0; out->num_isolated = isolated;
+    return HNSW_OK;
+}
+
+// ---- flattened-index file: header + vectors + layer 0 + upper layers (little endian) ---------------
+namespace {
+struct FileHeader {
+    char magic[8];        // "HNSWMI35"
+    uint32_t version;     // 1
+    int32_t d, metric, id_base, max_degree0, max_degree, max_layer, reserved;
+    int64_t n, entry_point;
+};
+bool wr(FILE *f, const void *p, size_t bytes) { return bytes == 0 || fwrite(p, 1, bytes, f) == bytes; }
+bool rd(FILE *f, void *p, size_t bytes) { return bytes == 0 || fread(p, 1, bytes, f) == bytes; }
+} // namespace
+
+int32_t hnsw_index_save(const hnsw_index *idx, const char *path) {
+    if (!idx || !path) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(idx->device));
+    const int64_t n = idx->iv.n; const int d = idx->iv.d; const int S0 = idx->iv.S0, SU = idx->iv.SU;
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(HNSW_ERR_BAD_ARG, "cannot open %s for writing", path);
+    FileHeader h{};
+    memcpy(h.magic, "HNSWMI35", 8); h.version = 1; h.d = d; h.metric = idx->info.metric; h.id_base = idx->iv.id_base;
+    h.max_degree0 = S0; h.max_degree = idx->info.max_degree; h.max_layer = idx->iv.max_layer; h.n = n;
+    h.entry_point = idx->info.entry_point;
+    bool ok = wr(f, &h, sizeof h);
+    {   // vectors, unpadded, in chunks
+        const int64_t stride = idx->iv.stride;
+        const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / (stride * 4));
+        std::vector<float> stage((size_t)chunk * stride), packed((size_t)chunk * d);
+        for (int64_t r0 = 0; ok && r0 < n; r0 += chunk) {
+            const int64_t nr = std::min(chunk, n - r0);
+            if (hipMemcpy(stage.data(), (const float *)idx->dX + r0 * stride, (size_t)nr * stride * 4, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+            for (int64_t i = 0; i < nr; ++i) memcpy(&packed[(size_t)i * d], &stage[(size_t)i * stride], (size_t)d * 4);
+            ok = wr(f, packed.data(), (size_t)nr * d * 4);
+        }
+    }
+    std::vector<int32_t> deg0((size_t)std::max<int64_t>(n, 1)), nbr0((size_t)std::max<int64_t>(n, 1) * S0);
+    if (ok && n > 0) ok = hnsw_index_export_layer0(idx, deg0.data(), nbr0.data()) == HNSW_OK;
+    ok = ok && wr(f, deg0.data(), (size_t)n * 4) && wr(f, nbr0.data(), (size_t)n * S0 * 4);
+    for (int l = 1; ok && l <= idx->iv.max_layer; ++l) {
+        int64_t c = 0;
+        ok = hnsw_index_export_upper_count(idx, l, &c) == HNSW_OK;
+        std::vector<int64_t> nodes((size_t)std::max<int64_t>(c, 1));
+        std::vector<int32_t> deg((size_t)std::max<int64_t>(c, 1)), nbr((size_t)std::max<int64_t>(c, 1) * SU);
+        ok = ok && hnsw_index_export_upper(idx, l, nodes.data(), deg.data(), nbr.data()) == HNSW_OK;
+        ok = ok && wr(f, &c, 8) && wr(f, nodes.data(), (size_t)c * 8) && wr(f, deg.data(), (size_t)c * 4) && wr(f, nbr.data(), (size_t)c * SU * 4);
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(HNSW_ERR_HIP, "writing %s failed", path);
+    return HNSW_OK;
+}
+
+int32_t hnsw_index_load(const char *path, int32_t device, hnsw_index **out) {
+    if (!path || !out) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(HNSW_ERR_BAD_ARG, "cannot open %s", path);
+    FileHeader h{};
+    if (!rd(f, &h, sizeof h) || memcmp(h.magic, "HNSWMI35", 8) != 0 || h.version != 1) { fclose(f); return fail(HNSW_ERR_BAD_ARG, "%s is not a flattened hnsw index (version 1)", path); }
+    if (h.n < 0 || h.n > 0x7FFFFFF0LL || h.d < 1 || h.max_degree0 < 1 || h.max_degree0 > 64 || h.max_layer < 0 || h.max_layer > 255) { fclose(f); return fail(HNSW_ERR_BAD_ARG, "%s: corrupt header", path); }
+    const int64_t n = h.n;
+    const int SU = h.max_layer > 0 ? h.max_degree : 1;
+    if (h.max_layer > 0 && (SU < 1 || SU > 64)) { fclose(f); return fail(HNSW_ERR_BAD_ARG, "%s: corrupt header", path); }
+    std::vector<float> X((size_t)std::max<int64_t>(n, 1) * h.d);
+    std::vector<int32_t> deg0((size_t)std::max<int64_t>(n, 1)), nbr0((size_t)std::max<int64_t>(n, 1) * h.max_degree0);
+    bool ok = rd(f, X.data(), (size_t)n * h.d * 4) && rd(f, deg0.data(), (size_t)n * 4) && rd(f, nbr0.data(), (size_t)n * h.max_degree0 * 4);
+    std::vector<std::vector<int64_t>> nodes((size_t)h.max_layer);
+    std::vector<std::vector<int32_t>> deg((size_t)h.max_layer), nbr((size_t)h.max_layer);
+    std::vector<hnsw_layer_desc> layers((size_t)std::max(h.max_layer, 1));
+    for (int l = 0; ok && l < h.max_layer; ++l) {
+        int64_t c = 0;
+        ok = rd(f, &c, 8) && c >= 0 && c <= n;
+        if (!ok) break;
+        nodes[(size_t)l].resize((size_t)std::max<int64_t>(c, 1)); deg[(size_t)l].resize((size_t)std::max<int64_t>(c, 1)); nbr[(size_t)l].resize((size_t)std::max<int64_t>(c, 1) * SU);
+        ok = rd(f, nodes[(size_t)l].data(), (size_t)c * 8) && rd(f, deg[(size_t)l].data(), (size_t)c * 4) && rd(f, nbr[(size_t)l].data(), (size_t)c * SU * 4);
+        layers[(size_t)l] = hnsw_layer_desc{c, nodes[(size_t)l].data(), deg[(size_t)l].data(), nbr[(size_t)l].data()};
+    }
+    fclose(f);
+    if (!ok) return fail(HNSW_ERR_BAD_ARG, "%s: truncated or corrupt", path);
+    hnsw_index_desc d{};
+    d.vectors = X.data(); d.n = n; d.d = h.d; d.row_stride = h.d; d.metric = h.metric; d.id_base = h.id_base;
+    d.max_degree0 = h.max_degree0; d.max_degree = h.max_degree; d.max_layer = h.max_layer; d.entry_point = h.entry_point;
+    d.deg0 = deg0.data(); d.nbr0 = nbr0.data(); d.upper = layers.data();
+    return hnsw_index_create(&d, device, out);   // re-validates every id and degree
+}
+
 } // extern "C"

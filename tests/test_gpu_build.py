@@ -129,3 +129,23 @@ def test_select_neighbours_operator_matches_oracle(H, oracle, metric, d, M, nc):
     got2 = H.Ohnsw.select_neighbours(hg, T, [c[:M] for c in cands], M, keep_all_if_few=True)
     for c, g in zip(cands, got2):
         assert sorted(g) == sorted(c[:M])
+
+
+def test_save_load_stats_roundtrip(H, oracle, built, tmp_path):
+    X, hg = built
+    p = tmp_path / "index.hnsw"
+    hg.save(p)
+    again = H.Hgraph.load(p)
+    Q = _uniform(200, 32, 9)
+    a = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=50)
+    b = H.Ohnsw.knn_batch_bigarray(again, 10, Q, ef=50)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    st = again.stats()                                  # Hgraph.Stats (lib/hnsw.ml:353-375)
+    assert st["num_nodes"] == hg.n and st["layer_sizes"][0] == hg.n
+    assert st["layer_connectivity"][0]["max"] == int(hg.deg0.max())
+    assert st["layer_connectivity"][0]["mean"] == pytest.approx(float(hg.deg0.mean()))
+    assert st["layer_sizes"][1] == len(hg.upper[0][0])
+    (tmp_path / "bad.hnsw").write_bytes(b"not an index")
+    with pytest.raises(H.InvalidArgument, match="not a flattened hnsw index"):
+        H.Hgraph.load(tmp_path / "bad.hnsw")
