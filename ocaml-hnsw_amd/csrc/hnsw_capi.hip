@@ -86,7 +86,7 @@ hipError_t dispatch_nch(int nch, int nslot, const IndexView &iv, const SearchArg
 template <int METRIC>
 hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq,
                          const int32_t *ids, int32_t m, float *out, hipStream_t st) {
-    const unsigned gy = (unsigned)std::max(1, std::min(64, (m + 3) / 4));
+    const unsigned gy = (unsigned)std::max(1, std::min(256, (m + 15) / 16));
     dim3 grid((unsigned)nq, gy), block(64);
     switch (nch) {
     case 1: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<1, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;

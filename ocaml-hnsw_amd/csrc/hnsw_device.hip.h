@@ -532,11 +532,13 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
 }
 
 // ---- gathered distances (bench_dist/bench_dist.ml counterpart) --------------------------------
-// one 16-lane group per (query, id) pair; a wave handles 4 pairs of the same query per step.
+// One 16-lane group per (query, id) pair, UB x 4 pairs of the same query in flight per wave; same
+// arithmetic and summation order as the search kernel.
 template <int NCH, int METRIC>
 __global__ void __launch_bounds__(64)
 hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq,
                      const int32_t *ids, int32_t m, float *out) {
+    constexpr int UB = NCH <= 2 ? 4 : (NCH <= 4 ? 2 : 1);
     const int lane = threadIdx.x;
     const int r = lane >> 4, l16 = lane & 15;
     const int64_t q = blockIdx.x;
@@ -544,32 +546,44 @@ hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64
     float4 qv[NCH];
     load_query<NCH>(qv, Q + q * q_stride, iv.d, l16);
     const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
-    const int64_t stride4 = iv.stride >> 2;
-    for (int base = blockIdx.y * 4; base < m; base += 4 * gridDim.y) {
-        const int j = base + r;
-        const bool valid = j < m;
-        const int id = valid ? ids[q * m + j] - iv.id_base : 0;
-        const float4 *row = X4 + (int64_t)id * stride4;
-        float acc = 0.f;
+    const uint32_t stride4 = (uint32_t)(iv.stride >> 2);
+    for (int base = blockIdx.y * 4 * UB; base < m; base += 4 * UB * gridDim.y) {
+        float4 v[UB][NCH];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = i * 16 + l16;
-            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid && c < iv.nchunks) z = row[c];
-            if (METRIC == 0) {
-                float dx = z.x - qv[i].x; acc = __builtin_fmaf(dx, dx, acc);
-                float dy = z.y - qv[i].y; acc = __builtin_fmaf(dy, dy, acc);
-                float dz = z.z - qv[i].z; acc = __builtin_fmaf(dz, dz, acc);
-                float dw = z.w - qv[i].w; acc = __builtin_fmaf(dw, dw, acc);
-            } else {
-                acc = __builtin_fmaf(z.x, qv[i].x, acc);
-                acc = __builtin_fmaf(z.y, qv[i].y, acc);
-                acc = __builtin_fmaf(z.z, qv[i].z, acc);
-                acc = __builtin_fmaf(z.w, qv[i].w, acc);
+        for (int u = 0; u < UB; ++u) {
+            const int j = base + 4 * u + r;
+            const int je = j < m ? j : base;            // past the end: re-read a row already in flight
+            const uint32_t row4 = (uint32_t)(ids[q * m + je] - iv.id_base) * stride4;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = i * 16 + l16;
+                v[u][i] = X4[row4 + (uint32_t)(c < iv.nchunks ? c : 0)];
             }
         }
-        acc = reduce16(acc);
-        if (valid && l16 == 0) out[q * m + j] = key_to_dist<METRIC>(dist_to_key<METRIC>(acc));
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                float4 z = v[u][i];
+                const bool cv = (i * 16 + l16) < iv.nchunks;
+                z.x = cv ? z.x : 0.f; z.y = cv ? z.y : 0.f; z.z = cv ? z.z : 0.f; z.w = cv ? z.w : 0.f;
+                if (METRIC == 0) {
+                    float dx = z.x - qv[i].x; acc = __builtin_fmaf(dx, dx, acc);
+                    float dy = z.y - qv[i].y; acc = __builtin_fmaf(dy, dy, acc);
+                    float dz = z.z - qv[i].z; acc = __builtin_fmaf(dz, dz, acc);
+                    float dw = z.w - qv[i].w; acc = __builtin_fmaf(dw, dw, acc);
+                } else {
+                    acc = __builtin_fmaf(z.x, qv[i].x, acc);
+                    acc = __builtin_fmaf(z.y, qv[i].y, acc);
+                    acc = __builtin_fmaf(z.z, qv[i].z, acc);
+                    acc = __builtin_fmaf(z.w, qv[i].w, acc);
+                }
+            }
+            acc = reduce16(acc);
+            const int j = base + 4 * u + r;
+            if (j < m && l16 == 0) out[q * m + j] = key_to_dist<METRIC>(dist_to_key<METRIC>(acc));
+        }
     }
 }
 
