@@ -169,8 +169,7 @@ int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_strid
     }
     bv.iv = idx->iv; bv.nbr0_w = (int32_t *)idx->dNbr0; bv.nbrU_w = (int32_t *)idx->dNbrU;
     bv.efc = efc; bv.cand_stride = cand_stride;
-    bv.vt_bits = 8;
-    while ((1 << bv.vt_bits) < 16 * efc && bv.vt_bits < 13) ++bv.vt_bits;
+    bv.vt_bits = efc <= 256 ? 11 : 12;
     while (bv.vt_bits < 16 && ((int64_t)1 << (bv.vt_bits + 15)) < n) ++bv.vt_bits;
 
     HIP_TRY_B(hipStreamCreate(&st));

@@ -190,11 +190,13 @@ __device__ __forceinline__ void eval_candidates(const IndexView &iv, const float
 constexpr uint32_t DUMMY_HI = 0xFFFFFFFEu;
 constexpr uint64_t KEY64_DUMMY = ((uint64_t)DUMMY_HI << 32) | 0xFFFFFFFFull;
 constexpr uint64_t KEY64_PAD = 1ull;
+constexpr uint64_t KEY64_INF = ~0ull;
 // the id field stores id + 1, so every real key is >= 2 > KEY64_PAD even at distance 0, node 0
 __device__ __forceinline__ uint32_t key_id(uint64_t k) { return ((uint32_t)k >> 1) - 1u; }
 
 template <int NSLOT> struct WList {
     uint64_t key[NSLOT];
+    uint64_t slotmax;     // NSLOT > 2 only: lane s holds key[s] of lane 63 (the slot's maximum)
     uint64_t wmax64;      // key of the top entry = max(W); flag bit kept in sync
     uint32_t wmax;        // its distance part: the accept threshold (DUMMY_HI while |W| < ef)
     // entries evicted while tied with max(W) and not yet expanded (still poppable, lib/ohnsw.ml:568)
@@ -219,6 +221,7 @@ __device__ __forceinline__ void wlist_init(WList<NSLOT> &w, int ef, int lane) {
     const int base = NSLOT * 64 - ef;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) w.key[s] = (s * 64 + lane) < base ? KEY64_PAD : KEY64_DUMMY;
+    w.slotmax = (lane < NSLOT && (lane + 1) * 64 > base) ? KEY64_DUMMY : (lane < NSLOT ? KEY64_PAD : KEY64_INF);
     w.wmax64 = KEY64_DUMMY; w.wmax = DUMMY_HI; w.ovf_cnt = 0; w.ovf_key = 0;
 }
 template <int NSLOT> __device__ __forceinline__ bool wlist_full(const WList<NSLOT> &w) { return w.wmax != DUMMY_HI; }
@@ -240,21 +243,38 @@ __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint3
                                              uint32_t *ovf_lds, uint32_t &status) {
     const uint64_t K = ((uint64_t)kd << 32) | ((uint64_t)(kid + 1u) << 1);
     const uint64_t K2 = K + 2;
-    int p = 0, q = 0;
+    int p = 0, q = 0, first = 0;
+    if (NSLOT <= 2) {
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        p += __popcll(__ballot(w.key[s] < K));
-        q += __popcll(__ballot(w.key[s] < K2));   // counts K and K|1 too
+        for (int s = 0; s < NSLOT; ++s) {
+            p += __popcll(__ballot(w.key[s] < K));
+            q += __popcll(__ballot(w.key[s] < K2));   // counts K and K|1 too
+        }
+    } else {
+        // the slot holding the rank position: the first whose maximum is not below K
+        first = __popcll(__ballot(w.slotmax < K));   // lanes >= NSLOT hold ~0
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (s == first) {
+                p = s * 64 + __popcll(__ballot(w.key[s] < K));
+                q = s * 64 + __popcll(__ballot(w.key[s] < K2));
+            }
+        }
     }
     if (p != q) return;                           // already in W
     const uint64_t ev = w.wmax64;                 // the entry that falls off
 #pragma unroll
     for (int s = NSLOT - 1; s >= 0; --s) {
+        if (NSLOT > 2 && s < first) continue;     // slots wholly below the rank stay (uniform)
         uint64_t carry = 0;
         if (s > 0) carry = rdlane64(w.key[s - 1], 63);
         const uint64_t sh = wave_shr1_64(w.key[s], carry);
         const int idx = s * 64 + lane;
         w.key[s] = idx < p ? w.key[s] : (idx == p ? K : sh);
+        if (NSLOT > 2) {
+            const uint64_t mx = rdlane64(w.key[s], 63);
+            w.slotmax = (lane == s) ? mx : w.slotmax;
+        }
     }
     w.wmax64 = rdlane64(w.key[NSLOT - 1], 63);
     w.wmax = (uint32_t)(w.wmax64 >> 32);

@@ -95,3 +95,27 @@ if os.environ.get("PREF_STATS"):
         H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef)
     dt = (time.perf_counter() - t) / 5
     print("host-buffer hnsw_search_batch (H2D + kernel + D2H + sync): %.3f ms/batch = %.0f q/s" % (dt * 1e3, nq / dt))
+
+if os.environ.get("ORDER_EXPERIMENT"):
+    # does co-scheduling spatially close queries on one XCD pay?  (host-side emulation)
+    nq, ef, k = 10000, 128, 10
+    Qd = make(nq, 2)
+    g = torch.Generator(device=dev); g.manual_seed(1234)
+    cen = torch.randint(20, 200, (centres, d), generator=g, device=dev).float()
+    cid = torch.cdist(Qd, cen).argmin(1)
+    order = torch.argsort(cid)
+    per = (nq + 7) // 8
+    b = torch.arange(nq, device=dev)
+    spos = (b % 8) * per + b // 8
+    spos = torch.clamp(spos, max=nq - 1)
+    variants = {"unsorted": Qd, "sorted (block-contiguous)": Qd[order], "sorted + xcd-aware": Qd[order][spos]}
+    ids = torch.empty((nq, k), dtype=torch.int32, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    for name, Qv in variants.items():
+        Qv = Qv.contiguous()
+        ts = []
+        for _ in range(7):
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            H.search_batch_device(hg, Qv.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(), 0, 0, 0, stream.cuda_stream)
+            e.record(stream); torch.cuda.synchronize(); ts.append(a.elapsed_time(e))
+        print("%-28s %.3f ms  %.0f q/s" % (name, np.median(ts), nq / np.median(ts) * 1e3), flush=True)
