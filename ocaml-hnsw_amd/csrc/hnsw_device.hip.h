@@ -54,6 +54,9 @@ struct SearchArgs {
     int32_t *out_ids;
     float *out_dist;
     uint32_t *out_ndist, *out_nhops, *out_status;
+    const int32_t *qmap;     // optional: block b searches query qmap[b] (re-run of flagged queries)
+    uint32_t *ovf_g;         // optional: [grid][ovf_gcap] global overflow slabs
+    int32_t ovf_gcap;
 };
 
 // ---- distance keys -------------------------------------------------------------------------
@@ -205,6 +208,22 @@ template <int NSLOT> struct WList {
 };
 
 constexpr int OVF_CAP = 64; // LDS entries
+// the stack of tied evicted entries: OVF_CAP in LDS, then an optional global slab (the exact
+// fallback the host entry point uses for the rare queries that need more)
+struct OvfStore {
+    uint32_t *lds;
+    uint32_t *g;
+    int gcap;
+};
+__device__ __forceinline__ bool ovf_push(const OvfStore &ov, int at, uint32_t id, int lane) {
+    if (at < OVF_CAP) { if (lane == 0) ov.lds[at] = id; return true; }
+    if (ov.g && at - OVF_CAP < ov.gcap) { if (lane == 0) ov.g[at - OVF_CAP] = id; return true; }
+    return false;
+}
+__device__ __forceinline__ uint32_t ovf_get(const OvfStore &ov, int at) {
+    if (at < OVF_CAP) return ov.lds[at];
+    return ov.g ? ov.g[at - OVF_CAP] : 0u;
+}
 
 __device__ __forceinline__ uint64_t rdlane64(uint64_t v, int lane) {
     const uint32_t lo = rdlane((uint32_t)v, lane), hi = rdlane((uint32_t)(v >> 32), lane);
@@ -240,7 +259,7 @@ template <int NSLOT> __device__ __forceinline__ int wlist_count(const WList<NSLO
 // the farthest.  Duplicates (same id already in W: a re-evaluated node) are ignored.
 template <int NSLOT>
 __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint32_t kid, int lane,
-                                             uint32_t *ovf_lds, uint32_t &status) {
+                                             const OvfStore &ov, uint32_t &status) {
     const uint64_t K = ((uint64_t)kd << 32) | ((uint64_t)(kid + 1u) << 1);
     const uint64_t K2 = K + 2;
     int p = 0, q = 0, first = 0;
@@ -280,7 +299,7 @@ __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint3
     w.wmax = (uint32_t)(w.wmax64 >> 32);
     if (w.ovf_cnt > 0 && w.ovf_key != w.wmax) w.ovf_cnt = 0;          // max(W).d dropped: all dead
     if (!(ev & 1ull) && (uint32_t)(ev >> 32) == w.wmax) {              // evicted, tied, unexpanded
-        if (w.ovf_cnt < OVF_CAP) { if (lane == 0) ovf_lds[w.ovf_cnt] = key_id(ev); w.ovf_cnt++; }
+        if (ovf_push(ov, w.ovf_cnt, key_id(ev), lane)) w.ovf_cnt++;
         else status |= 1u;
         w.ovf_key = w.wmax;
     }
@@ -332,7 +351,7 @@ struct WaveCtx {
     int32_t *cand_id;    // [64]
     uint32_t *cand_key;  // [64]
     uint32_t *trash;     // [64] write-only sink shared by every masked-off store
-    uint32_t *ovf;       // [OVF_CAP]
+    OvfStore ovf;        // lds: [OVF_CAP]
 };
 // 4 KiB of tags at vt_bits = 11 plus 1 KiB: 32 waves per CU fit the 160 KiB LDS
 __host__ __device__ inline size_t wave_lds_words(int vt_bits) { return (((size_t)1 << vt_bits) >> 1) + 192 + OVF_CAP; }
@@ -346,7 +365,7 @@ __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane
     cx.cand_id = reinterpret_cast<int32_t *>(rest);
     cx.cand_key = rest + 64;
     cx.trash = rest + 128;
-    cx.ovf = rest + 192;
+    cx.ovf.lds = rest + 192; cx.ovf.g = nullptr; cx.ovf.gcap = 0;
     return cx;
 }
 __device__ __forceinline__ void visited_clear(const WaveCtx &cx) { // Visited.clear, lib/ohnsw.ml:262
@@ -430,7 +449,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         else {
             // no unexpanded member of W: only entries evicted while tied with max(W) can still
             // satisfy "not (c.d > max(W).d)" (:568)
-            if (w.ovf_cnt > 0 && w.ovf_key == w.wmax) c = (int)cx.ovf[--w.ovf_cnt];
+            if (w.ovf_cnt > 0 && w.ovf_key == w.wmax) { __syncthreads(); c = (int)ovf_get(cx.ovf, --w.ovf_cnt); }
             else break;
         }
         n_hops++;
@@ -502,9 +521,10 @@ __global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES)
 hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
-    const int64_t q = blockIdx.x;
-    if (q >= a.nq) return;
-    const WaveCtx cx = make_ctx(lds, a.vt_bits, lane);
+    if ((int64_t)blockIdx.x >= a.nq) return;
+    const int64_t q = a.qmap ? a.qmap[blockIdx.x] : (int64_t)blockIdx.x;
+    WaveCtx cx = make_ctx(lds, a.vt_bits, lane);
+    if (a.ovf_g) { cx.ovf.g = a.ovf_g + (int64_t)blockIdx.x * a.ovf_gcap; cx.ovf.gcap = a.ovf_gcap; }
 
     float4 qv[NCH];
     load_query<NCH>(qv, a.Q + q * a.q_stride, iv.d, cx.l16);

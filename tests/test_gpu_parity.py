@@ -299,3 +299,46 @@ def test_reference_select_neighbours_kats(H, case):
     M = min(case["M"], 64)
     got = H.Ohnsw.select_neighbours(hg, np.array([[case["target"]]], np.float32), [case["candidates"]], M)
     assert sorted(got[0]) == case["expect"]
+
+
+def test_tie_overflow_beyond_lds_stack(H, oracle):
+    """More than 64 entries evicted while tied with max(W) and still unexpanded (lib/ohnsw.ml:568 keeps
+    them poppable): the asynchronous entry point flags the query, the host entry point re-runs it with a
+    global slab and must equal the oracle -- including a node reachable only through such an entry."""
+    import torch
+    # 1-D positions, query at 0: E far, 127 identical "shell" points at 10, a chain approaching, Z close
+    n = 229
+    pos = np.zeros(n, np.float32)
+    pos[0] = 20.0
+    pos[1:128] = 10.0
+    pos[128:228] = 9.0 - 0.01 * np.arange(100)
+    pos[228] = 0.1
+    rows = [[] for _ in range(n)]
+    rows[0] = [1] + list(range(2, 65))            # E -> H + 63 shells
+    rows[1] = list(range(65, 128)) + [128]        # H -> 63 shells + head of the chain
+    for i in range(99):
+        rows[128 + i] = [129 + i]
+    rows[40] = [228]                              # a shell evicted late is the only way to Z
+    deg0 = np.array([len(r) for r in rows], np.int32)
+    nbr0 = np.full((n, 64), -1, np.int32)
+    for i, r in enumerate(rows):
+        nbr0[i, :len(r)] = r
+    X = pos[:, None]
+    g = oracle.Graph(n, 0, deg0, nbr0)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    hg = H.Hgraph(X, deg0, nbr0, entry_point=0, max_degree=32)
+    Q = np.zeros((3, 1), np.float32)
+    want = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=10, ef=128, ties=oracle.TIES_CANONICAL, counters=True)
+    assert 228 in want[0][0]                       # the oracle does reach Z
+    got = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=128, counters=True)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    np.testing.assert_array_equal(got[3], want[3])
+    dev = torch.device("cuda", 0)
+    Qd = torch.from_numpy(Q).to(dev)
+    ids = torch.empty((3, 10), dtype=torch.int32, device=dev)
+    dd = torch.empty((3, 10), dtype=torch.float32, device=dev)
+    st = torch.zeros(3, dtype=torch.int32, device=dev)
+    H.search_batch_device(hg, Qd.data_ptr(), 3, 1, 128, 10, ids.data_ptr(), dd.data_ptr(), 0, 0, st.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert ((st.cpu().numpy() & 1) == 1).all()     # flagged: more than 64 tied evicted entries
