@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=4000, help="queries timed on the CPU restatement")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured path) or gloo (functional rehearsal of N > 1 on fewer GPUs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,13 +93,18 @@ def main():
     H.load()
     if H.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the search path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collectives run
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n, d, nq, k, ef = args.n, args.d, args.nq, args.k, args.ef
     t0 = time.time()
@@ -112,16 +118,16 @@ def main():
     # ---- index: built on the GPU by rank 0, replicated to every rank ----
     t0 = time.time()
     if rank == 0:
-        hg = H.Ohnsw.build_batch_bigarray(X, args.M, args.efc, seed=1, device=local_rank)
+        hg = H.Ohnsw.build_batch_bigarray(X, args.M, args.efc, seed=1, device=gpu)
         build_s = time.time() - t0
         log("graph built on the GPU in %.1fs (max_layer %d)" % (build_s, hg.max_layer))
         if world > 1 or not args.no_cpu:
             hg.export()
     if world > 1:
         import ocaml_hnsw_amd.sharding as sharding
-        deg0, nbr0, upper, entry = sharding.replicate_graph(dist, dev, hg if rank == 0 else None, args.M)
+        deg0, nbr0, upper, entry = sharding.replicate_graph(dist, cdev, hg if rank == 0 else None, args.M)
         if rank != 0:
-            hg = H.Hgraph(X, deg0, nbr0, upper, entry_point=entry, id_base=0, max_degree=args.M).to_device(local_rank)
+            hg = H.Hgraph(X, deg0, nbr0, upper, entry_point=entry, id_base=0, max_degree=args.M).to_device(gpu)
         del deg0, nbr0, upper
 
     # ---- device buffers; the kernel is launched on torch's current stream ----
@@ -130,8 +136,16 @@ def main():
     nd_d = torch.zeros(nq, dtype=torch.int32, device=dev)
     nh_d = torch.zeros(nq, dtype=torch.int32, device=dev)
     if world > 1:
-        all_ids = torch.empty((world * nq, k), dtype=torch.int32, device=dev)
-        all_dist = torch.empty((world * nq, k), dtype=torch.float32, device=dev)
+        all_ids = torch.empty((world * nq, k), dtype=torch.int32, device=cdev)
+        all_dist = torch.empty((world * nq, k), dtype=torch.float32, device=cdev)
+
+    def gather():   # the exchange step: per-shard results -> every rank (RCCL all-gather over xGMI)
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(all_ids, ids_d)
+            dist.all_gather_into_tensor(all_dist, dist_d)
+        else:
+            dist.all_gather_into_tensor(all_ids, ids_d.cpu())
+            dist.all_gather_into_tensor(all_dist, dist_d.cpu())
     stream = torch.cuda.current_stream()
 
     def search(ef_, counters=False):
@@ -141,9 +155,8 @@ def main():
 
     def step(ef_):
         search(ef_)
-        if world > 1:   # the exchange step: per-shard results -> every rank
-            dist.all_gather_into_tensor(all_ids, ids_d)
-            dist.all_gather_into_tensor(all_dist, dist_d)
+        if world > 1:
+            gather()
 
     def sync():
         if world > 1:
@@ -161,13 +174,12 @@ def main():
             search(ef_)
             ev[i][1].record(stream)
             if world > 1:
-                dist.all_gather_into_tensor(all_ids, ids_d)
-                dist.all_gather_into_tensor(all_dist, dist_d)
+                gather()
         sync()
         wall = time.perf_counter() - t
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         if world > 1:
-            w = torch.tensor([wall], dtype=torch.float64, device=dev)
+            w = torch.tensor([wall], dtype=torch.float64, device=cdev)
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             wall = float(w[0])
         return wall, kern_ms
@@ -178,6 +190,9 @@ def main():
 
     # ---- recall@10 on rank 0 (exact ground truth on the GPU) ----
     checks = {}
+    if world > 1:   # the gathered table holds this rank's shard at its place
+        mine = all_ids[rank * nq:(rank + 1) * nq]
+        checks["gathered_shard_matches"] = bool(torch.equal(mine.to(ids_d.device), ids_d))
     search(ef, counters=True)
     torch.cuda.synchronize()
     got = ids_d.cpu().numpy()
