@@ -244,9 +244,16 @@ def main():
             checks["parity_dist_bits_equal"] = bool(np.array_equal(odist.view(np.uint32), got_dist[:sample].view(np.uint32)))
             checks["gpu_reevaluation_overhead"] = round(float(gpu_nd[:sample].mean() / max(ond.mean(), 1) - 1), 4)
             if world == 1:
+                ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                t = time.perf_counter()
+                mids, _ = o.knn_batch_all_cores(g, sp, Qd.cpu().numpy(), k, ef, ncores)
+                mt_s = time.perf_counter() - t
+                checks["cpu_all_cores_ids_equal"] = bool(np.array_equal(mids, got))
                 cpu_baseline = {"value": round(sample / cpu_s, 1), "unit": "queries/s", "cores": 1, "kind": "port",
                                 "sample": "%d of the %d queries, same graph, ef=%d k=%d, single-thread C restatement "
-                                          "of Ohnsw.knn_batch_bigarray (not OCaml)" % (sample, nq, ef, k)}
+                                          "of Ohnsw.knn_batch_bigarray (not OCaml); the reference is single-threaded" % (sample, nq, ef, k),
+                                "all_cores": {"value": round(nq / mt_s, 1), "cores": ncores,
+                                              "sample": "all %d queries split over %d host threads" % (nq, ncores)}}
             log("cpu restatement: %.1f q/s on %d queries; parity ids=%s dist=%s" %
                 (sample / cpu_s, sample, checks["parity_ids_equal"], checks["parity_dist_bits_equal"]))
         # B_q = n_dist*(4d+4) + n_hops*4S + 4d + 8k   

@@ -570,6 +570,47 @@ int32_t og_ohnsw_knn_batch(const og_graph *g, og_space *sp, const float *Q, int6
     return 0;
 }
 
+/* The same batch loop with the queries split over host threads (each with its own Visited and
+ * arena).  The reference itself is single-threaded (lib/ohnsw.ml:883 is a sequential fold); this
+ * variant only exists so the CPU baseline can also be quoted on all host cores. */
+#include <pthread.h>
+typedef struct mt_job {
+    const og_graph *g; const og_space *sp; const float *Q; int64_t q0, q1, q_stride;
+    int32_t ef, k, ties; int32_t *out_ids; float *out_dist;
+} mt_job;
+static void *mt_worker(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    og_space sp = *j->sp;   /* private distance-call counter */
+    scratch *s = scratch_create(j->g->view.n);
+    int64_t *nodes = (int64_t *)malloc(sizeof(int64_t) * (size_t)j->k);
+    double *dists = (double *)malloc(sizeof(double) * (size_t)j->k);
+    for (int64_t q = j->q0; q < j->q1; ++q) {
+        for (int32_t i = 0; i < j->k; ++i) { j->out_dist[q * j->k + i] = NAN; j->out_ids[q * j->k + i] = -1; }
+        int32_t cnt = ohnsw_knn_view(&j->g->view, j->g->max_layer, j->g->entry_point, &sp, s,
+                                     (const void *)(j->Q + q * j->q_stride), j->ef, j->k, j->ties, nodes, dists, NULL);
+        for (int32_t i = 0; i < cnt; ++i) { j->out_dist[q * j->k + i] = (float)dists[i]; j->out_ids[q * j->k + i] = (int32_t)nodes[i]; }
+    }
+    free(nodes); free(dists);
+    scratch_destroy(s);
+    return NULL;
+}
+int32_t og_ohnsw_knn_batch_mt(const og_graph *g, og_space *sp, const float *Q, int64_t nq,
+                              int64_t q_stride, int32_t ef, int32_t k, int32_t ties, int32_t nthreads,
+                              int32_t *out_ids, float *out_dist) {
+    if (g->entry_point < 0) return -1;
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)nthreads);
+    for (int32_t t = 0; t < nthreads; ++t) {
+        mt_job j = { g, sp, Q, nq * t / nthreads, nq * (t + 1) / nthreads, q_stride, ef, k, ties, out_ids, out_dist };
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    }
+    for (int32_t t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+    return 0;
+}
+
 /* ======================================================================================== */
 /* functor path                                                                             */
 /* ======================================================================================== */

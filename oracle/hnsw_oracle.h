@@ -107,6 +107,11 @@ int32_t og_ohnsw_knn_batch(const og_graph *g, og_space *sp, const float *Q, int6
                            int32_t *out_ids, float *out_dist, uint32_t *out_ndist,
                            uint32_t *out_nhops);
 
+/* the same over `nthreads` host threads (CPU baseline on all cores; the reference is 1 thread) */
+int32_t og_ohnsw_knn_batch_mt(const og_graph *g, og_space *sp, const float *Q, int64_t nq,
+                              int64_t q_stride, int32_t ef, int32_t k, int32_t ties, int32_t nthreads,
+                              int32_t *out_ids, float *out_dist);
+
 /* ---- functor path: lib/hnsw_algo.ml + lib/hnsw.ml ----------------------------------------- */
 int64_t og_functor_search_one(const og_graph *g, int32_t layer, og_space *sp, int64_t start,
                               const void *target, int32_t ties, double *out_dist,

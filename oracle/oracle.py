@@ -29,7 +29,7 @@ def build(force=False):
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return _LIB_PATH
     cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-fPIC", "-shared", "-mavx2", "-mfma",
-           "-ffp-contract=off", src, "-o", _LIB_PATH, "-lm"]
+           "-ffp-contract=off", src, "-o", _LIB_PATH, "-lm", "-lpthread"]
     subprocess.check_call(cmd)
     return _LIB_PATH
 
@@ -68,6 +68,8 @@ def lib():
     L.og_ohnsw_knn.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.og_ohnsw_knn_batch.restype = i32
     L.og_ohnsw_knn_batch.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp]
+    L.og_ohnsw_knn_batch_mt.restype = i32
+    L.og_ohnsw_knn_batch_mt.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp]
     L.og_functor_search_one.restype = i64
     L.og_functor_search_one.argtypes = [vp, i32, vp, i64, vp, i32, vp, vp]
     L.og_functor_search.restype = i32
@@ -312,6 +314,19 @@ class Ohnsw:
         if r < 0:
             raise ValueError("knn: empty hgraph")
         return (ids, dist, nd, nh) if counters else (ids, dist)
+
+
+def knn_batch_all_cores(graph, space, batch, k, ef, nthreads, ties=TIES_CANONICAL):
+    """Ohnsw.knn_batch_bigarray with the query loop split over host threads (baseline only)."""
+    Q = np.ascontiguousarray(batch, dtype=np.float32)
+    nq = Q.shape[0]
+    ids = np.empty((nq, k), np.int32)
+    dist = np.empty((nq, k), np.float32)
+    r = lib().og_ohnsw_knn_batch_mt(graph._h, space.ref(), _ptr(Q), nq, Q.shape[1], ef, k, ties, nthreads,
+                                    _ptr(ids), _ptr(dist))
+    if r < 0:
+        raise ValueError("knn: empty hgraph")
+    return ids, dist
 
 
 class Functor:
