@@ -30,6 +30,26 @@ import torch
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured streaming)
 
 
+def host_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 64))
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -244,7 +264,7 @@ def main():
             checks["parity_dist_bits_equal"] = bool(np.array_equal(odist.view(np.uint32), got_dist[:sample].view(np.uint32)))
             checks["gpu_reevaluation_overhead"] = round(float(gpu_nd[:sample].mean() / max(ond.mean(), 1) - 1), 4)
             if world == 1:
-                ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                ncores = host_cores()
                 t = time.perf_counter()
                 mids, _ = o.knn_batch_all_cores(g, sp, Qd.cpu().numpy(), k, ef, ncores)
                 mt_s = time.perf_counter() - t
