@@ -91,11 +91,18 @@ typedef struct hnsw_index_desc {
     const hnsw_layer_desc *upper; /* [max_layer]; upper[l-1] describes layer l               */
 } hnsw_index_desc;
 
+/* Which accept rule W uses on layer 0 (they differ only when a neighbour is exactly as far as
+ * max(W)): OHNSW = accept iff |W| < ef or d < max(W).d (Ohnsw.search_k, lib/ohnsw.ml:574);
+ * FUNCTOR = Nearest.insert_distance (lib/hnsw.ml:494-506): accept iff the element is not farther
+ * than max(W), which under the (distance, node id) order means: a node tied with max(W) but with
+ * a smaller id takes its place.  Use FUNCTOR for Hnsw.Ba / Hnsw_algo.Knn.knn. */
+enum { HNSW_SEM_OHNSW = 0, HNSW_SEM_FUNCTOR = 1 };
+
 typedef struct hnsw_search_params {
     int32_t ef;   /* ~num_neighbours_search (lib/hnsw.ml:763); Ohnsw: ef == k (ohnsw.ml:859) */
     int32_t k;    /* ~num_neighbours / ~k                                                    */
     int32_t fill; /* HNSW_FILL_*                                                             */
-    int32_t reserved;
+    int32_t semantics; /* HNSW_SEM_*                                                         */
 } hnsw_search_params;
 
 typedef struct hnsw_index_info {

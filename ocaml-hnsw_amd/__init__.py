@@ -25,6 +25,7 @@ OK, ERR_BAD_ARG, ERR_EMPTY_INDEX, ERR_DEGREE_OVERFLOW = 0, -1, -2, -3
 ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = -4, -5, -6, -7
 METRIC_L2, METRIC_IP = 0, 1
 FILL_OHNSW, FILL_BA = 0, 1
+SEM_OHNSW, SEM_FUNCTOR = 0, 1
 
 # every symbol include/hnsw_mi355x.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -58,7 +59,7 @@ class _IndexDesc(_C.Structure):
 
 
 class _SearchParams(_C.Structure):
-    _fields_ = [("ef", _C.c_int32), ("k", _C.c_int32), ("fill", _C.c_int32), ("reserved", _C.c_int32)]
+    _fields_ = [("ef", _C.c_int32), ("k", _C.c_int32), ("fill", _C.c_int32), ("semantics", _C.c_int32)]
 
 
 class _BuildParams(_C.Structure):
@@ -297,7 +298,7 @@ class Hgraph:
             pass
 
 
-def _search(hgraph, batch, ef, k, fill, counters=False):
+def _search(hgraph, batch, ef, k, fill, counters=False, sem=0):
     Q = _np.ascontiguousarray(batch, dtype=_np.float32)
     if Q.ndim != 2 or (Q.shape[0] and Q.shape[1] != hgraph.d):
         raise InvalidArgument("batch must be [nq][d]")
@@ -306,16 +307,16 @@ def _search(hgraph, batch, ef, k, fill, counters=False):
     dist = _np.empty((nq, k), _np.float32)
     nd = _np.zeros(nq, _np.uint32) if counters else None
     nh = _np.zeros(nq, _np.uint32) if counters else None
-    p = _SearchParams(ef, k, fill, 0)
+    p = _SearchParams(ef, k, fill, sem)
     _check(load().hnsw_search_batch(hgraph.handle, _ptr(Q), nq, hgraph.d, _C.byref(p), _ptr(ids),
                                     _ptr(dist), _ptr(nd), _ptr(nh)))
     return (ids, dist, nd, nh) if counters else (ids, dist)
 
 
 def search_batch_device(hgraph, d_queries, nq, q_stride, ef, k, d_ids, d_dist, d_ndist=0, d_nhops=0,
-                        d_status=0, stream=0, fill=FILL_OHNSW):
+                        d_status=0, stream=0, fill=FILL_OHNSW, sem=SEM_OHNSW):
     """Asynchronous search on device pointers (ints), on HIP stream `stream` (int handle)."""
-    p = _SearchParams(ef, k, fill, 0)
+    p = _SearchParams(ef, k, fill, sem)
     _check(load().hnsw_search_batch_device(hgraph.handle, d_queries, nq, q_stride, _C.byref(p), d_ids,
                                            d_dist, d_ndist or None, d_nhops or None,
                                            d_status or None, stream or None))
@@ -389,10 +390,10 @@ class Ba:
     def knn(hgraph, point, num_neighbours_search, num_neighbours):
         """-> [{node; distance_to_target}] nearest first (lib/hnsw.ml:763-767)."""
         ids, dist = _search(hgraph, _np.asarray(point, _np.float32)[None, :], num_neighbours_search,
-                            num_neighbours, FILL_BA)
+                            num_neighbours, FILL_BA, sem=SEM_FUNCTOR)
         return [(int(i), float(d)) for i, d in zip(ids[0], dist[0]) if i >= hgraph.id_base]
 
     @staticmethod
     def knn_batch(hgraph, batch, num_neighbours_search, num_neighbours):
         """-> distances [nq][k] fp32, +inf where fewer than k were found (lib/hnsw.ml:769-777)."""
-        return _search(hgraph, batch, num_neighbours_search, num_neighbours, FILL_BA)[1]
+        return _search(hgraph, batch, num_neighbours_search, num_neighbours, FILL_BA, sem=SEM_FUNCTOR)[1]

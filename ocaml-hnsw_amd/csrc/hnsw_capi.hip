@@ -107,6 +107,7 @@ int check_params(const hnsw_index *idx, const hnsw_search_params *p) {
                     "(lib/hnsw_algo.ml:257-258); rejected", p->k, p->ef);
     if (p->ef > 1024) return fail(HNSW_ERR_UNSUPPORTED, "ef=%d > 1024 not supported", p->ef);
     if (p->fill != HNSW_FILL_OHNSW && p->fill != HNSW_FILL_BA) return fail(HNSW_ERR_BAD_ARG, "bad fill %d", p->fill);
+    if (p->semantics != HNSW_SEM_OHNSW && p->semantics != HNSW_SEM_FUNCTOR) return fail(HNSW_ERR_BAD_ARG, "bad semantics %d", p->semantics);
     if (idx->iv.entry_point < 0) return fail(HNSW_ERR_EMPTY_INDEX, "knn: empty hgraph");
     return HNSW_OK;
 }
@@ -290,7 +291,7 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
     if (q_stride < idx->iv.d) return fail(HNSW_ERR_BAD_ARG, "q_stride < d");
     HIP_TRY(hipSetDevice(idx->device));
     SearchArgs a{};
-    a.Q = d_queries; a.q_stride = q_stride; a.nq = nq; a.ef = params->ef; a.k = params->k; a.fill = params->fill;
+    a.Q = d_queries; a.q_stride = q_stride; a.nq = nq; a.ef = params->ef; a.k = params->k; a.fill = params->fill; a.sem = params->semantics;
     a.vt_bits = default_vt_bits(idx, params->ef);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_ndist; a.out_nhops = d_nhops; a.out_status = d_status;
     return launch_search_args(idx, a, (hipStream_t)stream);
@@ -332,7 +333,7 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
             const int64_t c = (int64_t)std::min<size_t>((size_t)chunk, flagged.size() - f0);
             hipError_t e = hipMemcpy(dMap.p, flagged.data() + f0, (size_t)c * 4, hipMemcpyHostToDevice);
             SearchArgs a{};
-            a.Q = (const float *)idx->sQ.p; a.q_stride = q_stride; a.nq = c; a.ef = params->ef; a.k = k; a.fill = params->fill;
+            a.Q = (const float *)idx->sQ.p; a.q_stride = q_stride; a.nq = c; a.ef = params->ef; a.k = k; a.fill = params->fill; a.sem = params->semantics;
             a.vt_bits = default_vt_bits(idx, params->ef);
             a.out_ids = (int32_t *)idx->sIds.p; a.out_dist = (float *)idx->sDist.p;
             a.out_ndist = (uint32_t *)idx->sNd.p; a.out_nhops = (uint32_t *)idx->sNh.p; a.out_status = (uint32_t *)idx->sSt.p;

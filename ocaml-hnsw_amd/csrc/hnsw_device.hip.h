@@ -50,6 +50,7 @@ struct SearchArgs {
     int64_t q_stride;
     int64_t nq;
     int32_t ef, k, fill;
+    int32_t sem;             // 0 = Ohnsw accept rule, 1 = functor (Nearest.insert_distance) rule
     int32_t vt_bits;         // log2 of the LDS visited-cache entries
     int32_t *out_ids;
     float *out_dist;
@@ -437,7 +438,12 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
 template <int NCH, int RB, int NSLOT, int METRIC>
 __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (&qv)[NCH], int layer,
                                              WList<NSLOT> &w, int ef, const WaveCtx &cx,
-                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status,
+                                             int sem = 0) {
+    // sem 0: Ohnsw, accept iff d < max(W).d (lib/ohnsw.ml:574).  sem 1: the functor path's
+    // Nearest.insert_distance (lib/hnsw.ml:494-506) under the canonical order: accept iff the
+    // element is not farther than max(W) in (d, id), i.e. its full key is below the top key --
+    // a node tied in distance with max(W) but with a smaller id replaces it.
     const int lane = cx.lane;
     int pref_id = -1, pref_nb = -1;
     for (;;) {
@@ -479,13 +485,15 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         const uint32_t my_key = cx.cand_key[lane];
         const uint32_t my_id = (uint32_t)cx.cand_id[lane];
         // :574 accept iff |W| < ef or d < max(W).d -- tested in row order against the CURRENT W
-        uint64_t pass = __ballot(lane < cnt && my_key < w.wmax);
+        const uint64_t my_key64 = ((uint64_t)my_key << 32) | ((uint64_t)(my_id + 1u) << 1);
+        uint64_t pass = __ballot(lane < cnt && (sem ? (my_key64 < w.wmax64) : (my_key < w.wmax)));
         while (pass) {
             const int i = __builtin_ctzll(pass);
             pass &= pass - 1;
             const uint32_t kd = rdlane(my_key, i);
-            if (!(kd < w.wmax)) continue;
-            wlist_insert(w, kd, rdlane(my_id, i), lane, cx.ovf, status);       // :575-577
+            const uint32_t kid = rdlane(my_id, i);
+            if (sem ? !((((uint64_t)kd << 32) | ((uint64_t)(kid + 1u) << 1)) < w.wmax64) : !(kd < w.wmax)) continue;
+            wlist_insert(w, kd, kid, lane, cx.ovf, status);                    // :575-577
         }
     }
 }
@@ -548,7 +556,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     wlist_insert(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);         // :871, seeds W :555-557
     { uint32_t hw; const uint32_t hc = vt_hash(cx, (uint32_t)cur); (void)visited_mem(cx, hc, hw); visited_add_masked(cx, hc, hw, lane == 0); }
     __syncthreads();
-    search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
+    search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status, a.sem); // :872-874
 
     // results: W[0..k) ascending (lib/ohnsw.ml:886-893)
     const int wbase = NSLOT * 64 - a.ef;

@@ -62,10 +62,10 @@ public:
 struct value_distance { int node; float distance_to_target; }; // lib/hnsw_algo.ml:85
 
 namespace detail {
-inline void search(const Hgraph &g, const Mat &batch, int ef, int k, int fill, std::vector<int32_t> &ids, std::vector<float> &dist) {
+inline void search(const Hgraph &g, const Mat &batch, int ef, int k, int fill, std::vector<int32_t> &ids, std::vector<float> &dist, int sem = HNSW_SEM_OHNSW) {
     ids.assign((size_t)batch.dim2 * k, -1);
     dist.assign((size_t)batch.dim2 * k, 0.f);
-    hnsw_search_params p{ef, k, fill, 0};
+    hnsw_search_params p{ef, k, fill, sem};
     check(hnsw_search_batch(g.handle(), batch.data, batch.dim2, batch.dim1, &p, ids.data(), dist.data(), nullptr, nullptr));
 }
 } // namespace detail
@@ -115,7 +115,7 @@ namespace Ba {
 // Hnsw.Ba.knn hgraph point ~num_neighbours_search ~num_neighbours (lib/hnsw.ml:763-767)
 inline std::vector<value_distance> knn(const Hgraph &g, const float *point, int num_neighbours_search, int num_neighbours) {
     std::vector<int32_t> ids; std::vector<float> dist;
-    detail::search(g, Mat{point, 1, g.dim()}, num_neighbours_search, num_neighbours, HNSW_FILL_BA, ids, dist);
+    detail::search(g, Mat{point, 1, g.dim()}, num_neighbours_search, num_neighbours, HNSW_FILL_BA, ids, dist, HNSW_SEM_FUNCTOR);
     std::vector<value_distance> out;
     for (int i = 0; i < num_neighbours && ids[(size_t)i] >= g.id_base(); ++i) out.push_back({ids[(size_t)i], dist[(size_t)i]});
     return out;
@@ -125,7 +125,7 @@ inline std::vector<value_distance> knn(const Hgraph &g, const float *point, int 
 // (lib/hnsw.ml:769-777): k x nq, +inf filled.
 inline std::vector<float> knn_batch(const Hgraph &g, const Mat &batch, int num_neighbours_search, int num_neighbours) {
     std::vector<int32_t> ids; std::vector<float> dist;
-    detail::search(g, batch, num_neighbours_search, num_neighbours, HNSW_FILL_BA, ids, dist);
+    detail::search(g, batch, num_neighbours_search, num_neighbours, HNSW_FILL_BA, ids, dist, HNSW_SEM_FUNCTOR);
     return dist;
 }
 

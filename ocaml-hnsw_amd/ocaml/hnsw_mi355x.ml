@@ -45,7 +45,7 @@ let search_params : search_params structure typ = structure "hnsw_search_params"
 let p_ef = field search_params "ef" int32_t
 let p_k = field search_params "k" int32_t
 let p_fill = field search_params "fill" int32_t
-let _p_reserved = field search_params "reserved" int32_t
+let p_semantics = field search_params "semantics" int32_t
 let () = seal search_params
 
 type index = unit ptr
@@ -152,13 +152,14 @@ let create ?(device = 0) ?(metric = 0) ~id_base ~num_connections:m (vectors : La
   Gc.finalise (fun t -> ignore (hnsw_index_destroy t.handle)) t;
   t
 
-let search t (batch : Lacaml.S.mat) ~ef ~k ~fill =
+let search ?(semantics = 0) t (batch : Lacaml.S.mat) ~ef ~k ~fill =
   let nq = A2.dim2 batch in
   (* results as the reference lays them out: k x nq Fortran = [nq][k] in memory *)
   let distances = Lacaml.S.Mat.create k nq in
   let ids = A2.create Bigarray.int32 Bigarray.fortran_layout k nq in
   let p = make search_params in
   setf p p_ef (Int32.of_int ef); setf p p_k (Int32.of_int k); setf p p_fill (Int32.of_int fill);
+  setf p p_semantics (Int32.of_int semantics);
   check (hnsw_search_batch t.handle (bigarray_start array2 batch) (Int64.of_int nq)
            (Int64.of_int t.dim) (addr p) (bigarray_start array2 ids)
            (bigarray_start array2 distances) (from_voidp uint32_t null) (from_voidp uint32_t null));
@@ -177,4 +178,4 @@ let ohnsw_knn_batch_bigarray (t : t) ~k (batch : Lacaml.S.mat) =
 (* Hnsw.Ba.knn_batch : t -> Lacaml.S.mat -> num_neighbours_search:int -> num_neighbours:int
    -> Lacaml.S.mat (lib/hnsw.ml:769-777): distances only, +inf filled (:771). *)
 let ba_knn_batch (t : t) (batch : Lacaml.S.mat) ~num_neighbours_search ~num_neighbours =
-  snd (search t batch ~ef:num_neighbours_search ~k:num_neighbours ~fill:1)
+  snd (search ~semantics:1 (* Nearest.insert_distance rule *) t batch ~ef:num_neighbours_search ~k:num_neighbours ~fill:1)

@@ -342,3 +342,27 @@ def test_tie_overflow_beyond_lds_stack(H, oracle):
     H.search_batch_device(hg, Qd.data_ptr(), 3, 1, 128, 10, ids.data_ptr(), dd.data_ptr(), 0, 0, st.data_ptr(), 0)
     torch.cuda.synchronize()
     assert ((st.cpu().numpy() & 1) == 1).all()     # flagged: more than 64 tied evicted entries
+
+
+@pytest.mark.parametrize("levels", [3, 8])
+def test_functor_accept_rule_on_ties(H, oracle, levels):
+    """Hnsw.Ba: Nearest.insert_distance (lib/hnsw.ml:494-506) accepts an element that is not farther
+    than max(W); under the canonical (distance, id) order the GPU's HNSW_SEM_FUNCTOR must equal the
+    oracle's functor path on tie-heavy data -- and differ from the Ohnsw rule somewhere."""
+    rng = np.random.default_rng(levels + 100)
+    X = rng.integers(0, levels, size=(4000, 6)).astype(np.float32)
+    Q = rng.integers(0, levels, size=(200, 6)).astype(np.float32)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 8, 60, seed=2)
+    hg1 = _hgraph(H, X, g, id_base=1, M=8)
+    differs = False
+    for ef, k in ((16, 16), (64, 10)):
+        d = H.Ba.knn_batch(hg1, Q, num_neighbours_search=ef, num_neighbours=k)
+        od, oi = oracle.Functor.knn_batch(g, sp, Q, ef, k, ties=oracle.TIES_CANONICAL, with_ids=True)
+        np.testing.assert_array_equal(d.view(np.uint32), od.view(np.uint32))
+        one = [H.Ba.knn(hg1, Q[j], ef, k) for j in range(10)]
+        for j in range(10):
+            assert [n for n, _ in one[j]] == [int(x) + 1 for x in oi[j] if x >= 0]
+        ids_ohnsw, _ = H.Ohnsw.knn_batch_bigarray(_hgraph(H, X, g, M=8), k, Q, ef=ef)
+        differs = differs or not np.array_equal(ids_ohnsw, oi)
+    assert differs
