@@ -184,8 +184,10 @@ int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_strid
  * selection order (nearest first), -1 padded. */
 int32_t hnsw_select_neighbours_batch(hnsw_index *idx, const float *targets, int64_t nb, int64_t t_stride,
                                      const int32_t *cand, const int32_t *cand_cnt, int32_t cand_stride,
-                                     int32_t num_neighbours, int32_t keep_all_if_few, int32_t *out,
-                                     int32_t *out_cnt);
+                                     int32_t num_neighbours, int32_t keep_all_if_few,
+                                     const int32_t *cand_degree /* NULL, or [nb][cand_stride]: ~do_not_isolate:true,
+                                        candidates whose degree is <= 1 are kept unconditionally, hnsw_algo.ml:591-592 */,
+                                     int32_t *out, int32_t *out_cnt);
 
 /* Export of the flattened graph held by an index (inverse of hnsw_index_create): ids
  * id_base-based, rows compacted, -1 padded. */

@@ -106,7 +106,7 @@ def load():
     L.hnsw_distance_batch.argtypes = [vp, vp, i64, i64, vp, i32, vp]
     L.hnsw_distance_batch_device.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp]
     L.hnsw_build.argtypes = [vp, i64, i32, i64, vp, i32, vp]
-    L.hnsw_select_neighbours_batch.argtypes = [vp, vp, i64, i64, vp, vp, i32, i32, i32, vp, vp]
+    L.hnsw_select_neighbours_batch.argtypes = [vp, vp, i64, i64, vp, vp, i32, i32, i32, vp, vp, vp]
     L.hnsw_select_neighbours_batch.restype = i32
     L.hnsw_index_layer_stats.argtypes = [vp, i32, vp]
     L.hnsw_index_save.argtypes = [vp, _C.c_char_p]
@@ -353,7 +353,7 @@ class Ohnsw:
         return Hgraph._from_handle(h, device, X, 0, metric)
 
     @staticmethod
-    def select_neighbours(hgraph, targets, candidates, num_neighbours, keep_all_if_few=False):
+    def select_neighbours(hgraph, targets, candidates, num_neighbours, keep_all_if_few=False, degrees=None):
         """Batched Ohnsw.select_neighbours distance value queue num_neighbours (lib/ohnsw.ml:647-663):
         candidates = list of id lists (one per target); returns the kept ids per target in selection
         order.  keep_all_if_few=True gives Hnsw_algo.SelectNeighbours' shortcut (hnsw_algo.ml:596-599)."""
@@ -365,10 +365,16 @@ class Ohnsw:
         for i, c in enumerate(candidates):
             cand[i, :len(c)] = c
             cnt[i] = len(c)
+        deg = None
+        if degrees is not None:   # ~do_not_isolate:true (lib/hnsw_algo.ml:591-592)
+            deg = _np.full((nb, stride), 2, _np.int32)
+            for i, dg in enumerate(degrees):
+                deg[i, :len(dg)] = dg
         out = _np.empty((nb, num_neighbours), _np.int32)
         ocnt = _np.empty(nb, _np.int32)
         _check(load().hnsw_select_neighbours_batch(hgraph.handle, _ptr(T), nb, T.shape[1], _ptr(cand), _ptr(cnt),
-                                                   stride, num_neighbours, int(keep_all_if_few), _ptr(out), _ptr(ocnt)))
+                                                   stride, num_neighbours, int(keep_all_if_few), _ptr(deg),
+                                                   _ptr(out), _ptr(ocnt)))
         return [out[i, :ocnt[i]].tolist() for i in range(nb)]
 
     @staticmethod

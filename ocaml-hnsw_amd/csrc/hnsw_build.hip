@@ -282,8 +282,8 @@ done:
 // ---- select_neighbours operator ----------------------------------------------------------------------
 int32_t hnsw_select_neighbours_batch(hnsw_index *idx, const float *targets, int64_t nb, int64_t t_stride,
                                      const int32_t *cand, const int32_t *cand_cnt, int32_t cand_stride,
-                                     int32_t num_neighbours, int32_t keep_all_if_few, int32_t *out,
-                                     int32_t *out_cnt) {
+                                     int32_t num_neighbours, int32_t keep_all_if_few, const int32_t *cand_degree,
+                                     int32_t *out, int32_t *out_cnt) {
     if (!idx) return fail(HNSW_ERR_BAD_ARG, "null index");
     if (nb == 0) return HNSW_OK;
     if (nb < 0 || !targets || !cand || !cand_cnt || !out || !out_cnt) return fail(HNSW_ERR_BAD_ARG, "bad buffers");
@@ -295,6 +295,14 @@ int32_t hnsw_select_neighbours_batch(hnsw_index *idx, const float *targets, int6
     for (int64_t b = 0; b < nb; ++b) {
         if (cand_cnt[b] < 0 || cand_cnt[b] > cand_stride) return fail(HNSW_ERR_BAD_ARG, "cand_cnt out of range");
         if (keep_all_if_few && cand_cnt[b] <= num_neighbours && cand_cnt[b] > 64) return fail(HNSW_ERR_UNSUPPORTED, "keep-all needs <= 64 candidates");
+        if (cand_degree) {
+            int forced = 0;
+            for (int j = 0; j < cand_cnt[b]; ++j) forced += cand_degree[b * cand_stride + j] <= 1;
+            // forced >= M: the reference's loop only checks the bound after an addition, so it can
+            // return more than num_neighbours (hnsw_algo.ml:591-592, 600-606); refuse instead of truncating
+            if (forced >= num_neighbours && cand_cnt[b] > num_neighbours)
+                return fail(HNSW_ERR_DEGREE_OVERFLOW, "do_not_isolate forces %d >= num_neighbours=%d candidates", forced, num_neighbours);
+        }
         for (int j = 0; j < cand_cnt[b]; ++j) {
             const int64_t v = (int64_t)cand[b * cand_stride + j] - base;
             if (v < 0 || v >= idx->iv.n) return fail(HNSW_ERR_BAD_ARG, "Vector.get: candidate id out of range");
@@ -302,7 +310,7 @@ int32_t hnsw_select_neighbours_batch(hnsw_index *idx, const float *targets, int6
         }
     }
     HIP_TRY(hipSetDevice(idx->device));
-    DevBuf dT, dC, dN, dO, dOc;
+    DevBuf dT, dC, dN, dO, dOc, dDg;
     int rc;
     const size_t tbytes = ((size_t)(nb - 1) * t_stride + idx->iv.d) * 4;
     if ((rc = dT.ensure(tbytes)) || (rc = dC.ensure(c0.size() * 4)) || (rc = dN.ensure((size_t)nb * 4)) ||
@@ -310,13 +318,17 @@ int32_t hnsw_select_neighbours_batch(hnsw_index *idx, const float *targets, int6
         dT.release(); dC.release(); dN.release(); dO.release(); dOc.release();
         return rc;
     }
-    auto cleanup = [&]() { dT.release(); dC.release(); dN.release(); dO.release(); dOc.release(); };
+    auto cleanup = [&]() { dT.release(); dC.release(); dN.release(); dO.release(); dOc.release(); dDg.release(); };
+    if (cand_degree) {
+        if ((rc = dDg.ensure((size_t)nb * cand_stride * 4))) { cleanup(); return rc; }
+        if (hipMemcpy(dDg.p, cand_degree, (size_t)nb * cand_stride * 4, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(HNSW_ERR_HIP, "upload failed"); }
+    }
     if (hipMemcpy(dT.p, targets, tbytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dC.p, c0.data(), c0.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(dN.p, cand_cnt, (size_t)nb * 4, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(HNSW_ERR_HIP, "upload failed"); }
     SelectOpArgs sa{};
     sa.targets = (const float *)dT.p; sa.t_stride = t_stride; sa.cand = (const int32_t *)dC.p; sa.cand_cnt = (const int32_t *)dN.p;
     sa.cand_stride = cand_stride; sa.nb = (int32_t)nb; sa.R = num_neighbours; sa.keep_all_if_few = keep_all_if_few;
-    sa.out = (int32_t *)dO.p; sa.out_cnt = (int32_t *)dOc.p;
+    sa.out = (int32_t *)dO.p; sa.out_cnt = (int32_t *)dOc.p; sa.cand_deg = cand_degree ? (const int32_t *)dDg.p : nullptr;
     const size_t lds = ((size_t)4 * cand_stride + 128) * 4;
     const int nch = pick_nch(idx->iv.nchunks);
     dim3 grid((unsigned)nb), block(64);

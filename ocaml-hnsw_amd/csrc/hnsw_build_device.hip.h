@@ -115,11 +115,11 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
 template <int NCH, int METRIC>
 __device__ __forceinline__ int select_heuristic(const IndexView &iv, const int32_t *c_id,
                                                 const uint32_t *c_key, int nc, int R, int32_t *k_id,
-                                                int lane) {
+                                                int lane, int kept0 = 0) {
     const int r = lane >> 4, l16 = lane & 15;
     const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
     const int64_t stride4 = iv.stride >> 2;
-    int kept = 0;
+    int kept = kept0;   // k_id[0..kept0) already holds forced neighbours (do_not_isolate)
     for (int i = 0; i < nc && kept < R; ++i) {
         const int c = c_id[i];
         const uint32_t ckey = c_key[i];
@@ -306,6 +306,8 @@ struct SelectOpArgs {
     const int32_t *cand_cnt;// [nb]
     int32_t cand_stride, nb, R;
     int32_t keep_all_if_few; // functor path: #candidates <= R returns them all (hnsw_algo.ml:596-599)
+    const int32_t *cand_deg; // optional [nb][cand_stride]: do_not_isolate forces candidates whose
+                             // degree is <= 1 into the result (hnsw_algo.ml:591-592)
     int32_t *out;           // [nb][R] selection order, -1 padded (0-based)
     int32_t *out_cnt;       // [nb]
 };
@@ -324,8 +326,21 @@ select_neighbours_kernel(const IndexView iv, const SelectOpArgs sa) {
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     if (b >= sa.nb) return;
-    const int nc = sa.cand_cnt[b];
-    for (int j = lane; j < nc; j += 64) c_id[j] = sa.cand[(int64_t)b * cs + j];
+    const int nall = sa.cand_cnt[b];
+    // do_not_isolate: candidates with degree <= 1 go straight to the result, in candidate order;
+    // the others form the heap.  (Serial over the list: this is a cold, build-time operator.)
+    int nc = 0, forced = 0;
+    if (sa.cand_deg) {
+        for (int j = 0; j < nall; ++j) {
+            const int id = sa.cand[(int64_t)b * cs + j];
+            const bool f = sa.cand_deg[(int64_t)b * cs + j] <= 1;
+            if (lane == 0) { if (f) k_id[forced] = id; else c_id[nc] = id; }
+            forced += f; nc += !f;
+        }
+    } else {
+        nc = nall;
+        for (int j = lane; j < nc; j += 64) c_id[j] = sa.cand[(int64_t)b * cs + j];
+    }
     float4 qv[NCH];
     load_query<NCH>(qv, sa.targets + (int64_t)b * sa.t_stride, iv.d, lane & 15);
     __syncthreads();
@@ -343,11 +358,11 @@ select_neighbours_kernel(const IndexView iv, const SelectOpArgs sa) {
     }
     __syncthreads();
     int kept;
-    if (sa.keep_all_if_few && nc <= sa.R) {
-        kept = nc;
-        if (lane < nc) k_id[lane] = s_id[lane];
+    if (sa.keep_all_if_few && nall <= sa.R) {
+        kept = forced + nc;
+        if (lane < nc) k_id[forced + lane] = s_id[lane];
     } else {
-        kept = select_heuristic<NCH, METRIC>(iv, s_id, s_key, nc, sa.R, k_id, lane);
+        kept = select_heuristic<NCH, METRIC>(iv, s_id, s_key, nc, sa.R, k_id, lane, forced);
     }
     __syncthreads();
     if (lane < sa.R) sa.out[(int64_t)b * sa.R + lane] = lane < kept ? k_id[lane] : -1;

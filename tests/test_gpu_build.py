@@ -149,3 +149,27 @@ def test_save_load_stats_roundtrip(H, oracle, built, tmp_path):
     (tmp_path / "bad.hnsw").write_bytes(b"not an index")
     with pytest.raises(H.InvalidArgument, match="not a flattened hnsw index"):
         H.Hgraph.load(tmp_path / "bad.hnsw")
+
+
+def test_select_neighbours_functor_variant(H, oracle):
+    """Hnsw_algo.SelectNeighbours.select_neighbours (lib/hnsw_algo.ml:572-609): the keep-all shortcut
+    and ~do_not_isolate:true, against the oracle's restatement (canonical order)."""
+    rng = np.random.default_rng(5)
+    X = rng.integers(0, 20, size=(2000, 12)).astype(np.float32)
+    hg = H.Hgraph(X, np.zeros(2000, np.int32), np.full((2000, 2), -1, np.int32), entry_point=0)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    M = 8
+    for trial in range(30):
+        base = int(rng.integers(0, 2000))
+        nc = int(rng.integers(1, 40))
+        cand = rng.choice(2000, size=nc, replace=False).tolist()
+        degs = rng.integers(0, 6, size=nc).tolist()
+        if sum(d <= 1 for d in degs) >= M:
+            continue
+        cd = [float(np.sqrt(np.float64(np.float32(oracle.l2sq_tree16(X[c], X[base]))))) for c in cand]
+        want = oracle.Functor.select_neighbours(sp, cand, cd, M, cand_degree=degs, do_not_isolate=True,
+                                                ties=oracle.TIES_CANONICAL)
+        got = H.Ohnsw.select_neighbours(hg, X[base][None, :], [cand], M, keep_all_if_few=True, degrees=[degs])[0]
+        assert sorted(got) == sorted(want), (trial, got, want)
+        if nc > M:
+            assert got == want            # same selection order when the heuristic runs
