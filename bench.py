@@ -151,32 +151,45 @@ def main():
         del deg0, nbr0, upper
 
     # ---- device buffers; the kernel is launched on torch's current stream ----
-    ids_d = torch.empty((nq, k), dtype=torch.int32, device=dev)
-    dist_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    # Results of one step live in ONE buffer ([ids | distance bits], int32) so the exchange is a
+    # single all-gather; two such buffers alternate so that step i+1's search overlaps step i's
+    # all-gather (the collective runs on RCCL's own stream).
+    nres = nq * k
+    res = [torch.empty(2 * nres, dtype=torch.int32, device=dev) for _ in range(2)]
+    ids_v = [r[:nres].view(nq, k) for r in res]
+    dist_v = [r[nres:].view(torch.float32).view(nq, k) for r in res]
+    ids_d, dist_d = ids_v[0], dist_v[0]
     nd_d = torch.zeros(nq, dtype=torch.int32, device=dev)
     nh_d = torch.zeros(nq, dtype=torch.int32, device=dev)
     if world > 1:
-        all_ids = torch.empty((world * nq, k), dtype=torch.int32, device=cdev)
-        all_dist = torch.empty((world * nq, k), dtype=torch.float32, device=cdev)
-
-    def gather():   # the exchange step: per-shard results -> every rank (RCCL all-gather over xGMI)
-        if args.backend == "nccl":
-            dist.all_gather_into_tensor(all_ids, ids_d)
-            dist.all_gather_into_tensor(all_dist, dist_d)
-        else:
-            dist.all_gather_into_tensor(all_ids, ids_d.cpu())
-            dist.all_gather_into_tensor(all_dist, dist_d.cpu())
+        all_res = [torch.empty(world * 2 * nres, dtype=torch.int32, device=cdev) for _ in range(2)]
     stream = torch.cuda.current_stream()
 
-    def search(ef_, counters=False):
-        H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef_, k, ids_d.data_ptr(), dist_d.data_ptr(),
+    def search(ef_, counters=False, slot=0):
+        H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(),
                               nd_d.data_ptr() if counters else 0, nh_d.data_ptr() if counters else 0,
                               0, stream.cuda_stream)
 
-    def step(ef_):
-        search(ef_)
-        if world > 1:
-            gather()
+    def gather(slot):
+        """the exchange step: per-shard results -> every rank (one RCCL all-gather over xGMI), async"""
+        src = res[slot] if args.backend == "nccl" else res[slot].cpu()
+        return dist.all_gather_into_tensor(all_res[slot], src, async_op=True)
+
+    def run_steps(ef_, steps, ev=None):
+        works = []
+        for i in range(steps):
+            slot = i & 1
+            if world > 1 and i >= 2:
+                works[i - 2].wait()          # the gather that read this slot two steps ago is done
+            if ev:
+                ev[i][0].record(stream)
+            search(ef_, slot=slot)
+            if ev:
+                ev[i][1].record(stream)
+            if world > 1:
+                works.append(gather(slot))
+        for w in works[-2:]:
+            w.wait()
 
     def sync():
         if world > 1:
@@ -184,17 +197,11 @@ def main():
         torch.cuda.synchronize()
 
     def timed(ef_, steps, warmup):
-        for _ in range(warmup):
-            step(ef_)
+        run_steps(ef_, warmup)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         sync()
         t = time.perf_counter()
-        for i in range(steps):
-            ev[i][0].record(stream)
-            search(ef_)
-            ev[i][1].record(stream)
-            if world > 1:
-                gather()
+        run_steps(ef_, steps, ev)
         sync()
         wall = time.perf_counter() - t
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -210,9 +217,11 @@ def main():
 
     # ---- recall@10 on rank 0 (exact ground truth on the GPU) ----
     checks = {}
-    if world > 1:   # the gathered table holds this rank's shard at its place
-        mine = all_ids[rank * nq:(rank + 1) * nq]
-        checks["gathered_shard_matches"] = bool(torch.equal(mine.to(ids_d.device), ids_d))
+    if world > 1:   # the gathered table holds every rank's [ids | distances] block at its place
+        last = (args.steps - 1) & 1
+        blocks = all_res[last].view(world, 2 * nres)
+        checks["gathered_shard_matches"] = bool(torch.equal(blocks[rank].to(dev), res[last]))
+        checks["gathered_all_shards_nonempty"] = bool((blocks[:, :nres] >= 0).any(dim=1).all())
     search(ef, counters=True)
     torch.cuda.synchronize()
     got = ids_d.cpu().numpy()

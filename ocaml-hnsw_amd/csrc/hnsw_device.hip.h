@@ -435,11 +435,10 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
 // While the rows of a hop are in flight, the adjacency row of the then-nearest unexpanded
 // candidate is fetched too: if it is still the nearest after this hop's insertions (the common
 // case once the search has converged) the next hop starts without a dependent round trip.
-template <int NCH, int RB, int NSLOT, int METRIC>
+template <int NCH, int RB, int NSLOT, int METRIC, int sem = 0>
 __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (&qv)[NCH], int layer,
                                              WList<NSLOT> &w, int ef, const WaveCtx &cx,
-                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status,
-                                             int sem = 0) {
+                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
     // sem 0: Ohnsw, accept iff d < max(W).d (lib/ohnsw.ml:574).  sem 1: the functor path's
     // Nearest.insert_distance (lib/hnsw.ml:494-506) under the canonical order: accept iff the
     // element is not farther than max(W) in (d, id), i.e. its full key is below the top key --
@@ -556,7 +555,9 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     wlist_insert(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);         // :871, seeds W :555-557
     { uint32_t hw; const uint32_t hc = vt_hash(cx, (uint32_t)cur); (void)visited_mem(cx, hc, hw); visited_add_masked(cx, hc, hw, lane == 0); }
     __syncthreads();
-    search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status, a.sem); // :872-874
+    // the two accept rules are separate instantiations: no per-hop cost for the choice
+    if (a.sem) search_layer<NCH, RB, NSLOT, METRIC, 1>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status);
+    else search_layer<NCH, RB, NSLOT, METRIC, 0>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
 
     // results: W[0..k) ascending (lib/ohnsw.ml:886-893)
     const int wbase = NSLOT * 64 - a.ef;
