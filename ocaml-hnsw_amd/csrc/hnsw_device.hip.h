@@ -315,6 +315,26 @@ __device__ __forceinline__ void wlist_unexpanded_masks(const WList<NSLOT> &w, ui
 // First set position over the slot masks: returns the node id there (or -1) and clears that bit.
 template <int NSLOT>
 __device__ __forceinline__ int wlist_take_first(const WList<NSLOT> &w, uint64_t (&m)[NSLOT], int &index) {
+    if (NSLOT == 1) {
+        const uint64_t m0 = m[0];
+        const int L = __builtin_ctzll(m0 | (1ull << 63));
+        const int v = (int)(rdlane((uint32_t)w.key[0], L) >> 1) - 1;
+        m[0] = m0 & (m0 - 1);
+        index = m0 ? L : -1;
+        return m0 ? v : -1;
+    }
+    if (NSLOT == 2) {   // straight-line: two readlanes, scalar selects
+        const uint64_t m0 = m[0], m1 = m[1];
+        const bool in0 = m0 != 0ull;
+        const uint64_t mm = in0 ? m0 : m1;
+        const int L = __builtin_ctzll(mm | (1ull << 63));
+        const uint32_t v0 = rdlane((uint32_t)w.key[0], L), v1 = rdlane((uint32_t)w.key[NSLOT - 1], L);
+        const int v = (int)((in0 ? v0 : v1) >> 1) - 1;
+        m[0] = in0 ? (m0 & (m0 - 1)) : m0;
+        m[NSLOT - 1] = in0 ? m1 : (m1 & (m1 - 1));
+        index = mm ? (in0 ? L : 64 + L) : -1;
+        return mm ? v : -1;
+    }
     int c = -1;
     index = -1;
     bool found = false;
@@ -454,7 +474,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         else {
             // no unexpanded member of W: only entries evicted while tied with max(W) can still
             // satisfy "not (c.d > max(W).d)" (:568)
-            if (w.ovf_cnt > 0 && w.ovf_key == w.wmax) { __syncthreads(); c = (int)ovf_get(cx.ovf, --w.ovf_cnt); }
+            if (w.ovf_cnt > 0 && w.ovf_key == w.wmax) { __syncthreads(); c = uniform((int)ovf_get(cx.ovf, --w.ovf_cnt)); }
             else break;
         }
         n_hops++;
