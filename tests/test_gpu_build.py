@@ -173,3 +173,38 @@ def test_select_neighbours_functor_variant(H, oracle):
         assert sorted(got) == sorted(want), (trial, got, want)
         if nc > M:
             assert got == want            # same selection order when the heuristic runs
+
+
+def test_randomized_builds(H, oracle):
+    """Random builder configurations: symmetric links, degree caps, no self links / duplicates, and
+    search parity on the produced graph, every time."""
+    rng = np.random.default_rng(77)
+    for trial in range(24):
+        n = int(rng.integers(1, 2500))
+        d = int(rng.choice([1, 3, 8, 33, 64, 100, 130]))
+        M = int(rng.choice([2, 4, 8, 16, 32]))
+        efc = int(rng.choice([1, 5, 33, 64, 65, 200, 300]))
+        metric = int(rng.integers(0, 2))
+        X = rng.integers(0, int(rng.choice([3, 1000])), size=(n, d)).astype(np.float32)
+        if metric:
+            X = X + rng.uniform(0.01, 0.5, size=X.shape).astype(np.float32)
+            X /= np.linalg.norm(X, axis=1, keepdims=True)
+        hg = H.Ohnsw.build_batch_bigarray(X, M, efc, seed=trial, metric=metric, max_batch=int(rng.choice([0, 64, 1000])),
+                                          batch_div=int(rng.choice([0, 2, 50]))).export()
+        ctx = dict(trial=trial, n=n, d=d, M=M, efc=efc, metric=metric)
+        assert hg.deg0.max(initial=0) <= 2 * M, ctx
+        sets = []
+        for i in range(n):
+            row = hg.nbr0[i, :hg.deg0[i]].tolist()
+            assert len(set(row)) == len(row) and i not in row, ctx
+            sets.append(set(row))
+        assert all(i in sets[j] for i in range(n) for j in sets[i]), ctx
+        for nodes, deg, nbr in hg.upper:
+            assert deg.max(initial=0) <= M, ctx
+        sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
+        g = _oracle_graph(oracle, hg)
+        k = min(4, n)
+        Q = X[rng.integers(0, n, 8)]
+        ids, dist = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=max(k, 30))
+        oi, od = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=k, ef=max(k, 30), ties=oracle.TIES_CANONICAL)
+        assert np.array_equal(ids, oi) and np.array_equal(dist.view(np.uint32), od.view(np.uint32)), ctx

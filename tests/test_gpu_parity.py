@@ -366,3 +366,45 @@ def test_functor_accept_rule_on_ties(H, oracle, levels):
         ids_ohnsw, _ = H.Ohnsw.knn_batch_bigarray(_hgraph(H, X, g, M=8), k, Q, ef=ef)
         differs = differs or not np.array_equal(ids_ohnsw, oi)
     assert differs
+
+
+def test_randomized_small_configurations(H, oracle):
+    """Many small random configurations across every template boundary (ef around 64/128/256, d around
+    4/64/128/256, row widths up to 64, 0..5 upper layers, both metrics, both id bases, duplicate
+    points): ids, distances and hop counts must equal the oracle's bit for bit in all of them."""
+    rng = np.random.default_rng(2024)
+    efs = [1, 2, 7, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300]
+    ds = [1, 2, 3, 4, 5, 16, 31, 63, 64, 65, 100, 127, 128, 129, 200, 256, 257, 300]
+    checked = 0
+    for trial in range(70):
+        n = int(rng.integers(1, 400))
+        d = int(rng.choice(ds))
+        M = int(rng.choice([2, 3, 5, 8, 16, 32]))
+        ef = int(rng.choice(efs))
+        k = int(rng.integers(1, ef + 1))
+        metric = int(rng.integers(0, 2))
+        id_base = int(rng.integers(0, 2))
+        levels = int(rng.choice([2, 4, 50]))         # few distinct coordinate values => exact ties
+        X = rng.integers(0, levels, size=(n, d)).astype(np.float32)
+        if metric == 1:
+            X = X + rng.uniform(0, 0.5, size=X.shape).astype(np.float32)
+            X /= np.maximum(np.linalg.norm(X, axis=1, keepdims=True), 1e-6)
+        sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
+        g = oracle.build_ohnsw(sp, M, int(rng.integers(4, 60)), seed=int(rng.integers(0, 1000)))
+        hg = _hgraph(H, X, g, id_base=id_base, metric=metric, M=M)
+        nq = 6
+        Q = X[rng.integers(0, n, nq)] + (rng.integers(0, 2, size=(nq, d)) if metric == 0 else 0)
+        Q = Q.astype(np.float32)
+        ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True)
+        oi, od, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=k, ef=ef, ties=oracle.TIES_CANONICAL, counters=True)
+        oi = np.where(oi >= 0, oi + id_base, -1)
+        ctx = dict(trial=trial, n=n, d=d, M=M, ef=ef, k=k, metric=metric, id_base=id_base, levels=levels)
+        assert np.array_equal(ids, oi), ctx
+        assert np.array_equal(dist.view(np.uint32), od.view(np.uint32)), ctx
+        assert np.array_equal(nh, onh), ctx
+        fd = H.Ba.knn_batch(hg, Q, num_neighbours_search=ef, num_neighbours=k) if id_base == 1 else None
+        if fd is not None:
+            ofd = oracle.Functor.knn_batch(g, sp, Q, ef, k, ties=oracle.TIES_CANONICAL)
+            assert np.array_equal(fd.view(np.uint32), ofd.view(np.uint32)), ctx
+        checked += 1
+    assert checked == 70
