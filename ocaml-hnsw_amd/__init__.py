@@ -146,6 +146,17 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(_C.c_void_p)
 
 
+def _rows(a):
+    """[n][d] fp32 whose rows are contiguous but may be spaced (a Lacaml sub-matrix keeps its parent's
+    leading dimension): returned as (array, row stride in floats) without copying when possible."""
+    a = _np.asarray(a)
+    if (a.dtype == _np.float32 and a.ndim == 2 and a.shape[0] > 0 and a.strides[1] == 4
+            and a.strides[0] % 4 == 0 and a.strides[0] >= 4 * a.shape[1]):
+        return a, a.strides[0] // 4
+    a = _np.ascontiguousarray(a, dtype=_np.float32)
+    return a, (a.shape[1] if a.ndim == 2 else 0)
+
+
 class Hgraph:
     """The flattened form of Ohnsw.Hgraph.t (lib/ohnsw.ml:307-312) / Hnsw.Ba.Hgraph.t
     (lib/hnsw.ml:342-348) that crosses the C ABI: vectors + per-layer neighbour rows in the
@@ -156,7 +167,7 @@ class Hgraph:
 
     def __init__(self, vectors, deg0, nbr0, upper=(), entry_point=None, id_base=0,
                  max_degree=None, metric=METRIC_L2):
-        self.vectors = _np.ascontiguousarray(vectors, dtype=_np.float32)
+        self.vectors, self.row_stride = _rows(vectors)
         if self.vectors.ndim != 2:
             raise InvalidArgument("vectors must be [n][d]")
         self.n, self.d = self.vectors.shape
@@ -261,7 +272,7 @@ class Hgraph:
             layers[i].nodes, layers[i].deg, layers[i].nbr = nodes.ctypes.data, deg.ctypes.data, nbr.ctypes.data
         d = _IndexDesc()
         d.vectors = self.vectors.ctypes.data
-        d.n, d.d, d.row_stride = self.n, self.d, self.vectors.shape[1]
+        d.n, d.d, d.row_stride = self.n, self.d, self.row_stride
         d.metric, d.id_base = self.metric, self.id_base
         d.max_degree0, d.max_degree, d.max_layer = self.max_degree0, self.max_degree, nl
         d.entry_point = self.id_base - 1 if self.entry_point is None else self.entry_point
@@ -299,7 +310,7 @@ class Hgraph:
 
 
 def _search(hgraph, batch, ef, k, fill, counters=False, sem=0):
-    Q = _np.ascontiguousarray(batch, dtype=_np.float32)
+    Q, qs = _rows(batch)
     if Q.ndim != 2 or (Q.shape[0] and Q.shape[1] != hgraph.d):
         raise InvalidArgument("batch must be [nq][d]")
     nq = Q.shape[0]
@@ -308,7 +319,7 @@ def _search(hgraph, batch, ef, k, fill, counters=False, sem=0):
     nd = _np.zeros(nq, _np.uint32) if counters else None
     nh = _np.zeros(nq, _np.uint32) if counters else None
     p = _SearchParams(ef, k, fill, sem)
-    _check(load().hnsw_search_batch(hgraph.handle, _ptr(Q), nq, hgraph.d, _C.byref(p), _ptr(ids),
+    _check(load().hnsw_search_batch(hgraph.handle, _ptr(Q), nq, max(qs, hgraph.d), _C.byref(p), _ptr(ids),
                                     _ptr(dist), _ptr(nd), _ptr(nh)))
     return (ids, dist, nd, nh) if counters else (ids, dist)
 

@@ -408,3 +408,20 @@ def test_randomized_small_configurations(H, oracle):
             assert np.array_equal(fd.view(np.uint32), ofd.view(np.uint32)), ctx
         checked += 1
     assert checked == 70
+
+
+def test_strided_vectors_and_queries(H, oracle, tiny):
+    """A Lacaml sub-matrix keeps its parent's leading dimension (benchmark/dataset.ml:91-93): rows that
+    are contiguous but spaced must work for the vector table (row_stride) and the batch (q_stride)."""
+    X, sp, g = tiny
+    big = np.full((X.shape[0], X.shape[1] + 7), 9e9, np.float32)
+    big[:, :X.shape[1]] = X
+    Xv = big[:, :X.shape[1]]
+    hg = H.Hgraph(Xv, g.deg0, g.nbr0, g.upper, entry_point=g.entry_point, max_degree=6)
+    assert hg.row_stride == X.shape[1] + 7
+    Qbig = np.full((40, X.shape[1] + 3), -7e9, np.float32)
+    Qbig[:, :X.shape[1]] = X[:40] + 0.01
+    ids, dist = H.Ohnsw.knn_batch_bigarray(hg, 5, Qbig[:, :X.shape[1]], ef=30)
+    oi, od = oracle.Ohnsw.knn_batch_bigarray(g, sp, X[:40] + 0.01, k=5, ef=30, ties=oracle.TIES_CANONICAL)
+    np.testing.assert_array_equal(ids, oi)
+    np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
