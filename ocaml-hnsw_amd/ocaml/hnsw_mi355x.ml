@@ -123,6 +123,45 @@ let flatten_ohnsw (h : _ Ohnsw.Hgraph.t) ~num_connections:m : flat =
   { deg0; nbr0; upper; max_layer;
     entry_point = (match Ohnsw.Hgraph.entry_point h with Some e -> e | None -> -1) }
 
+(* Hnsw.Ba.Hgraph.t (lib/hnsw.ml:342-348): layers = Map int -> MapGraph.t, a MapGraph holding
+   connections = Map int -> NeighbourList.t ({list; length}, lib/hnsw.ml:33-45).  Node ids are the
+   1-based matrix columns (lib/hnsw.ml:325); a node without an entry in a layer's map has no
+   neighbours there (MapGraph.adjacent, lib/hnsw.ml:146-149).  NeighbourList.fold walks the list head
+   first (lib/hnsw.ml:44-45), which is the order Search.search folds over (lib/hnsw_algo.ml:381-383).
+   Pass the result to [create ~id_base:1]. *)
+let flatten_ba (h : Hnsw.Ba.Hgraph.t) ~num_connections:m : flat =
+  let module G = Hnsw.Ba.Hgraph in
+  let n = G.max_node_id h in                       (* = Values.length, lib/hnsw.ml:394 *)
+  let max_layer = G.max_layer h in
+  let fill_row (nl : Hnsw.NeighbourList.t) width (dst : (int32, _, _) A2.t) r =
+    if Hnsw.NeighbourList.length nl > width then invalid_arg "flatten: degree exceeds row width";
+    let j = ref 0 in
+    Hnsw.NeighbourList.fold nl ~init:() ~f:(fun () e -> dst.{r, !j} <- Int32.of_int e; incr j);
+    !j
+  in
+  let deg0 = A1.create Bigarray.int32 Bigarray.c_layout n in
+  let nbr0 = A2.create Bigarray.int32 Bigarray.c_layout n (2 * m) in
+  A1.fill deg0 0l; A2.fill nbr0 (-1l);
+  let g0 = G.layer h 0 in
+  Base.Map.iteri g0.Hnsw.MapGraph.connections ~f:(fun ~key ~data ->
+      deg0.{key - 1} <- Int32.of_int (fill_row data (2 * m) nbr0 (key - 1)));
+  let upper =
+    Array.init max_layer (fun l ->
+        let g = G.layer h (l + 1) in
+        let c = Base.Map.length g.Hnsw.MapGraph.connections in
+        let nodes = A1.create Bigarray.int64 Bigarray.c_layout c in
+        let deg = A1.create Bigarray.int32 Bigarray.c_layout c in
+        let nbr = A2.create Bigarray.int32 Bigarray.c_layout c m in
+        A2.fill nbr (-1l);
+        let s = ref 0 in
+        Base.Map.iteri g.Hnsw.MapGraph.connections ~f:(fun ~key ~data ->
+            nodes.{!s} <- Int64.of_int key;
+            deg.{!s} <- Int32.of_int (fill_row data m nbr !s);
+            incr s);
+        (nodes, deg, nbr))
+  in
+  { deg0; nbr0; upper; max_layer; entry_point = G.entry_point h (* -1 when empty, lib/hnsw.ml:391 *) }
+
 (* ---- device-resident index ------------------------------------------------------------------ *)
 type t = { handle : index; k_base : int; dim : int }
 
