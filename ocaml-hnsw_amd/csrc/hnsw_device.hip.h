@@ -286,6 +286,7 @@ __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint3
 #pragma unroll
     for (int s = NSLOT - 1; s >= 0; --s) {
         if (NSLOT > 2 && s < first) continue;     // slots wholly below the rank stay (uniform)
+        if (NSLOT == 2 && s == 0 && p >= 64) continue;
         uint64_t carry = 0;
         if (s > 0) carry = rdlane64(w.key[s - 1], 63);
         const uint64_t sh = wave_shr1_64(w.key[s], carry);
@@ -298,8 +299,10 @@ __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint3
     }
     w.wmax64 = rdlane64(w.key[NSLOT - 1], 63);
     w.wmax = (uint32_t)(w.wmax64 >> 32);
-    if (w.ovf_cnt > 0 && w.ovf_key != w.wmax) w.ovf_cnt = 0;          // max(W).d dropped: all dead
-    if (!(ev & 1ull) && (uint32_t)(ev >> 32) == w.wmax) {              // evicted, tied, unexpanded
+    if ((uint32_t)(ev >> 32) != w.wmax) {
+        w.ovf_cnt = 0;                            // max(W).d dropped: every stacked entry is dead
+    } else if (!(ev & 1ull)) {                    // rare: evicted while tied with the new max(W), unexpanded
+        if (w.ovf_cnt > 0 && w.ovf_key != w.wmax) w.ovf_cnt = 0;
         if (ovf_push(ov, w.ovf_cnt, key_id(ev), lane)) w.ovf_cnt++;
         else status |= 1u;
         w.ovf_key = w.wmax;
