@@ -498,8 +498,10 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         const int pos = __popcll(m & ((1ull << lane) - 1ull));
         __syncthreads();
         // lanes without a fresh neighbour write to scratch entries past the live ones (no branch)
-        visited_add_masked(cx, h, vword, fresh);                         // Visited.add, :572
-        (fresh ? &cx.cand_id[pos] : reinterpret_cast<int32_t *>(&cx.trash[lane]))[0] = nb;
+        if (fresh) {                                                     // Visited.add, :572
+            if ((h & 0xFFFFu) != 0xFFFFu) cx.vt[h >> 16] = (vword << 16) | (h & 0xFFFFu);
+            cx.cand_id[pos] = nb;
+        }
         __syncthreads();
         eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, cnt, cx.r, cx.l16); // :573
         __syncthreads();
