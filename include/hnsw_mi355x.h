@@ -14,6 +14,11 @@
  *                            Hnsw.Ba.knn_batch / MakeBatch.knn_batch (lib/hnsw.ml:769-777)
  *   hnsw_knn                 Ohnsw.knn (lib/ohnsw.ml:859-875), Hnsw.Ba.knn (lib/hnsw.ml:763-767),
  *                            Hnsw_algo.Knn.knn (lib/hnsw_algo.ml:990-1011)
+ *   hnsw_search_layer_batch  Ohnsw.search_k (lib/ohnsw.ml:543-588), Hnsw_algo.Search.search
+ *                            (lib/hnsw_algo.ml:350-391): one layer, explicit start nodes
+ *   hnsw_search_one_batch    Ohnsw.search_one (lib/ohnsw.ml:492-512), Search.search_one
+ *                            (lib/hnsw_algo.ml:393-437)
+ *   hnsw_multi_*             the batch entry point over several GPUs from one host process
  *   hnsw_distance_batch      Ohnsw.distance_l2 / EuclideanBa.distance (lib/ohnsw.ml:899,
  *                            lib/hnsw.ml:809-815) as timed by bench_dist/bench_dist.ml:22-33
  *
@@ -156,6 +161,50 @@ int32_t hnsw_distance_batch(hnsw_index *idx, const float *queries, int64_t nq, i
 int32_t hnsw_distance_batch_device(hnsw_index *idx, const float *d_queries, int64_t nq,
                                    int64_t q_stride, const int32_t *d_ids, int32_t m,
                                    float *d_out, void *stream);
+
+/* ---- the layer-level functions of the path, as batched operators -------------------------------
+ * hnsw_search_layer_batch = Ohnsw.search_k (lib/ohnsw.ml:543-588; params->semantics = OHNSW) or
+ * Hnsw_algo.Search.search (lib/hnsw_algo.ml:350-391; FUNCTOR) on ONE layer from explicit start
+ * nodes -- what Ohnsw.knn calls on layer 0 (:872-874) and what the builder calls on every layer
+ * (lib/ohnsw.ml:811, lib/hnsw_algo.ml:663).  For target q: W is seeded with start_nodes[q][*]
+ * (id_base-based; entries < id_base are skipped, so lists may be ragged; distinct ids;
+ * 1 <= n_start <= ef, the only shape the reference produces), the layer is searched with W
+ * bounded by params->ef, and W[0..k) comes back ascending in out_ids/out_dist [nq][k] with
+ * out_cnt[q] = min(|W|, k) (optional).  A start node that does not exist on `layer` has no
+ * neighbours there (MapGraph.adjacent of a missing node is empty, lib/hnsw.ml:146-149). */
+int32_t hnsw_search_layer_batch(hnsw_index *idx, int32_t layer, const float *targets, int64_t nq,
+                                int64_t t_stride, const int64_t *start_nodes, int32_t n_start,
+                                const hnsw_search_params *params, int32_t *out_ids, float *out_dist,
+                                int32_t *out_cnt, uint32_t *out_ndist, uint32_t *out_nhops);
+
+/* hnsw_search_one_batch = Ohnsw.search_one (= search_one_simple, lib/ohnsw.ml:492-512); also the
+ * result of Hnsw_algo.Search.search_one (lib/hnsw_algo.ml:393-437), which reaches the same node by
+ * an ef = 1 search.  Greedy walk on `layer` from start[q]: scan all neighbours of the current
+ * node, move to the nearest one if it is strictly closer (:502), until no change.
+ * out_node [nq] id_base-based; out_dist [nq] (optional) its distance (the value_distance the
+ * functor version carries down, lib/hnsw_algo.ml:1005). */
+int32_t hnsw_search_one_batch(hnsw_index *idx, int32_t layer, const float *targets, int64_t nq,
+                              int64_t t_stride, const int64_t *start, int64_t *out_node,
+                              float *out_dist);
+
+/* ---- one host process, several GPUs ------------------------------------------------
+ * The index is REPLICATED on every listed device (a device may be listed more than once); a
+ * query batch is split into n_devices contiguous shards [g*nq/G, (g+1)*nq/G), each searched on
+ * its own device by its own host thread, and the results land in the caller's arrays at the
+ * shard's offset -- bit-identical to hnsw_search_batch on one device (each query is an
+ * independent traversal, lib/ohnsw.ml:883-895).  No collective: the outputs are host buffers.
+ * (One process PER GPU with RCCL all-gather of device-resident results is the other deployment:
+ * ocaml-hnsw_amd/sharding.py and bench.py.) */
+typedef struct hnsw_multi hnsw_multi;
+int32_t hnsw_multi_create(const hnsw_index_desc *desc, const int32_t *devices, int32_t n_devices,
+                          hnsw_multi **out);
+int32_t hnsw_multi_destroy(hnsw_multi *m);
+int32_t hnsw_multi_num_replicas(const hnsw_multi *m, int32_t *n_devices);
+/* replica g (borrowed: destroyed with the hnsw_multi) */
+int32_t hnsw_multi_replica(hnsw_multi *m, int32_t g, hnsw_index **out);
+int32_t hnsw_multi_search_batch(hnsw_multi *m, const float *queries, int64_t nq, int64_t q_stride,
+                                const hnsw_search_params *params, int32_t *out_ids, float *out_dist,
+                                uint32_t *out_ndist, uint32_t *out_nhops);
 
 /* ---- graph construction on the device (next-row scope: the reference's builder stays OCaml;
  * this entry point exists so an index can also be produced where no OCaml build is at hand,

@@ -34,6 +34,8 @@ ABI_SYMBOLS = [
     "hnsw_search_batch_device", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
     "hnsw_index_layer_stats", "hnsw_index_save", "hnsw_index_load",
+    "hnsw_search_layer_batch", "hnsw_search_one_batch",
+    "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
 ]
 
 
@@ -122,6 +124,16 @@ def load():
     for f in ("hnsw_device_count", "hnsw_index_create", "hnsw_index_destroy", "hnsw_index_get_info",
               "hnsw_index_set_option", "hnsw_search_batch", "hnsw_search_batch_device", "hnsw_knn",
               "hnsw_distance_batch", "hnsw_distance_batch_device"):
+        getattr(L, f).restype = i32
+    L.hnsw_search_layer_batch.argtypes = [vp, i32, vp, i64, i64, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.hnsw_search_one_batch.argtypes = [vp, i32, vp, i64, i64, vp, vp, vp]
+    L.hnsw_multi_create.argtypes = [vp, vp, i32, vp]
+    L.hnsw_multi_destroy.argtypes = [vp]
+    L.hnsw_multi_num_replicas.argtypes = [vp, vp]
+    L.hnsw_multi_replica.argtypes = [vp, i32, vp]
+    L.hnsw_multi_search_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp]
+    for f in ("hnsw_search_layer_batch", "hnsw_search_one_batch", "hnsw_multi_create", "hnsw_multi_destroy",
+              "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -257,12 +269,10 @@ class Hgraph:
         self.deg0 = self.nbr0 = self.upper = None
         return self
 
-    def to_device(self, device=0):
-        """Upload to HBM (hnsw_index_create).  Idempotent per device."""
-        if self._index is not None and self._device == device:
-            return self
-        self.release()
-        L = load()
+    def _desc(self):
+        """(hnsw_index_desc, keep-alive) of the host copy of the flattened graph."""
+        if self.vectors is None or self.deg0 is None:
+            raise InvalidArgument("no host copy of the graph: call export() (and keep the vectors) first")
         nl = self.max_layer
         layers = (_LayerDesc * max(nl, 1))()
         for i, (nodes, deg, nbr) in enumerate(self.upper):
@@ -272,14 +282,22 @@ class Hgraph:
             layers[i].nodes, layers[i].deg, layers[i].nbr = nodes.ctypes.data, deg.ctypes.data, nbr.ctypes.data
         d = _IndexDesc()
         d.vectors = self.vectors.ctypes.data
-        d.n, d.d, d.row_stride = self.n, self.d, self.row_stride
+        d.n, d.d, d.row_stride = self.n, self.d, getattr(self, "row_stride", self.vectors.strides[0] // 4)
         d.metric, d.id_base = self.metric, self.id_base
         d.max_degree0, d.max_degree, d.max_layer = self.max_degree0, self.max_degree, nl
         d.entry_point = self.id_base - 1 if self.entry_point is None else self.entry_point
         d.deg0, d.nbr0 = self.deg0.ctypes.data, self.nbr0.ctypes.data
         d.upper = _C.cast(layers, _C.c_void_p)
+        return d, layers
+
+    def to_device(self, device=0):
+        """Upload to HBM (hnsw_index_create).  Idempotent per device."""
+        if self._index is not None and self._device == device:
+            return self
+        self.release()
+        d, _keep = self._desc()
         h = _C.c_void_p()
-        _check(L.hnsw_index_create(_C.byref(d), device, _C.byref(h)))
+        _check(load().hnsw_index_create(_C.byref(d), device, _C.byref(h)))
         self._index, self._device = h, device
         return self
 
@@ -350,6 +368,45 @@ class Ohnsw:
         return _search(hgraph, batch, k if ef is None else ef, k, FILL_OHNSW, counters)
 
     @staticmethod
+    def search_k(hgraph, layer, start_nodes, targets, k, ef=None, sem=SEM_OHNSW, counters=False):
+        """Batched Ohnsw.search_k layer distance value visited start_nodes target k ... (lib/ohnsw.ml:
+        543-588) on one layer: start_nodes = one id list per target (the start MinQueue; distances
+        are recomputed), W bounded by ef (= k, the reference's only shape, unless given).
+        -> list per target of [(node, distance)] nearest first (result_minq order)."""
+        T, ts = _rows(_np.atleast_2d(_np.asarray(targets, _np.float32)))
+        nq = T.shape[0]
+        if len(start_nodes) != nq:
+            raise InvalidArgument("one start list per target")
+        ef = k if ef is None else ef
+        ns = max([len(c) for c in start_nodes] + [1])
+        st = _np.full((nq, ns), hgraph.id_base - 1, _np.int64)
+        for i, c in enumerate(start_nodes):
+            st[i, :len(c)] = c
+        ids = _np.empty((nq, k), _np.int32)
+        dist = _np.empty((nq, k), _np.float32)
+        cnt = _np.empty(nq, _np.int32)
+        nd = _np.zeros(nq, _np.uint32)
+        nh = _np.zeros(nq, _np.uint32)
+        p = _SearchParams(ef, k, FILL_OHNSW, sem)
+        _check(load().hnsw_search_layer_batch(hgraph.handle, layer, _ptr(T), nq, max(ts, hgraph.d), _ptr(st), ns,
+                                              _C.byref(p), _ptr(ids), _ptr(dist), _ptr(cnt), _ptr(nd), _ptr(nh)))
+        res = [[(int(ids[i, j]), float(dist[i, j])) for j in range(cnt[i])] for i in range(nq)]
+        return (res, nd, nh) if counters else res
+
+    @staticmethod
+    def search_one(hgraph, layer, start, targets, with_distance=False):
+        """Batched Ohnsw.search_one layer distance value visited start_node target (lib/ohnsw.ml:492-512):
+        -> node per target (and its distance)."""
+        T, ts = _rows(_np.atleast_2d(_np.asarray(targets, _np.float32)))
+        nq = T.shape[0]
+        st = _np.ascontiguousarray(_np.broadcast_to(_np.asarray(start, _np.int64), (nq,)))
+        node = _np.empty(nq, _np.int64)
+        dist = _np.empty(nq, _np.float32)
+        _check(load().hnsw_search_one_batch(hgraph.handle, layer, _ptr(T), nq, max(ts, hgraph.d), _ptr(st),
+                                            _ptr(node), _ptr(dist)))
+        return (node, dist) if with_distance else node
+
+    @staticmethod
     def build_batch_bigarray(batch, num_connections, num_nodes_search_construction, seed=0,
                              metric=METRIC_L2, device=0, max_batch=0, batch_div=0):
         """Ohnsw.build_batch_bigarray distance batch ~num_connections ~num_nodes_search_construction
@@ -414,3 +471,68 @@ class Ba:
     def knn_batch(hgraph, batch, num_neighbours_search, num_neighbours):
         """-> distances [nq][k] fp32, +inf where fewer than k were found (lib/hnsw.ml:769-777)."""
         return _search(hgraph, batch, num_neighbours_search, num_neighbours, FILL_BA, sem=SEM_FUNCTOR)[1]
+
+    @staticmethod
+    def search(hgraph, layer, start_nodes, targets, size_nearest):
+        """Batched Hnsw_algo.Search.search hgraph layer visited ~start_nodes target ~size_nearest
+        (lib/hnsw_algo.ml:350-391) -> Nearest.t per target as [(node, distance)] nearest first."""
+        return Ohnsw.search_k(hgraph, layer, start_nodes, targets, size_nearest, sem=SEM_FUNCTOR)
+
+    @staticmethod
+    def search_one(hgraph, layer, start, targets):
+        """Batched Hnsw_algo.Search.search_one (lib/hnsw_algo.ml:393-437) -> (node, distance) arrays
+        (the value_distance it returns)."""
+        return Ohnsw.search_one(hgraph, layer, start, targets, with_distance=True)
+
+
+class MultiHgraph:
+    """One host process, several GPUs: the flattened graph replicated on every listed
+    device; knn_batch_bigarray / knn_batch split the batch into contiguous shards, one device each,
+    and return the same arrays as the single-device calls."""
+
+    def __init__(self, hgraph, devices):
+        self.hgraph = hgraph
+        self.devices = [int(x) for x in devices]
+        d, _keep = hgraph._desc()
+        dev = _np.asarray(self.devices, _np.int32)
+        h = _C.c_void_p()
+        _check(load().hnsw_multi_create(_C.byref(d), _ptr(dev), len(dev), _C.byref(h)))
+        self._h = h
+
+    def num_replicas(self):
+        c = _C.c_int32(0)
+        _check(load().hnsw_multi_num_replicas(self._h, _C.byref(c)))
+        return c.value
+
+    def _search(self, batch, ef, k, fill, sem, counters=False):
+        Q, qs = _rows(batch)
+        if Q.ndim != 2 or (Q.shape[0] and Q.shape[1] != self.hgraph.d):
+            raise InvalidArgument("batch must be [nq][d]")
+        nq = Q.shape[0]
+        ids = _np.empty((nq, k), _np.int32)
+        dist = _np.empty((nq, k), _np.float32)
+        nd = _np.zeros(nq, _np.uint32) if counters else None
+        nh = _np.zeros(nq, _np.uint32) if counters else None
+        p = _SearchParams(ef, k, fill, sem)
+        _check(load().hnsw_multi_search_batch(self._h, _ptr(Q), nq, max(qs, self.hgraph.d), _C.byref(p), _ptr(ids),
+                                              _ptr(dist), _ptr(nd), _ptr(nh)))
+        return (ids, dist, nd, nh) if counters else (ids, dist)
+
+    def knn_batch_bigarray(self, k, batch, ef=None, counters=False):
+        """Ohnsw.knn_batch_bigarray over all replicas (lib/ohnsw.ml:877-897)."""
+        return self._search(batch, k if ef is None else ef, k, FILL_OHNSW, SEM_OHNSW, counters)
+
+    def knn_batch(self, batch, num_neighbours_search, num_neighbours):
+        """Hnsw.Ba.knn_batch over all replicas (lib/hnsw.ml:769-777)."""
+        return self._search(batch, num_neighbours_search, num_neighbours, FILL_BA, SEM_FUNCTOR)[1]
+
+    def release(self):
+        if self._h is not None:
+            load().hnsw_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

@@ -112,20 +112,6 @@ int check_params(const hnsw_index *idx, const hnsw_search_params *p) {
     return HNSW_OK;
 }
 
-int default_vt_bits(const hnsw_index *idx, int ef) {
-    int b = idx->vt_bits_override ? idx->vt_bits_override : env_int("HNSW_VT_BITS", 0);
-    if (b <= 0) {
-        // Re-encounters of a node come soon after its first evaluation, so the cache need not
-        // grow with ef: 2^11 tags (4 KiB, 32 waves/CU) cost 3.5 % re-evaluations on C2 and 2.6 %
-        // at ef = 512 (measured), while 2^13 halves the resident waves.  One step more once the
-        // W registers cap the occupancy anyway.
-        b = ef <= 256 ? 11 : 12;
-    }
-    b = std::max(4, std::min(16, b));
-    while (b < 16 && ((int64_t)1 << (b + 15)) < idx->iv.n) ++b;   // tags must identify ids exactly
-    return b;
-}
-
 } // namespace
 
 // ---- ABI ---------------------------------------------------------------------------------------
@@ -292,7 +278,7 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
     HIP_TRY(hipSetDevice(idx->device));
     SearchArgs a{};
     a.Q = d_queries; a.q_stride = q_stride; a.nq = nq; a.ef = params->ef; a.k = params->k; a.fill = params->fill; a.sem = params->semantics;
-    a.vt_bits = default_vt_bits(idx, params->ef);
+    a.vt_bits = search_vt_bits(idx, params->ef);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_ndist; a.out_nhops = d_nhops; a.out_status = d_status;
     return launch_search_args(idx, a, (hipStream_t)stream);
 }
@@ -318,32 +304,19 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
                                   (uint32_t *)idx->sSt.p, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    // Exactness fallback: a query whose stack of tied, evicted, still expandable entries outgrew
-    // its 64 LDS slots is searched again with a global slab that can hold every node.
-    std::vector<uint32_t> st((size_t)nq);
-    HIP_TRY(hipMemcpy(st.data(), idx->sSt.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
-    std::vector<int32_t> flagged;
-    for (int64_t i = 0; i < nq; ++i) if (st[(size_t)i] & 1u) flagged.push_back((int32_t)i);
-    if (!flagged.empty()) {
-        const int64_t n = idx->iv.n;
-        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(256, (512ll << 20) / (n * 4 + 1)));
-        DevBuf dMap, dSlab;
-        if ((rc = dMap.ensure((size_t)chunk * 4)) || (rc = dSlab.ensure((size_t)chunk * n * 4))) { dMap.release(); dSlab.release(); return rc; }
-        for (size_t f0 = 0; f0 < flagged.size(); f0 += (size_t)chunk) {
-            const int64_t c = (int64_t)std::min<size_t>((size_t)chunk, flagged.size() - f0);
-            hipError_t e = hipMemcpy(dMap.p, flagged.data() + f0, (size_t)c * 4, hipMemcpyHostToDevice);
-            SearchArgs a{};
-            a.Q = (const float *)idx->sQ.p; a.q_stride = q_stride; a.nq = c; a.ef = params->ef; a.k = k; a.fill = params->fill; a.sem = params->semantics;
-            a.vt_bits = default_vt_bits(idx, params->ef);
-            a.out_ids = (int32_t *)idx->sIds.p; a.out_dist = (float *)idx->sDist.p;
-            a.out_ndist = (uint32_t *)idx->sNd.p; a.out_nhops = (uint32_t *)idx->sNh.p; a.out_status = (uint32_t *)idx->sSt.p;
-            a.qmap = (const int32_t *)dMap.p; a.ovf_g = (uint32_t *)dSlab.p; a.ovf_gcap = (int32_t)n;
-            if (e == hipSuccess) rc = launch_search_args(idx, a, nullptr);
-            if (e == hipSuccess && !rc) e = hipDeviceSynchronize();
-            if (e != hipSuccess || rc) { dMap.release(); dSlab.release(); return rc ? rc : fail(HNSW_ERR_HIP, "overflow re-run failed: %s", hipGetErrorString(e)); }
-        }
-        dMap.release(); dSlab.release();
-    }
+    // Exactness fallback for queries whose tie-overflow stack outgrew its LDS slots
+    rc = rerun_overflowed(idx, nq, (const uint32_t *)idx->sSt.p,
+                          [&](const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap) {
+                              SearchArgs a{};
+                              a.Q = (const float *)idx->sQ.p; a.q_stride = q_stride; a.nq = c; a.ef = params->ef; a.k = k;
+                              a.fill = params->fill; a.sem = params->semantics;
+                              a.vt_bits = search_vt_bits(idx, params->ef);
+                              a.out_ids = (int32_t *)idx->sIds.p; a.out_dist = (float *)idx->sDist.p;
+                              a.out_ndist = (uint32_t *)idx->sNd.p; a.out_nhops = (uint32_t *)idx->sNh.p; a.out_status = (uint32_t *)idx->sSt.p;
+                              a.qmap = qmap; a.ovf_g = slab; a.ovf_gcap = cap;
+                              return launch_search_args(idx, a, nullptr);
+                          });
+    if (rc) return rc;
     HIP_TRY(hipMemcpy(out_ids, idx->sIds.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_dist, idx->sDist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
     if (out_ndist) HIP_TRY(hipMemcpy(out_ndist, idx->sNd.p, (size_t)nq * 4, hipMemcpyDeviceToHost));

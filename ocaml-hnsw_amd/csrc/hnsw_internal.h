@@ -70,3 +70,48 @@ struct hnsw_index {
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt; // scratch for the host-buffer entry points
     int vt_bits_override = 0;
 };
+
+namespace hnsw_host {
+
+// log2 entries of the per-query LDS visited cache (never changes results)
+inline int search_vt_bits(const hnsw_index *idx, int ef) {
+    int b = idx->vt_bits_override ? idx->vt_bits_override : env_int("HNSW_VT_BITS", 0);
+    if (b <= 0) {
+        // Re-encounters of a node come soon after its first evaluation, so the cache need not
+        // grow with ef: 2^11 tags (4 KiB, 32 waves/CU) cost 3.5 % re-evaluations on C2 and 2.6 %
+        // at ef = 512 (measured), while 2^13 halves the resident waves.  One step more once the
+        // W registers cap the occupancy anyway.
+        b = ef <= 256 ? 11 : 12;
+    }
+    b = std::max(4, std::min(16, b));
+    while (b < 16 && ((int64_t)1 << (b + 15)) < idx->iv.n) ++b;   // tags must identify ids exactly
+    return b;
+}
+
+// Exactness fallback of the host-buffer entry points: a query whose stack of tied, evicted, still
+// expandable entries outgrew its 64 LDS slots (status bit 0) is searched again with a global slab
+// that can hold every node.  launch(qmap, count, slab, slab_cap) starts the kernel for `count`
+// flagged queries; it is synchronised here.
+template <class Launch>
+int rerun_overflowed(hnsw_index *idx, int64_t nq, const uint32_t *d_status, Launch &&launch) {
+    std::vector<uint32_t> st((size_t)nq);
+    HIP_TRY(hipMemcpy(st.data(), d_status, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> flagged;
+    for (int64_t i = 0; i < nq; ++i) if (st[(size_t)i] & 1u) flagged.push_back((int32_t)i);
+    if (flagged.empty()) return HNSW_OK;
+    const int64_t n = idx->iv.n;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(256, (512ll << 20) / (n * 4 + 1)));
+    DevBuf dMap, dSlab;
+    struct Guard { DevBuf &a, &b; ~Guard() { a.release(); b.release(); } } guard{dMap, dSlab};
+    int rc;
+    if ((rc = dMap.ensure((size_t)chunk * 4)) || (rc = dSlab.ensure((size_t)chunk * n * 4))) return rc;
+    for (size_t f0 = 0; f0 < flagged.size(); f0 += (size_t)chunk) {
+        const int64_t c = (int64_t)std::min<size_t>((size_t)chunk, flagged.size() - f0);
+        HIP_TRY(hipMemcpy(dMap.p, flagged.data() + f0, (size_t)c * 4, hipMemcpyHostToDevice));
+        if ((rc = launch((const int32_t *)dMap.p, c, (uint32_t *)dSlab.p, (int32_t)n))) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    return HNSW_OK;
+}
+
+} // namespace hnsw_host

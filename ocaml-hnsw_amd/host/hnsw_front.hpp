@@ -3,6 +3,8 @@
 //
 //   Hnsw::Ohnsw::knn / knn_batch_bigarray / build_batch_bigarray / distance_l2   lib/ohnsw.ml:840-899
 //   Hnsw::Ba::knn / knn_batch                                                    lib/hnsw.ml:763-777
+//   Hnsw::Ohnsw::search_k / search_one, Hnsw::Ba::search                         lib/ohnsw.ml:492-588, lib/hnsw_algo.ml:350-437
+//   Hnsw::MultiHgraph (one process, several GPUs)                                SURVEY 8e
 //
 // Same names, argument meaning and error behaviour: OCaml Invalid_argument -> std::invalid_argument
 // ("knn: empty hgraph", lib/ohnsw.ml:862), Failure -> std::runtime_error.  A `Mat` is a
@@ -101,6 +103,28 @@ inline std::pair<std::vector<std::vector<int>>, std::vector<float>> knn_batch_bi
     return {std::move(out), std::move(dist)};
 }
 
+// Ohnsw.search_k layer distance value visited start_nodes target k (lib/ohnsw.ml:543-588): one target,
+// the start queue as a list of nodes; result_minq popped ascending.  `sem` = HNSW_SEM_FUNCTOR gives
+// Hnsw_algo.Search.search (lib/hnsw_algo.ml:350-391).
+inline std::vector<value_distance> search_k(const Hgraph &g, int layer, const std::vector<int64_t> &start_nodes,
+                                            const float *target, int k, int sem = HNSW_SEM_OHNSW) {
+    std::vector<int32_t> ids((size_t)k); std::vector<float> dist((size_t)k);
+    int32_t cnt = 0;
+    hnsw_search_params p{k, k, HNSW_FILL_OHNSW, sem};
+    check(hnsw_search_layer_batch(g.handle(), layer, target, 1, g.dim(), start_nodes.data(), (int32_t)start_nodes.size(), &p,
+                                  ids.data(), dist.data(), &cnt, nullptr, nullptr));
+    std::vector<value_distance> out;
+    for (int i = 0; i < cnt; ++i) out.push_back({ids[(size_t)i], dist[(size_t)i]});
+    return out;
+}
+
+// Ohnsw.search_one layer distance value visited start_node target (lib/ohnsw.ml:492-512)
+inline value_distance search_one(const Hgraph &g, int layer, int64_t start_node, const float *target) {
+    int64_t node = 0; float d = 0.f;
+    check(hnsw_search_one_batch(g.handle(), layer, target, 1, g.dim(), &start_node, &node, &d));
+    return {(int)node, d};
+}
+
 // Ohnsw.distance_l2 a b (lib/ohnsw.ml:899), batched: out[q][j] = distance(batch[q], value ids[q][j])
 inline std::vector<float> distance_l2(const Hgraph &g, const Mat &batch, const int32_t *ids, int m) {
     std::vector<float> out((size_t)batch.dim2 * m);
@@ -129,5 +153,37 @@ inline std::vector<float> knn_batch(const Hgraph &g, const Mat &batch, int num_n
     return dist;
 }
 
+// Hnsw_algo.Search.search hgraph layer visited ~start_nodes target ~size_nearest (lib/hnsw_algo.ml:350-391)
+inline std::vector<value_distance> search(const Hgraph &g, int layer, const std::vector<int64_t> &start_nodes,
+                                          const float *target, int size_nearest) {
+    return Ohnsw::search_k(g, layer, start_nodes, target, size_nearest, HNSW_SEM_FUNCTOR);
+}
+
 } // namespace Ba
+
+// One host process, several GPUs: the flattened graph replicated on every listed device, batches split
+// into contiguous shards (hnsw_multi_*).
+class MultiHgraph {
+public:
+    MultiHgraph(const hnsw_index_desc &desc, const std::vector<int32_t> &devices) : d_(desc.d) {
+        check(hnsw_multi_create(&desc, devices.data(), (int32_t)devices.size(), &m_));
+    }
+    MultiHgraph(const MultiHgraph &) = delete;
+    MultiHgraph &operator=(const MultiHgraph &) = delete;
+    ~MultiHgraph() { if (m_) hnsw_multi_destroy(m_); }
+    int num_replicas() const { int32_t c = 0; check(hnsw_multi_num_replicas(m_, &c)); return c; }
+
+    // Ohnsw.knn_batch_bigarray over all replicas: ids and distances [nq][k]
+    std::pair<std::vector<int32_t>, std::vector<float>> knn_batch_bigarray(int k, const Mat &batch, int ef = 0) const {
+        std::vector<int32_t> ids((size_t)batch.dim2 * k, -1); std::vector<float> dist((size_t)batch.dim2 * k, 0.f);
+        hnsw_search_params p{ef > 0 ? ef : k, k, HNSW_FILL_OHNSW, HNSW_SEM_OHNSW};
+        check(hnsw_multi_search_batch(m_, batch.data, batch.dim2, batch.dim1, &p, ids.data(), dist.data(), nullptr, nullptr));
+        return {std::move(ids), std::move(dist)};
+    }
+
+private:
+    hnsw_multi *m_ = nullptr;
+    int d_ = 0;
+};
+
 } // namespace Hnsw

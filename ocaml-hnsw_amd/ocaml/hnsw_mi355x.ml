@@ -61,6 +61,25 @@ let hnsw_search_batch =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_search_batch"
     (index @-> ptr float @-> int64_t @-> int64_t @-> ptr search_params @-> ptr int32_t @-> ptr float
      @-> ptr uint32_t @-> ptr uint32_t @-> returning int32_t)
+let hnsw_search_layer_batch =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_search_layer_batch"
+    (index @-> int32_t @-> ptr float @-> int64_t @-> int64_t @-> ptr int64_t @-> int32_t
+     @-> ptr search_params @-> ptr int32_t @-> ptr float @-> ptr int32_t @-> ptr uint32_t
+     @-> ptr uint32_t @-> returning int32_t)
+let hnsw_search_one_batch =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_search_one_batch"
+    (index @-> int32_t @-> ptr float @-> int64_t @-> int64_t @-> ptr int64_t @-> ptr int64_t
+     @-> ptr float @-> returning int32_t)
+type multi = unit ptr
+let multi : multi typ = ptr void
+let hnsw_multi_create =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_multi_create"
+    (ptr index_desc @-> ptr int32_t @-> int32_t @-> ptr multi @-> returning int32_t)
+let hnsw_multi_destroy = foreign ~from:lib "hnsw_multi_destroy" (multi @-> returning int32_t)
+let hnsw_multi_search_batch =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_multi_search_batch"
+    (multi @-> ptr float @-> int64_t @-> int64_t @-> ptr search_params @-> ptr int32_t @-> ptr float
+     @-> ptr uint32_t @-> ptr uint32_t @-> returning int32_t)
 
 (* Error convention -> the reference's exceptions (lib/ohnsw.ml:25,343,862) *)
 let check rc =
@@ -218,3 +237,26 @@ let ohnsw_knn_batch_bigarray (t : t) ~k (batch : Lacaml.S.mat) =
    -> Lacaml.S.mat (lib/hnsw.ml:769-777): distances only, +inf filled (:771). *)
 let ba_knn_batch (t : t) (batch : Lacaml.S.mat) ~num_neighbours_search ~num_neighbours =
   snd (search ~semantics:1 (* Nearest.insert_distance rule *) t batch ~ef:num_neighbours_search ~k:num_neighbours ~fill:1)
+
+(* Ohnsw.search_k (lib/ohnsw.ml:543-588) on one layer for ONE target: the start MinQueue as a node
+   list, the result MinQueue as an ascending (node, distance) list.  ~semantics:1 is
+   Hnsw_algo.Search.search (lib/hnsw_algo.ml:350-391). *)
+let search_k ?(semantics = 0) (t : t) ~layer ~(start_nodes : int list) (target : Lacaml.S.vec) ~k =
+  let ns = List.length start_nodes in
+  let st = CArray.of_list int64_t (List.map Int64.of_int start_nodes) in
+  let ids = CArray.make int32_t k and dist = CArray.make float k in
+  let cnt = allocate int32_t 0l in
+  let p = make search_params in
+  setf p p_ef (Int32.of_int k); setf p p_k (Int32.of_int k); setf p p_fill 0l;
+  setf p p_semantics (Int32.of_int semantics);
+  check (hnsw_search_layer_batch t.handle (Int32.of_int layer) (bigarray_start array1 target) 1L
+           (Int64.of_int t.dim) (CArray.start st) (Int32.of_int ns) (addr p) (CArray.start ids)
+           (CArray.start dist) cnt (from_voidp uint32_t null) (from_voidp uint32_t null));
+  List.init (Int32.to_int !@cnt) (fun i -> Int32.to_int (CArray.get ids i), CArray.get dist i)
+
+(* Ohnsw.search_one (lib/ohnsw.ml:492-512): the node the greedy walk on `layer` ends on *)
+let search_one (t : t) ~layer ~start_node (target : Lacaml.S.vec) =
+  let st = allocate int64_t (Int64.of_int start_node) and node = allocate int64_t 0L in
+  check (hnsw_search_one_batch t.handle (Int32.of_int layer) (bigarray_start array1 target) 1L
+           (Int64.of_int t.dim) st node (from_voidp float null));
+  Int64.to_int !@node

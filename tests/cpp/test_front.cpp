@@ -62,6 +62,33 @@ int main() {
         auto r = Hnsw::Ohnsw::knn(g, 5, X.data() + 8 * 17);
         EXPECT(r.size() == 5 && r[0].node == 17 && r[0].distance_to_target == 0.f);
     }
+    {   // the layer-level functions called as the reference's inline tests call them
+        auto g = ring5(vals, -1, 0);
+        const float t45 = 4.5f, t0 = 0.f;
+        auto r = Hnsw::Ohnsw::search_k(g, 0, {1}, &t45, 2);                    // lib/ohnsw.ml:634-635
+        EXPECT(r.size() == 2 && r[0].node == 4 && r[1].node == 3);
+        auto all = Hnsw::Ba::search(g, 0, {2}, &t0, 42);                       // lib/ohnsw.ml:640-643 through Search.search
+        EXPECT(all.size() == 5 && all[0].node == 0 && all[4].node == 4);
+        const float ones[5] = {1, 2, 3, 4, 5};
+        auto g1 = ring5(ones, -1, 0);
+        const float t31 = 3.1f, far = 42.f;
+        EXPECT(Hnsw::Ohnsw::search_one(g1, 0, 1, &t31).node == 2);             // lib/ohnsw.ml:524-525
+        EXPECT(Hnsw::Ohnsw::search_one(g1, 0, 1, &far).node == 4);             // lib/ohnsw.ml:528-529
+    }
+    {   // one process, several devices: replicas on device 0 give the single-device arrays
+        static int32_t deg0[5]; static int32_t nbr0[10];
+        const int lists[5][2] = {{4, 1}, {0, 2}, {1, 3}, {2, 4}, {3, 0}};
+        for (int i = 0; i < 5; ++i) { deg0[i] = 2; nbr0[2 * i] = lists[i][0]; nbr0[2 * i + 1] = lists[i][1]; }
+        hnsw_index_desc d{};
+        d.vectors = vals; d.n = 5; d.d = 1; d.row_stride = 1; d.metric = HNSW_METRIC_L2; d.id_base = 0;
+        d.max_degree0 = 2; d.max_degree = 1; d.max_layer = 0; d.entry_point = 2; d.deg0 = deg0; d.nbr0 = nbr0;
+        Hnsw::MultiHgraph m(d, {0, 0});
+        EXPECT(m.num_replicas() == 2);
+        const float q[3] = {0.f, 4.5f, 2.2f};
+        auto r = m.knn_batch_bigarray(2, Hnsw::Mat{q, 3, 1}, 5);
+        const int want[6] = {0, 1, 4, 3, 2, 3};
+        for (int i = 0; i < 6; ++i) EXPECT(r.first[(size_t)i] == want[i]);
+    }
     std::printf(fails ? "FAILED (%d)\n" : "front-end ok\n", fails);
     return fails ? 1 : 0;
 }

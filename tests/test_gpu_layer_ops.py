@@ -1,0 +1,214 @@
+"""GPU parity of the layer-level operators (hnsw_search_layer_batch = Ohnsw.search_k /
+Hnsw_algo.Search.search, hnsw_search_one_batch = Ohnsw.search_one / Search.search_one) and of the
+single-process multi-device entry points (hnsw_multi_*), through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+G = load_golden("ohnsw_inline_tests.json")
+
+
+@pytest.fixture(scope="module")
+def H():
+    import ocaml_hnsw_amd as H
+    H.load()
+    assert H.device_count() >= 1, "GPU tests need a HIP device"
+    return H
+
+
+def _hgraph(H, X, g, id_base=0, metric=0, M=None):
+    up = [(nodes + id_base, deg, np.where(nbr >= 0, nbr + id_base, -1)) for nodes, deg, nbr in g.upper]
+    nbr0 = np.where(g.nbr0 >= 0, g.nbr0 + id_base, -1)
+    ep = None if g.entry_point < 0 else g.entry_point + id_base
+    return H.Hgraph(X, g.deg0, nbr0, up, entry_point=ep, id_base=id_base, max_degree=M, metric=metric)
+
+
+def _kat_graph(o, kind, n):
+    return o.Graph.from_lists([[] for _ in range(n)]) if kind == "isolated" else o.Graph.ring(n)
+
+
+# ---- the reference's inline tests, called the way the reference calls them -------------------------
+@pytest.mark.parametrize("case", G["search_k"], ids=lambda c: c["ref"])
+def test_reference_search_k_kats_layer_operator(H, oracle, case):
+    """lib/ohnsw.ml:593-644: search_k layer distance value visited {start} target k.  d = 1 makes
+    the L2 distance |a-b| (the tests' distance, :361)."""
+    vals = np.array(case["values"], np.float32)[:, None]
+    hg = _hgraph(H, vals, _kat_graph(oracle, case["graph"], len(vals)), M=2)
+    got = H.Ohnsw.search_k(hg, 0, [[case["start"]]], [[case["target"]]], case["k"])[0]
+    assert [n for n, _ in got] == [n for n, _ in case["expect"]]
+    for (_, d), (_, e) in zip(got, case["expect"]):
+        assert d == pytest.approx(e, rel=1e-6, abs=1e-6)
+    # the functor path's Search.search gives the same W on these tie-free cases
+    got_f = H.Ba.search(hg, 0, [[case["start"]]], [[case["target"]]], case["k"])[0]
+    assert [n for n, _ in got_f] == [n for n, _ in case["expect"]]
+
+
+@pytest.mark.parametrize("case", G["search_one"], ids=lambda c: c["ref"])
+def test_reference_search_one_kats_layer_operator(H, oracle, case):
+    """lib/ohnsw.ml:514-534: search_one layer distance value visited start target."""
+    vals = np.array(case["values"], np.float32)[:, None]
+    hg = _hgraph(H, vals, _kat_graph(oracle, case["graph"], len(vals)), M=2)
+    got = H.Ohnsw.search_one(hg, 0, case["start"], [[case["target"]]])
+    assert got.tolist() == [case["expect"]]
+
+
+# ---- seeded parity on built graphs, every layer ------------------------------------------------------
+@pytest.fixture(scope="module")
+def built(H, oracle):
+    rng = np.random.default_rng(77)
+    X = rng.integers(0, 12, size=(5000, 24)).astype(np.float32)     # integer grid: exact ties
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 6, 50, seed=9)
+    assert g.max_layer >= 2
+    return X, sp, g
+
+
+def _layer_nodes(g, layer):
+    return np.arange(g.n) if layer == 0 else g.upper[layer - 1][0]
+
+
+@pytest.mark.parametrize("id_base", [0, 1])
+def test_search_k_every_layer_matches_oracle(H, oracle, built, id_base):
+    X, sp, g = built
+    hg = _hgraph(H, X, g, id_base=id_base, M=6)
+    rng = np.random.default_rng(5 + id_base)
+    for layer in range(g.max_layer + 1):
+        nodes = _layer_nodes(g, layer)
+        for ef, k in ((1, 1), (7, 7), (40, 12), (64, 64), (130, 100), (300, 5)):
+            nq = 12
+            T = (X[rng.integers(0, g.n, nq)] + rng.integers(0, 2, size=(nq, X.shape[1]))).astype(np.float32)
+            starts = [rng.choice(nodes, size=int(rng.integers(1, min(ef, len(nodes), 70) + 1)), replace=False).tolist()
+                      for _ in range(nq)]
+            got, nd, nh = H.Ohnsw.search_k(hg, layer, [[s + id_base for s in st] for st in starts], T, k, ef=ef, counters=True)
+            got_f = H.Ba.search(hg, layer, [[s + id_base for s in st] for st in starts], T, ef)
+            for j in range(nq):
+                want, c = oracle.Ohnsw.search_k(g, sp, starts[j], T[j], ef, layer=layer, ties=oracle.TIES_CANONICAL, counters=True)
+                ctx = dict(layer=layer, ef=ef, k=k, j=j, n_start=len(starts[j]))
+                assert [n - id_base for n, _ in got[j]] == [n for n, _ in want[:k]], ctx
+                assert [np.float32(d).view(np.uint32) for _, d in got[j]] == \
+                       [np.float32(d).view(np.uint32) for _, d in want[:k]], ctx
+                assert int(nh[j]) == c.n_hops, ctx
+                assert int(nd[j]) >= len(starts[j]), ctx
+                want_f = oracle.Functor.search(g, sp, starts[j], T[j], ef, layer=layer, ties=oracle.TIES_CANONICAL)
+                assert [n - id_base for n, _ in got_f[j]] == [n for n, _ in want_f], ctx
+
+
+def test_search_one_every_layer_matches_both_reference_versions(H, oracle, built):
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    rng = np.random.default_rng(6)
+    for layer in range(g.max_layer + 1):
+        nodes = _layer_nodes(g, layer)
+        nq = 60
+        T = (X[rng.integers(0, g.n, nq)] + rng.integers(0, 3, size=(nq, X.shape[1]))).astype(np.float32)
+        start = rng.choice(nodes, size=nq)
+        node, dist = H.Ba.search_one(hg, layer, start, T)
+        for j in range(nq):
+            a = oracle.Ohnsw.search_one(g, sp, int(start[j]), T[j], layer=layer)
+            b, bd = oracle.Functor.search_one(g, sp, int(start[j]), T[j], layer=layer, ties=oracle.TIES_CANONICAL)
+            # both reference versions walk to a node at the same distance; on the simple version's
+            # node the GPU agrees exactly
+            assert int(node[j]) == a, (layer, j)
+            assert np.float32(dist[j]).view(np.uint32) == np.float32(bd).view(np.uint32), (layer, j)
+
+
+def test_start_node_missing_from_layer_and_ragged_lists(H, oracle, built):
+    """A start node that is not on the layer has no neighbours there (MapGraph.adjacent,
+    lib/hnsw.ml:146-149): W is just the seeds.  Lists of different lengths are padded with
+    id_base - 1."""
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    top = g.max_layer
+    on_top = set(g.upper[top - 1][0].tolist())
+    absent = [i for i in range(g.n) if i not in on_top][:3]
+    got = H.Ohnsw.search_k(hg, top, [absent, absent[:1]], X[:2], 8)
+    assert sorted(n for n, _ in got[0]) == sorted(absent)
+    assert [n for n, _ in got[1]] == absent[:1]
+    want = oracle.Ohnsw.search_k(g, sp, absent, X[0], 8, layer=top, ties=oracle.TIES_CANONICAL)
+    assert [n for n, _ in got[0]] == [n for n, _ in want]
+
+
+def test_layer_operator_tie_overflow_is_exact(H, oracle):
+    """The crafted graph of test_tie_overflow_beyond_lds_stack, through search_k on layer 0."""
+    n = 229
+    pos = np.zeros(n, np.float32)
+    pos[0] = 20.0
+    pos[1:128] = 10.0
+    pos[128:228] = 9.0 - 0.01 * np.arange(100)
+    pos[228] = 0.1
+    rows = [[] for _ in range(n)]
+    rows[0] = [1] + list(range(2, 65))
+    rows[1] = list(range(65, 128)) + [128]
+    for i in range(99):
+        rows[128 + i] = [129 + i]
+    rows[40] = [228]
+    deg0 = np.array([len(r) for r in rows], np.int32)
+    nbr0 = np.full((n, 64), -1, np.int32)
+    for i, r in enumerate(rows):
+        nbr0[i, :len(r)] = r
+    X = pos[:, None]
+    g = oracle.Graph(n, 0, deg0, nbr0)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    hg = H.Hgraph(X, deg0, nbr0, entry_point=0, max_degree=32)
+    want = oracle.Ohnsw.search_k(g, sp, [0], np.zeros(1, np.float32), 128, ties=oracle.TIES_CANONICAL)
+    got = H.Ohnsw.search_k(hg, 0, [[0]], np.zeros((1, 1), np.float32), 128)[0]
+    assert 228 in [n for n, _ in want]
+    assert [n for n, _ in got] == [n for n, _ in want]
+
+
+def test_layer_operator_errors(H, oracle, built):
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    with pytest.raises(H.InvalidArgument):
+        H.Ohnsw.search_k(hg, g.max_layer + 1, [[0]], X[:1], 4)          # Hgraph.layer out of range
+    with pytest.raises(H.InvalidArgument):
+        H.Ohnsw.search_k(hg, 0, [[0, 1, 2]], X[:1], 2)                  # n_start > ef
+    with pytest.raises(H.InvalidArgument):
+        H.Ohnsw.search_k(hg, 0, [[g.n]], X[:1], 2)                      # Vector.get out of range
+    with pytest.raises(H.InvalidArgument):
+        H.Ohnsw.search_one(hg, 0, -1, X[:1])
+    with pytest.raises(H.InvalidArgument):
+        H.Ohnsw.search_one(hg, -1, 0, X[:1])
+
+
+# ---- one process, several devices ------------------------------------------------------------------
+def test_multi_device_replicas_equal_single_device(H, oracle, built):
+    """hnsw_multi_*: replicas (here three on device 0; the box has one GPU) + contiguous shards give
+    the arrays of the single-device call bit for bit, for batch sizes around the shard count."""
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    hg1 = _hgraph(H, X, g, id_base=1, M=6)
+    multi = H.MultiHgraph(hg, [0, 0, 0])
+    multi1 = H.MultiHgraph(hg1, [0, 0])
+    assert multi.num_replicas() == 3
+    rng = np.random.default_rng(3)
+    for nq in (0, 1, 2, 3, 4, 7, 301):
+        Q = (X[rng.integers(0, g.n, nq)] + rng.integers(0, 2, size=(nq, X.shape[1]))).astype(np.float32).reshape(nq, X.shape[1])
+        a = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=48, counters=True)
+        b = multi.knn_batch_bigarray(10, Q, ef=48, counters=True)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
+        np.testing.assert_array_equal(H.Ba.knn_batch(hg1, Q, 48, 10).view(np.uint32),
+                                      multi1.knn_batch(Q, 48, 10).view(np.uint32))
+    oi, od = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=10, ef=48, ties=oracle.TIES_CANONICAL)
+    np.testing.assert_array_equal(b[0], oi)
+    multi.release()
+    multi1.release()
+
+
+def test_multi_device_errors(H, oracle, built):
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    with pytest.raises(H.InvalidArgument):
+        H.MultiHgraph(hg, [0, H.device_count() + 5])                   # no such device
+    with pytest.raises(H.InvalidArgument):
+        H.MultiHgraph(hg, [])
+    empty = H.Hgraph(np.zeros((0, 4), np.float32), np.zeros(0, np.int32), np.zeros((0, 4), np.int32))
+    m = H.MultiHgraph(empty, [0, 0])
+    with pytest.raises(H.InvalidArgument, match="empty hgraph"):
+        m.knn_batch_bigarray(1, np.zeros((5, 4), np.float32))
+    with pytest.raises(H.InvalidArgument):
+        H.MultiHgraph(hg, [0, 0]).knn_batch_bigarray(10, X[:4], ef=5)   # k > ef, message from a worker thread
