@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=4000, help="queries timed on the CPU restatement")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dataset", default=None,
+                    help="optional real data instead of the synthetic C2 set: an ann-benchmarks .hdf5 file, or a "
+                         "directory holding *base.fvecs and *query.fvecs (TEXMEX); n and d come from the file")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured path) or gloo (functional rehearsal of N > 1 on fewer GPUs)")
     args = ap.parse_args()
 
@@ -128,9 +131,27 @@ def main():
 
     n, d, nq, k, ef = args.n, args.d, args.nq, args.k, args.ef
     t0 = time.time()
-    Xd = make_sift_like(n, d, seed=1, device=dev)
-    # every rank searches its own shard of the global batch of world * nq queries
-    Qall = make_sift_like(world * nq, d, seed=2, device=dev)
+    if args.dataset:
+        # benchmark/dataset.ml:76-102 (HDF5) / Makefile:27-28 (TEXMEX): real vectors when the box has them
+        import glob
+        import ocaml_hnsw_amd.dataset as D
+        if os.path.isdir(args.dataset):
+            base = sorted(glob.glob(os.path.join(args.dataset, "*base.fvecs")))
+            query = sorted(glob.glob(os.path.join(args.dataset, "*query.fvecs")))
+            if not base or not query:
+                raise SystemExit("--dataset %s: no *base.fvecs / *query.fvecs" % args.dataset)
+            Xh, Qh = D.read_fvecs(base[0]), D.read_fvecs(query[0])
+        else:
+            ds = D.Dataset.read(args.dataset)
+            Xh, Qh = ds.train, ds.test
+        n, d = Xh.shape
+        Xd = torch.from_numpy(Xh).to(dev)
+        reps = -(-(world * nq) // Qh.shape[0])
+        Qall = torch.from_numpy(np.tile(Qh, (reps, 1))[:world * nq]).to(dev)   # the file's queries, repeated to fill the batch
+    else:
+        Xd = make_sift_like(n, d, seed=1, device=dev)
+        # every rank searches its own shard of the global batch of world * nq queries
+        Qall = make_sift_like(world * nq, d, seed=2, device=dev)
     Qd = Qall[rank * nq:(rank + 1) * nq].contiguous()
     X = Xd.cpu().numpy()
     log("data: n=%d d=%d nq/gpu=%d (%.1fs)" % (n, d, nq, time.time() - t0))
@@ -309,10 +330,11 @@ def main():
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "C2: SIFT1M-shaped synthetic (n=%d d=%d clustered ints 0..218), M=%d efConstruction=%d "
+            "data": ("file:" + os.path.basename(os.path.normpath(args.dataset))) if args.dataset else "synthetic",
+            "config": {"workload": "C2: %s (n=%d d=%d), M=%d efConstruction=%d "
                                    "(graph built on the GPU), ef=%d k=%d, %d queries per GPU per step, replicated index%s"
-                                   % (n, d, args.M, args.efc, ef, k, nq,
+                                   % ("vectors from " + args.dataset if args.dataset else "SIFT1M-shaped synthetic, clustered ints 0..218",
+                                      n, d, args.M, args.efc, ef, k, nq,
                                       ", RCCL all-gather of results" if world > 1 else ""),
                        "n": n, "d": d, "M": args.M, "ef_construction": args.efc, "ef": ef, "k": k,
                        "queries_per_gpu": nq, "global_batch": world * nq, "parallelism": "replica x%d" % world},

@@ -60,16 +60,46 @@ class Dataset:
 
     @classmethod
     def read(cls, path, limit_train=None, limit_test=None):
-        """ann-benchmarks HDF5 (needs h5py, which this image does not ship: raises ImportError)."""
-        import h5py
-        with h5py.File(path, "r") as f:
-            distance = f.attrs.get("distance", "euclidean")
-            if isinstance(distance, bytes):
-                distance = distance.decode()
-            train = np.asarray(f["train"][:limit_train], np.float32)
-            test = np.asarray(f["test"][:limit_test], np.float32)
-            dist = np.asarray(f["distances"][:limit_test], np.float32)
+        """ann-benchmarks HDF5 (benchmark/dataset.ml:76-102: datasets `train`, `test`, `distances`,
+        attribute `distance`; ?limit_train / ?limit_test keep the first columns, :88-93).  Uses h5py
+        when importable, else libhdf5 through ctypes (h5lite)."""
+        try:
+            import h5py
+        except ImportError:
+            h5py = None
+        if h5py is not None:
+            with h5py.File(path, "r") as f:
+                distance = f.attrs.get("distance", "euclidean")
+                if isinstance(distance, bytes):
+                    distance = distance.decode()
+                train = np.asarray(f["train"][:limit_train], np.float32)
+                test = np.asarray(f["test"][:limit_test], np.float32)
+                dist = np.asarray(f["distances"][:limit_test], np.float32)
+            return cls(train, test, dist, distance)
+        try:
+            from . import h5lite
+        except ImportError:       # imported as a plain module (tools/)
+            import h5lite
+        with h5lite.File(path) as f:
+            distance = f.attr("distance", "euclidean")
+            train = f.read("train", np.float32, limit_train)
+            test = f.read("test", np.float32, limit_test)
+            dist = f.read("distances", np.float32, limit_test)
         return cls(train, test, dist, distance)
+
+    def write(self, path, neighbors=None):
+        """The same layout back out (e.g. a synthetic set for another tool)."""
+        try:
+            from . import h5lite
+        except ImportError:
+            import h5lite
+        with h5lite.File(path, "w") as f:
+            f.write("train", self.train)
+            f.write("test", self.test)
+            f.write("distances", self.test_distances)
+            if neighbors is not None:
+                f.write("neighbors", np.ascontiguousarray(neighbors, np.int32))
+            f.set_attr("distance", self.distance)
 
     @classmethod
     def read_texmex(cls, base, query, groundtruth=None, k=10, limit_train=None, limit_test=None):

@@ -29,10 +29,55 @@ def test_recall_matches_reference_definition(oracle):
         D.Recall.compute(exact, exact[:, :3])
 
 
-def test_hdf5_reader_needs_h5py(tmp_path):
-    import ocaml_hnsw_amd.dataset as D
+def _h5():
+    import ocaml_hnsw_amd.h5lite as h5
     try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            D.Dataset.read(tmp_path / "missing.hdf5")
+        h5.lib()
+    except h5.H5Error as e:
+        pytest.skip(str(e))
+    return h5
+
+
+def test_hdf5_ann_benchmarks_layout_roundtrip(tmp_path):
+    """benchmark/dataset.ml:76-102: train / test / distances + attribute `distance`; the limits keep
+    the first vectors (:88-93).  Read back through libhdf5 (ctypes) -- the image has no h5py."""
+    _h5()
+    import ocaml_hnsw_amd.dataset as D
+    ds = D.Dataset.random(dim=6, num_train=50, num_test=9, k=4, seed=3)
+    ds.distance = "angular"
+    nb = np.arange(36, dtype=np.int32).reshape(9, 4)
+    ds.write(tmp_path / "toy.hdf5", neighbors=nb)
+    back = D.Dataset.read(tmp_path / "toy.hdf5")
+    np.testing.assert_array_equal(back.train, ds.train)
+    np.testing.assert_array_equal(back.test, ds.test)
+    np.testing.assert_array_equal(back.test_distances, ds.test_distances)
+    assert back.distance == "angular"
+    lim = D.Dataset.read(tmp_path / "toy.hdf5", limit_train=7, limit_test=2)
+    np.testing.assert_array_equal(lim.train, ds.train[:7])
+    np.testing.assert_array_equal(lim.test, ds.test[:2])
+    np.testing.assert_array_equal(lim.test_distances, ds.test_distances[:2])
+
+
+def test_hdf5_low_level(tmp_path):
+    h5 = _h5()
+    p = tmp_path / "x.h5"
+    with h5.File(p, "w") as f:
+        f.write("d64", np.linspace(0, 1, 12).reshape(3, 4))          # float64 on disk, converted on read
+        f.write("ids", np.arange(10, dtype=np.int64))
+        f.write("empty", np.zeros((0, 5), np.float32))
+        f.set_attr("distance", "euclidean", variable=False)           # fixed-length string flavour
+    with h5.File(p) as f:
+        assert "d64" in f and "nope" not in f
+        assert f.shape("d64") == (3, 4)
+        np.testing.assert_allclose(f.read("d64", np.float32), np.linspace(0, 1, 12).reshape(3, 4).astype(np.float32))
+        np.testing.assert_array_equal(f.read("ids", np.int32, limit=4), np.arange(4))
+        assert f.read("empty").shape == (0, 5)
+        assert f.attr("distance") == "euclidean"
+        assert f.attr("missing", "dflt") == "dflt"
+        with pytest.raises(h5.H5Error):
+            f.read("nope")
+    with pytest.raises(FileNotFoundError):
+        h5.File(tmp_path / "missing.hdf5")
+    (tmp_path / "junk.hdf5").write_bytes(b"not an hdf5 file")
+    with pytest.raises(h5.H5Error):
+        h5.File(tmp_path / "junk.hdf5")
