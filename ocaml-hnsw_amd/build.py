@@ -32,16 +32,19 @@ def up_to_date():
 
 
 def build(force=False, verbose=False, resource_log=None):
-    if not force and up_to_date():
+    if not force and up_to_date() and not os.environ.get("HNSW_LIB_OUT"):
         return LIB
     base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include")]
     if os.environ.get("HNSW_RB_NCH2"):
         base += ["-DHNSW_RB_NCH2=" + os.environ["HNSW_RB_NCH2"]]
     if os.environ.get("HNSW_SEARCH_MIN_WAVES"):
         base += ["-DHNSW_SEARCH_MIN_WAVES=" + os.environ["HNSW_SEARCH_MIN_WAVES"]]
+    extra = os.environ.get("HNSW_EXTRA_CFLAGS", "").split()   # experiments: variant builds
+    base += extra
+    lib_out = os.environ.get("HNSW_LIB_OUT") or LIB
     if resource_log:
         base += ["-Rpass-analysis=kernel-resource-usage"]
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build") if lib_out == LIB else lib_out + ".obj"
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for s_ in SOURCES:  # one hipcc per translation unit, in parallel
@@ -59,7 +62,7 @@ def build(force=False, verbose=False, resource_log=None):
         if rc != 0:
             raise subprocess.CalledProcessError(rc, cmd)
         objs.append(obj)
-    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_out]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
@@ -67,7 +70,7 @@ def build(force=False, verbose=False, resource_log=None):
         with open(resource_log, "w") as f:
             for s_ in SOURCES:
                 f.write(open(resource_log + "." + s_).read())
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":

@@ -557,6 +557,9 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     const int64_t q = a.qmap ? a.qmap[blockIdx.x] : (int64_t)blockIdx.x;
     WaveCtx cx = make_ctx(lds, a.vt_bits, lane);
     if (a.ovf_g) { cx.ovf.g = a.ovf_g + (int64_t)blockIdx.x * a.ovf_gcap; cx.ovf.gcap = a.ovf_gcap; }
+#ifdef HNSW_TIMING
+    const uint64_t t_start__ = wall_clock64();
+#endif
 
     float4 qv[NCH];
     load_query<NCH>(qv, a.Q + q * a.q_stride, iv.d, cx.l16);
@@ -599,8 +602,13 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
         }
     }
     if (lane == 0) {
+#ifdef HNSW_TIMING   // measurement build (tools/sweep.py TIMELINE=1): each query's start / end in 10 ns ticks
+        if (a.out_ndist) a.out_ndist[q] = (uint32_t)t_start__;
+        if (a.out_nhops) a.out_nhops[q] = (uint32_t)wall_clock64();
+#else
         if (a.out_ndist) a.out_ndist[q] = n_dist;
         if (a.out_nhops) a.out_nhops[q] = n_hops;
+#endif
         if (a.out_status) a.out_status[q] = status;
     }
 }

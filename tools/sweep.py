@@ -119,3 +119,58 @@ if os.environ.get("ORDER_EXPERIMENT"):
             H.search_batch_device(hg, Qv.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(), 0, 0, 0, stream.cuda_stream)
             e.record(stream); torch.cuda.synchronize(); ts.append(a.elapsed_time(e))
         print("%-28s %.3f ms  %.0f q/s" % (name, np.median(ts), nq / np.median(ts) * 1e3), flush=True)
+
+if os.environ.get("OVERLAP_EXPERIMENT"):
+    # Is the 10 k batch paying pipeline fill/drain (time = latency + nq/throughput) or is the larger
+    # batch simply hitting in cache?  Back-to-back 10 k batches on ONE stream vs alternated over
+    # TWO streams (the tail of batch i overlaps the head of batch i+1; different queries each).
+    nq, ef, k, nb = 10000, 128, 10, 16
+    Qs = [make(nq, 100 + i) for i in range(nb)]
+    outs = [(torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev)) for _ in range(nb)]
+    for nstreams in (1, 2, 3, 4):
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+        ts = []
+        for rep in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(nb):
+                s_ = streams[i % nstreams]
+                H.search_batch_device(hg, Qs[i].data_ptr(), nq, d, ef, k, outs[i][0].data_ptr(), outs[i][1].data_ptr(), 0, 0, 0, s_.cuda_stream)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / nb)
+        ms = float(np.median(ts)) * 1e3
+        print("%d stream(s): %.3f ms per 10k batch  %.0f q/s" % (nstreams, ms, nq / ms * 1e3), flush=True)
+
+if os.environ.get("HOP_STATS"):
+    nq, ef, k = 10000, 128, 10
+    Qd = make(nq, 2)
+    ids = torch.empty((nq, k), dtype=torch.int32, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    nd = torch.zeros(nq, dtype=torch.int32, device=dev); nh = torch.zeros(nq, dtype=torch.int32, device=dev)
+    H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(), nd.data_ptr(), nh.data_ptr(), 0, stream.cuda_stream)
+    torch.cuda.synchronize()
+    for name, v in (("hops", nh.cpu().numpy()), ("evaluations", nd.cpu().numpy())):
+        print("%s per query: min %d p10 %d p50 %d p90 %d p99 %d max %d mean %.1f" %
+              (name, v.min(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max(), v.mean()), flush=True)
+
+if os.environ.get("TIMELINE"):
+    # needs a library built with -DHNSW_TIMING: out_ndist / out_nhops carry each query's start / end (10 ns ticks)
+    for nq in (7168, 10000, 20000):
+        ef, k = 128, 10
+        Qd = make(nq, 2)
+        ids = torch.empty((nq, k), dtype=torch.int32, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        t0 = torch.zeros(nq, dtype=torch.int32, device=dev); t1 = torch.zeros(nq, dtype=torch.int32, device=dev)
+        for _ in range(3):
+            H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(), t0.data_ptr(), t1.data_ptr(), 0, stream.cuda_stream)
+            torch.cuda.synchronize()
+        a = t0.cpu().numpy().astype(np.uint32).astype(np.int64); b = t1.cpu().numpy().astype(np.uint32).astype(np.int64)
+        base = a.min(); a = (a - base) / 100.0; b = (b - base) / 100.0      # microseconds
+        dur = b - a
+        print("nq=%d: launch span %.0f us; start p50 %.0f p90 %.0f max %.0f; duration p10 %.0f p50 %.0f p90 %.0f max %.0f us" %
+              (nq, b.max(), np.percentile(a, 50), np.percentile(a, 90), a.max(), np.percentile(dur, 10), np.percentile(dur, 50), np.percentile(dur, 90), dur.max()), flush=True)
+        first = a < 5.0
+        print("   first wave: %d queries, duration p50 %.0f us, end p10 %.0f p50 %.0f p90 %.0f; later starters: %d, duration p50 %.0f us" %
+              (first.sum(), np.median(dur[first]), np.percentile(b[first], 10), np.percentile(b[first], 50), np.percentile(b[first], 90),
+               (~first).sum(), np.median(dur[~first]) if (~first).any() else 0), flush=True)
+        edges = np.arange(0, b.max() + 50, 50)
+        act = [int(((a <= t) & (b > t)).sum()) for t in edges]
+        print("   queries in flight every 50 us:", act, flush=True)
