@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:   # PyTorch-ROCm wheels bundle their own HIP runtime: load it before libhnsw_mi355x.so pulls in the
+    import torch  # noqa: F401  system one, so that a process ends up with ONE runtime whatever the test order
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
