@@ -68,6 +68,7 @@ struct hnsw_index {
     void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr;
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt; // scratch for the host-buffer entry points
+    hipStream_t hs[4] = {nullptr, nullptr, nullptr, nullptr}; // streams of the chunked host-buffer search (lazy)
     int vt_bits_override = 0;
 };
 
@@ -93,11 +94,12 @@ inline int search_vt_bits(const hnsw_index *idx, int ef) {
 // that can hold every node.  launch(qmap, count, slab, slab_cap) starts the kernel for `count`
 // flagged queries; it is synchronised here.
 template <class Launch>
-int rerun_overflowed(hnsw_index *idx, int64_t nq, const uint32_t *d_status, Launch &&launch) {
+int rerun_overflowed(hnsw_index *idx, int64_t nq, const uint32_t *d_status, Launch &&launch, int64_t *n_rerun = nullptr) {
     std::vector<uint32_t> st((size_t)nq);
     HIP_TRY(hipMemcpy(st.data(), d_status, (size_t)nq * 4, hipMemcpyDeviceToHost));
     std::vector<int32_t> flagged;
     for (int64_t i = 0; i < nq; ++i) if (st[(size_t)i] & 1u) flagged.push_back((int32_t)i);
+    if (n_rerun) *n_rerun = (int64_t)flagged.size();
     if (flagged.empty()) return HNSW_OK;
     const int64_t n = idx->iv.n;
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(256, (512ll << 20) / (n * 4 + 1)));
