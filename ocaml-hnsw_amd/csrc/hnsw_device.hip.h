@@ -468,6 +468,12 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     // a node tied in distance with max(W) but with a smaller id replaces it.
     const int lane = cx.lane;
     int pref_id = -1, pref_nb = -1;
+#ifdef HNSW_PHASE_TIMING   // measurement build: shader-clock cycles per phase, summed over the query's hops
+    uint64_t tp0 = 0, tp1 = 0, tp2 = 0, tmark = clock64();
+#define HNSW_PHASE(acc) do { const uint64_t tn__ = clock64(); acc += tn__ - tmark; tmark = tn__; } while (0)
+#else
+#define HNSW_PHASE(acc) do { } while (0)
+#endif
     for (;;) {
         uint64_t um[NSLOT];
         wlist_unexpanded_masks(w, um);
@@ -494,7 +500,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         int pidx;
         pref_id = wlist_take_first(w, um, pidx);                         // the next nearest unexpanded
         if (pref_id >= 0) pref_nb = adj_entry(iv, layer, pref_id, lane);
-        if (cnt == 0) continue;
+        if (cnt == 0) { HNSW_PHASE(tp0); continue; }
         const int pos = __popcll(m & ((1ull << lane) - 1ull));
         __syncthreads();
         // lanes without a fresh neighbour write to scratch entries past the live ones (no branch)
@@ -503,10 +509,15 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             cx.cand_id[pos] = nb;
         }
         __syncthreads();
+        HNSW_PHASE(tp0);                                                 // pop + adjacency + filter + compaction
         eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, cnt, cx.r, cx.l16); // :573
         __syncthreads();
         n_dist += cnt;
         const uint32_t my_key = cx.cand_key[lane];
+#ifdef HNSW_PHASE_TIMING
+        asm volatile("" :: "v"(my_key));
+#endif
+        HNSW_PHASE(tp1);                                                 // row loads + arithmetic + keys back from LDS
         const uint32_t my_id = (uint32_t)cx.cand_id[lane];
         // :574 accept iff |W| < ef or d < max(W).d -- tested in row order against the CURRENT W
         const uint64_t my_key64 = ((uint64_t)my_key << 32) | ((uint64_t)(my_id + 1u) << 1);
@@ -519,7 +530,12 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             if (sem ? !((((uint64_t)kd << 32) | ((uint64_t)(kid + 1u) << 1)) < w.wmax64) : !(kd < w.wmax)) continue;
             wlist_insert(w, kd, kid, lane, cx.ovf, status);                    // :575-577
         }
+        HNSW_PHASE(tp2);                                                 // accept tests + insertions
     }
+#ifdef HNSW_PHASE_TIMING
+    n_dist = (uint32_t)tp0; n_hops = (uint32_t)tp1; status = (uint32_t)tp2 << 8;   // reported through the counters
+#endif
+#undef HNSW_PHASE
 }
 
 template <int NCH>

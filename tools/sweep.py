@@ -174,3 +174,19 @@ if os.environ.get("TIMELINE"):
         edges = np.arange(0, b.max() + 50, 50)
         act = [int(((a <= t) & (b > t)).sum()) for t in edges]
         print("   queries in flight every 50 us:", act, flush=True)
+
+if os.environ.get("PHASES"):
+    # needs a library built with -DHNSW_PHASE_TIMING: the counters carry shader-clock cycles per phase
+    for nq in (64, 10000):
+        ef, k = 128, 10
+        Qd = make(nq, 2)
+        ids = torch.empty((nq, k), dtype=torch.int32, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        a = torch.zeros(nq, dtype=torch.int32, device=dev); b = torch.zeros(nq, dtype=torch.int32, device=dev); c = torch.zeros(nq, dtype=torch.int32, device=dev)
+        for _ in range(3):
+            H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+        p0 = a.cpu().numpy().astype(np.uint32).astype(np.float64); p1 = b.cpu().numpy().astype(np.uint32).astype(np.float64)
+        p2 = (c.cpu().numpy().astype(np.uint32) >> 8).astype(np.float64)
+        tot = p0 + p1 + p2
+        print("nq=%d: cycles per query (median): pop/filter/compact %.0f (%.0f%%)  rows+arith %.0f (%.0f%%)  accept/insert %.0f (%.0f%%)  total %.0f" %
+              (nq, np.median(p0), 100 * p0.sum() / tot.sum(), np.median(p1), 100 * p1.sum() / tot.sum(), np.median(p2), 100 * p2.sum() / tot.sum(), np.median(tot)), flush=True)
