@@ -86,7 +86,28 @@ def recall_ids(got, gt):
     return float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got.tolist(), gt.tolist())]))
 
 
+def _stdout_to_stderr():
+    """Everything libraries write to fd 1 while the bench runs (RCCL prints a version banner there at
+    communicator creation) goes to stderr: stdout carries the ONE JSON line only."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return saved
+
+
+def _restore_stdout(saved):
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)     # C stdio buffers of native libraries, while fd 1 still is stderr
+    except Exception:
+        pass
+    os.dup2(saved, 1)
+    os.close(saved)
+
+
 def main():
+    saved_stdout = _stdout_to_stderr()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -121,9 +142,13 @@ def main():
     dev = torch.device("cuda", gpu)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where collectives run
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL init, broadcast, async all-gather, barrier) with
+    # world_size 1 -- the only way to rehearse the nccl backend on a one-GPU box
+    multi = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -162,9 +187,9 @@ def main():
         hg = H.Ohnsw.build_batch_bigarray(X, args.M, args.efc, seed=1, device=gpu)
         build_s = time.time() - t0
         log("graph built on the GPU in %.1fs (max_layer %d)" % (build_s, hg.max_layer))
-        if world > 1 or not args.no_cpu:
+        if multi or not args.no_cpu:
             hg.export()
-    if world > 1:
+    if multi:
         import ocaml_hnsw_amd.sharding as sharding
         deg0, nbr0, upper, entry = sharding.replicate_graph(dist, cdev, hg if rank == 0 else None, args.M)
         if rank != 0:
@@ -182,7 +207,7 @@ def main():
     ids_d, dist_d = ids_v[0], dist_v[0]
     nd_d = torch.zeros(nq, dtype=torch.int32, device=dev)
     nh_d = torch.zeros(nq, dtype=torch.int32, device=dev)
-    if world > 1:
+    if multi:
         all_res = [torch.empty(world * 2 * nres, dtype=torch.int32, device=cdev) for _ in range(2)]
     stream = torch.cuda.current_stream()
 
@@ -200,20 +225,20 @@ def main():
         works = []
         for i in range(steps):
             slot = i & 1
-            if world > 1 and i >= 2:
+            if multi and i >= 2:
                 works[i - 2].wait()          # the gather that read this slot two steps ago is done
             if ev:
                 ev[i][0].record(stream)
             search(ef_, slot=slot)
             if ev:
                 ev[i][1].record(stream)
-            if world > 1:
+            if multi:
                 works.append(gather(slot))
         for w in works[-2:]:
             w.wait()
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -226,7 +251,7 @@ def main():
         sync()
         wall = time.perf_counter() - t
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        if world > 1:
+        if multi:
             w = torch.tensor([wall], dtype=torch.float64, device=cdev)
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             wall = float(w[0])
@@ -261,7 +286,7 @@ def main():
 
     # ---- recall@10 on rank 0 (exact ground truth on the GPU) ----
     checks = {}
-    if world > 1:   # the gathered table holds every rank's [ids | distances] block at its place
+    if multi:   # the gathered table holds every rank's [ids | distances] block at its place
         last = (args.steps - 1) & 1
         blocks = all_res[last].view(world, 2 * nres)
         checks["gathered_shard_matches"] = bool(torch.equal(blocks[rank].to(dev), res[last]))
@@ -363,10 +388,15 @@ def main():
                        "queries_per_gpu": nq, "global_batch": world * nq, "parallelism": "replica x%d" % world},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "pipelined": pipelined, "checks": checks,
         }
+        _restore_stdout(saved_stdout)
+        saved_stdout = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)                      # whatever teardown prints does not follow the JSON line
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if saved_stdout is not None:
+        os.close(saved_stdout)
 
 
 if __name__ == "__main__":
