@@ -34,6 +34,8 @@ X = Xd.cpu().numpy()
 t = time.time(); hg = H.Ohnsw.build_batch_bigarray(X, M, efc, seed=1, metric=METRIC); print("build %.2fs (n=%d d=%d M=%d efC=%d metric=%d %s)" % (time.time() - t, n, d, M, efc, METRIC, KIND), flush=True)
 stream = torch.cuda.current_stream()
 
+_orc = {}
+
 def run(nq, ef, k=K, vt=0, reps=5):
     Qd = make(nq, 2)
     ids = torch.empty((nq, k), dtype=torch.int32, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
@@ -54,8 +56,21 @@ def run(nq, ef, k=K, vt=0, reps=5):
     rec = bench.recall_ids(ids.cpu().numpy()[:ns], gt)
     print("nq=%7d ef=%4d vt=%2d: %8.3f ms  %10.0f q/s  n_dist(gpu)=%.0f hops=%.0f  gpu-bytes %.2f TB/s  recall %.3f" %
           (nq, ef, vt, ms, nq / ms * 1e3, ndm, nhm, bq * nq / ms / 1e9, rec), flush=True)
+    if os.environ.get("PARITY"):
+        # bit parity with the CPU oracle (the checker) on a sample, at this full size
+        from oracle import oracle as o
+        if "g" not in _orc:
+            hg.export()
+            _orc["sp"] = (o.Space.ip if METRIC else o.Space.l2)(X, arith=o.TREE16)
+            _orc["g"] = o.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, hg.upper)
+        np_ = int(os.environ["PARITY"])
+        go(True); torch.cuda.synchronize()
+        oi, od, ond, onh = o.Ohnsw.knn_batch_bigarray(_orc["g"], _orc["sp"], Qd[:np_].cpu().numpy(), k=k, ef=ef, ties=o.TIES_CANONICAL, counters=True)
+        gi, gd = ids[:np_].cpu().numpy(), dist[:np_].cpu().numpy()
+        print("   parity on %d queries: ids %s, distance bits %s, hop counts %s; oracle n_dist %.0f (GPU re-evaluations +%.1f%%)" %
+              (np_, np.array_equal(gi, oi), np.array_equal(gd.view(np.uint32), od.view(np.uint32)),
+               np.array_equal(nh[:np_].cpu().numpy(), onh), ond.mean(), 100 * (nd[:np_].float().mean().item() / ond.mean() - 1)), flush=True)
 
-_orc = {}
 def oracle_ndist(ef, k, ns=200):
     """exact-visited-set evaluation count from the CPU oracle (checker) on the same graph"""
     from oracle import oracle as o
