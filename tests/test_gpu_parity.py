@@ -425,3 +425,28 @@ def test_strided_vectors_and_queries(H, oracle, tiny):
     oi, od = oracle.Ohnsw.knn_batch_bigarray(g, sp, X[:40] + 0.01, k=5, ef=30, ties=oracle.TIES_CANONICAL)
     np.testing.assert_array_equal(ids, oi)
     np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+
+
+def test_inner_product_with_negative_distances(H, oracle):
+    """1 - <a,b> is negative for long vectors: the ordered-key transform must keep the order across the
+    sign change, and the reported distances must be the oracle's, bit for bit."""
+    rng = np.random.default_rng(31)
+    X = (rng.normal(size=(3000, 20)) * 2.0).astype(np.float32)          # dots from about -60 to +60
+    Q = (rng.normal(size=(80, 20)) * 2.0).astype(np.float32)
+    sp = oracle.Space.ip(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 8, 60, seed=4)
+    hg = _hgraph(H, X, g, metric=1, M=8)
+    for ef, k in ((10, 10), (100, 30)):
+        ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True)
+        oi, od, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=k, ef=ef, ties=oracle.TIES_CANONICAL, counters=True)
+        np.testing.assert_array_equal(ids, oi)
+        np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+        np.testing.assert_array_equal(nh, onh)
+        assert (dist < 0).any()
+        assert (np.diff(dist, axis=1) >= 0).all()
+    # both signs, through the gathered-distance entry point
+    pick = rng.integers(0, 3000, size=(80, 50)).astype(np.int32)
+    got = H.Ohnsw.distance_l2(hg, Q, pick)
+    want = np.array([[np.float32(1.0) - np.float32(oracle.dot_tree16(X[j], q)) for j in row] for q, row in zip(Q, pick)], np.float32)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (got < 0).any() and (got > 0).any()
