@@ -450,3 +450,34 @@ def test_inner_product_with_negative_distances(H, oracle):
     want = np.array([[np.float32(1.0) - np.float32(oracle.dot_tree16(X[j], q)) for j in row] for q, row in zip(Q, pick)], np.float32)
     np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
     assert (got < 0).any() and (got > 0).any()
+
+
+@pytest.mark.parametrize("n,d,metric,M,ef,k", [(3000, 20, 0, 8, 1024, 1024),     # the largest W (16 slots), k = ef
+                                                 (600, 1024, 0, 6, 64, 10),        # the widest rows (16 chunks per lane)
+                                                 (600, 1000, 1, 6, 70, 70),        # ragged last chunk at that width, inner product
+                                                 (2500, 7, 0, 32, 500, 3)])        # 64-wide adjacency rows, ef far above k
+def test_extremes_of_the_supported_range(H, oracle, n, d, metric, M, ef, k):
+    rng = np.random.default_rng(n + d)
+    X = rng.normal(size=(n, d)).astype(np.float32)
+    Q = rng.normal(size=(12, d)).astype(np.float32)
+    sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, M, 40, seed=3)
+    hg = _hgraph(H, X, g, metric=metric, M=M)
+    ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True)
+    oi, od, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=k, ef=ef, ties=oracle.TIES_CANONICAL, counters=True)
+    np.testing.assert_array_equal(ids, oi)
+    np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+    np.testing.assert_array_equal(nh, onh)
+    with pytest.raises(H.InvalidArgument):
+        H.Ohnsw.knn_batch_bigarray(hg, k + 1, Q, ef=k)                  # k > ef is rejected, never clamped
+
+
+def test_beyond_the_supported_range_is_refused(H, oracle, tiny):
+    X, sp, g = tiny
+    hg = _hgraph(H, X, g, M=6)
+    with pytest.raises(H.Failure, match="ef=1025"):
+        H.Ohnsw.knn_batch_bigarray(hg, 5, X[:2], ef=1025)
+    with pytest.raises(H.Failure, match="d=1025"):
+        H.Hgraph(np.zeros((4, 1025), np.float32), np.zeros(4, np.int32), np.full((4, 2), -1, np.int32), entry_point=0).to_device(0)
+    with pytest.raises(H.Failure, match="max_degree0=65"):
+        H.Hgraph(np.zeros((4, 8), np.float32), np.zeros(4, np.int32), np.full((4, 65), -1, np.int32), entry_point=0).to_device(0)
