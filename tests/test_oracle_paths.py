@@ -130,3 +130,22 @@ def test_canonical_vs_heap_on_integer_ties(oracle):
     ib, db = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=8, ef=24, ties=1)
     same = np.mean(np.all(da == db, axis=1))
     assert same > 0.8  # different tie orders explore slightly different sets; profiles mostly equal
+
+
+def test_c1_configuration_regression_pin(oracle):
+    """BASELINE.json configs[0] (10 k random fp32 vectors d = 32, M 8, ef 32, k 10: the reference's own
+    CPU-runnable case) through the oracle: results pinned by tests/golden/c1_oracle_checksum.json
+    (regenerated by tests/golden/make_c1_checksum.py) so that the checker cannot drift unnoticed."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_c1_checksum", os.path.join(here, "make_c1_checksum.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    got = m.run()
+    with open(os.path.join(here, "c1_oracle_checksum.json")) as f:
+        want = json.load(f)
+    assert got == want
+    assert got["seq_f32"]["ids_sha256"] == got["tree16"]["ids_sha256"]      # the summation order moves no neighbour here
+    assert 0.6 < got["seq_f32"]["recall_at_10"] < 0.9                        # ef = 32 on structureless data (BASELINE.md)
