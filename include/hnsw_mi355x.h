@@ -18,6 +18,7 @@
  *                            (lib/hnsw_algo.ml:350-391): one layer, explicit start nodes
  *   hnsw_search_one_batch    Ohnsw.search_one (lib/ohnsw.ml:492-512), Search.search_one
  *                            (lib/hnsw_algo.ml:393-437)
+ *   hnsw_search_submit/_wait the same batch call in two halves (several batches in flight)
  *   hnsw_multi_*             the batch entry point over several GPUs from one host process
  *   hnsw_distance_batch      Ohnsw.distance_l2 / EuclideanBa.distance (lib/ohnsw.ml:899,
  *                            lib/hnsw.ml:809-815) as timed by bench_dist/bench_dist.ml:22-33
@@ -149,6 +150,20 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
                                  int64_t q_stride, const hnsw_search_params *params,
                                  int32_t *d_ids, float *d_dist, uint32_t *d_ndist,
                                  uint32_t *d_nhops, uint32_t *d_status, void *stream);
+
+/* The same batch call in two halves, for callers that keep batches coming: a single batch ends with
+ * a drain phase (its last queries run on a nearly empty chip at their serial latency, DESIGN.md
+ * section 4), which the next batch can fill.  hnsw_search_submit copies the queries in and starts the
+ * search on one of the handle's streams, then returns; hnsw_search_wait blocks until that request is
+ * done, copies its results out (same arrays and meaning as hnsw_search_batch) and releases it.
+ * Requests may be waited for in any order; every submitted request must be waited for (or the index
+ * destroyed).  Still one host thread at a time per handle.
+ *     submit(b1); submit(b2); wait(b1); submit(b3); wait(b2); ...                                  */
+typedef struct hnsw_request hnsw_request;
+int32_t hnsw_search_submit(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
+                           const hnsw_search_params *params, hnsw_request **out);
+int32_t hnsw_search_wait(hnsw_request *req, int32_t *out_ids, float *out_dist,
+                         uint32_t *out_ndist, uint32_t *out_nhops);
 
 /* Single query (Ohnsw.knn / Hnsw.Ba.knn).  *out_count = number of results (<= k). */
 int32_t hnsw_knn(hnsw_index *idx, const float *query, const hnsw_search_params *params,

@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
     "hnsw_index_layer_stats", "hnsw_index_save", "hnsw_index_load",
     "hnsw_search_layer_batch", "hnsw_search_one_batch",
+    "hnsw_search_submit", "hnsw_search_wait",
     "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
 ]
 
@@ -127,6 +128,9 @@ def load():
         getattr(L, f).restype = i32
     L.hnsw_search_layer_batch.argtypes = [vp, i32, vp, i64, i64, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hnsw_search_one_batch.argtypes = [vp, i32, vp, i64, i64, vp, vp, vp]
+    L.hnsw_search_submit.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hnsw_search_wait.argtypes = [vp, vp, vp, vp, vp]
+    L.hnsw_search_submit.restype = L.hnsw_search_wait.restype = i32
     L.hnsw_multi_create.argtypes = [vp, vp, i32, vp]
     L.hnsw_multi_destroy.argtypes = [vp]
     L.hnsw_multi_num_replicas.argtypes = [vp, vp]
@@ -340,6 +344,37 @@ def _search(hgraph, batch, ef, k, fill, counters=False, sem=0):
     _check(load().hnsw_search_batch(hgraph.handle, _ptr(Q), nq, max(qs, hgraph.d), _C.byref(p), _ptr(ids),
                                     _ptr(dist), _ptr(nd), _ptr(nh)))
     return (ids, dist, nd, nh) if counters else (ids, dist)
+
+
+class Request:
+    """A batch in flight (hnsw_search_submit): `wait()` returns what the synchronous call would have.
+    Lets a caller overlap consecutive batches (the next one fills the drain of the previous one):
+        r1 = submit(hg, b1, ef, k); r2 = submit(hg, b2, ef, k); ids1, d1 = r1.wait(); ..."""
+
+    def __init__(self, hgraph, handle, nq, k, keep):
+        self._hg, self._h, self.nq, self.k, self._keep = hgraph, handle, nq, k, keep
+
+    def wait(self, counters=False):
+        if self._h is None:
+            raise InvalidArgument("request already waited for")
+        ids = _np.empty((self.nq, self.k), _np.int32)
+        dist = _np.empty((self.nq, self.k), _np.float32)
+        nd = _np.zeros(self.nq, _np.uint32) if counters else None
+        nh = _np.zeros(self.nq, _np.uint32) if counters else None
+        h, self._h, self._keep = self._h, None, None
+        _check(load().hnsw_search_wait(h, _ptr(ids), _ptr(dist), _ptr(nd), _ptr(nh)))
+        return (ids, dist, nd, nh) if counters else (ids, dist)
+
+
+def submit(hgraph, batch, ef, k, fill=FILL_OHNSW, sem=SEM_OHNSW):
+    """hnsw_search_submit: copy the batch in, start the search, return at once."""
+    Q, qs = _rows(batch)
+    if Q.ndim != 2 or Q.shape[0] < 1 or Q.shape[1] != hgraph.d:
+        raise InvalidArgument("batch must be [nq][d], nq >= 1")
+    p = _SearchParams(ef, k, fill, sem)
+    h = _C.c_void_p()
+    _check(load().hnsw_search_submit(hgraph.handle, _ptr(Q), Q.shape[0], max(qs, hgraph.d), _C.byref(p), _C.byref(h)))
+    return Request(hgraph, h, Q.shape[0], k, Q)
 
 
 def search_batch_device(hgraph, d_queries, nq, q_stride, ef, k, d_ids, d_dist, d_ndist=0, d_nhops=0,

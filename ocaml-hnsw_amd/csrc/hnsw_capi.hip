@@ -240,6 +240,11 @@ int32_t hnsw_index_destroy(hnsw_index *idx) {
     if (idx->device >= 0) (void)hipSetDevice(idx->device);
     for (void *p : {idx->dX, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl}) if (p) (void)hipFree(p);
     idx->sQ.release(); idx->sIds.release(); idx->sDist.release(); idx->sNd.release(); idx->sNh.release(); idx->sSt.release();
+    (void)hipDeviceSynchronize();                      // requests never waited for
+    for (hnsw_request *r : idx->all_requests) {
+        r->q.release(); r->ids.release(); r->dist.release(); r->nd.release(); r->nh.release(); r->st.release();
+        delete r;
+    }
     for (hipStream_t st : idx->hs) if (st) (void)hipStreamDestroy(st);
     delete idx;
     return HNSW_OK;
@@ -350,6 +355,71 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
         HIP_TRY(hipDeviceSynchronize());
     }
     return HNSW_OK;
+}
+
+int32_t hnsw_search_submit(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
+                           const hnsw_search_params *params, hnsw_request **out) {
+    if (!out) return fail(HNSW_ERR_BAD_ARG, "null out");
+    *out = nullptr;
+    int rc = check_params(idx, params);
+    if (rc) return rc;
+    if (nq < 1 || nq > 0x7FFFFFFFLL || !queries) return fail(HNSW_ERR_BAD_ARG, "bad buffers (nq=%lld)", (long long)nq);
+    if (q_stride < idx->iv.d) return fail(HNSW_ERR_BAD_ARG, "q_stride < d");
+    HIP_TRY(hipSetDevice(idx->device));
+    hnsw_request *r;
+    if (!idx->free_requests.empty()) { r = idx->free_requests.back(); idx->free_requests.pop_back(); }
+    else { r = new hnsw_request(); idx->all_requests.push_back(r); }
+    auto give_back = [&](int code) { idx->free_requests.push_back(r); return code; };
+    r->idx = idx; r->nq = nq; r->q_stride = q_stride; r->params = *params;
+    r->stream = idx->next_stream; idx->next_stream = (idx->next_stream + 1) & 3;
+    if (!idx->hs[r->stream] && hipStreamCreateWithFlags(&idx->hs[r->stream], hipStreamNonBlocking) != hipSuccess)
+        return give_back(fail(HNSW_ERR_HIP, "hipStreamCreate failed"));
+    const int k = params->k;
+    const size_t qbytes = ((size_t)(nq - 1) * q_stride + idx->iv.d) * sizeof(float);
+    if ((rc = r->q.ensure(qbytes)) || (rc = r->ids.ensure((size_t)nq * k * 4)) || (rc = r->dist.ensure((size_t)nq * k * 4)) ||
+        (rc = r->nd.ensure((size_t)nq * 4)) || (rc = r->nh.ensure((size_t)nq * 4)) || (rc = r->st.ensure((size_t)nq * 4)))
+        return give_back(rc);
+    hipStream_t st = idx->hs[r->stream];
+    if (hipMemcpyAsync(r->q.p, queries, qbytes, hipMemcpyHostToDevice, st) != hipSuccess)
+        return give_back(fail(HNSW_ERR_HIP, "query upload failed"));
+    rc = hnsw_search_batch_device(idx, (const float *)r->q.p, nq, q_stride, params, (int32_t *)r->ids.p, (float *)r->dist.p,
+                                  (uint32_t *)r->nd.p, (uint32_t *)r->nh.p, (uint32_t *)r->st.p, st);
+    if (rc) return give_back(rc);
+    idx->live_requests++;
+    *out = r;
+    return HNSW_OK;
+}
+
+int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uint32_t *out_ndist, uint32_t *out_nhops) {
+    if (!r || !r->idx) return fail(HNSW_ERR_BAD_ARG, "null request");
+    hnsw_index *idx = r->idx;
+    auto done = [&](int code) { r->idx = nullptr; idx->live_requests--; idx->free_requests.push_back(r); return code; };
+    if (!out_ids || !out_dist) return done(fail(HNSW_ERR_BAD_ARG, "null result buffers"));
+    if (hipSetDevice(idx->device) != hipSuccess) return done(fail(HNSW_ERR_HIP, "hipSetDevice failed"));
+    hipStream_t st = idx->hs[r->stream];
+    if (hipStreamSynchronize(st) != hipSuccess) return done(fail(HNSW_ERR_HIP, "search failed: %s", hipGetErrorString(hipGetLastError())));
+    const int k = r->params.k;
+    const int64_t nq = r->nq;
+    // exactness fallback for queries whose tie-overflow stack outgrew its LDS slots (as in hnsw_search_batch)
+    int rc = rerun_overflowed(idx, nq, (const uint32_t *)r->st.p,
+                              [&](const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap) {
+                                  SearchArgs a{};
+                                  a.Q = (const float *)r->q.p; a.q_stride = r->q_stride; a.nq = c; a.ef = r->params.ef; a.k = k;
+                                  a.fill = r->params.fill; a.sem = r->params.semantics;
+                                  a.vt_bits = search_vt_bits(idx, r->params.ef);
+                                  a.out_ids = (int32_t *)r->ids.p; a.out_dist = (float *)r->dist.p;
+                                  a.out_ndist = (uint32_t *)r->nd.p; a.out_nhops = (uint32_t *)r->nh.p; a.out_status = (uint32_t *)r->st.p;
+                                  a.qmap = qmap; a.ovf_g = slab; a.ovf_gcap = cap;
+                                  return launch_search_args(idx, a, st);
+                              });
+    if (rc) return done(rc);
+    hipError_t e = hipMemcpyAsync(out_ids, r->ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_dist, r->dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && out_ndist) e = hipMemcpyAsync(out_ndist, r->nd.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && out_nhops) e = hipMemcpyAsync(out_nhops, r->nh.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return done(fail(HNSW_ERR_HIP, "result download failed: %s", hipGetErrorString(e)));
+    return done(HNSW_OK);
 }
 
 int32_t hnsw_knn(hnsw_index *idx, const float *query, const hnsw_search_params *params,

@@ -61,6 +61,16 @@ int upload_vectors(const float *vectors, int64_t n, int d, int64_t row_stride, v
 
 } // namespace hnsw_host
 
+struct hnsw_index;
+// one submitted batch (hnsw_search_submit / hnsw_search_wait): its own device buffers and stream
+struct hnsw_request {
+    hnsw_index *idx = nullptr;
+    int64_t nq = 0, q_stride = 0;
+    hnsw_search_params params{};
+    hnsw_host::DevBuf q, ids, dist, nd, nh, st;
+    int stream = 0;
+};
+
 struct hnsw_index {
     int device = -1;
     hnsw_dev::IndexView iv{};
@@ -68,7 +78,10 @@ struct hnsw_index {
     void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr;
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt; // scratch for the host-buffer entry points
-    hipStream_t hs[4] = {nullptr, nullptr, nullptr, nullptr}; // streams of the chunked host-buffer search (lazy)
+    hipStream_t hs[4] = {nullptr, nullptr, nullptr, nullptr}; // streams of the chunked host-buffer search and of requests (lazy)
+    std::vector<hnsw_request *> free_requests;               // finished requests keep their buffers for the next submit
+    std::vector<hnsw_request *> all_requests;                // every request ever created (released with the index)
+    int live_requests = 0, next_stream = 0;
     int vt_bits_override = 0;
 };
 

@@ -161,6 +161,28 @@ inline std::vector<value_distance> search(const Hgraph &g, int layer, const std:
 
 } // namespace Ba
 
+// A batch in flight (hnsw_search_submit / hnsw_search_wait): wait() returns what knn_batch_bigarray would have.
+class Pending {
+public:
+    Pending(const Hgraph &g, const Mat &batch, int ef, int k, int fill = HNSW_FILL_OHNSW, int sem = HNSW_SEM_OHNSW) : nq_(batch.dim2), k_(k) {
+        hnsw_search_params p{ef, k, fill, sem};
+        check(hnsw_search_submit(g.handle(), batch.data, batch.dim2, batch.dim1, &p, &r_));
+    }
+    Pending(const Pending &) = delete;
+    Pending &operator=(const Pending &) = delete;
+    Pending(Pending &&o) noexcept : r_(o.r_), nq_(o.nq_), k_(o.k_) { o.r_ = nullptr; }
+    std::pair<std::vector<int32_t>, std::vector<float>> wait() {
+        std::vector<int32_t> ids((size_t)nq_ * k_); std::vector<float> dist((size_t)nq_ * k_);
+        hnsw_request *r = r_; r_ = nullptr;
+        check(hnsw_search_wait(r, ids.data(), dist.data(), nullptr, nullptr));
+        return {std::move(ids), std::move(dist)};
+    }
+private:
+    hnsw_request *r_ = nullptr;
+    int64_t nq_ = 0;
+    int k_ = 0;
+};
+
 // One host process, several GPUs: the flattened graph replicated on every listed device, batches split
 // into contiguous shards (hnsw_multi_*).
 class MultiHgraph {

@@ -89,6 +89,15 @@ int main() {
         const int want[6] = {0, 1, 4, 3, 2, 3};
         for (int i = 0; i < 6; ++i) EXPECT(r.first[(size_t)i] == want[i]);
     }
+    {   // two batches in flight, waited for in the other order
+        auto g = ring5(vals, 2, 0);
+        const float q1[2] = {0.f, 4.5f}, q2[1] = {2.2f};
+        Hnsw::Pending a(g, Hnsw::Mat{q1, 2, 1}, 5, 2), b(g, Hnsw::Mat{q2, 1, 1}, 5, 2);
+        auto rb = b.wait();
+        auto ra = a.wait();
+        EXPECT(ra.first[0] == 0 && ra.first[1] == 1 && ra.first[2] == 4 && ra.first[3] == 3);
+        EXPECT(rb.first[0] == 2 && rb.first[1] == 3);
+    }
     std::printf(fails ? "FAILED (%d)\n" : "front-end ok\n", fails);
     return fails ? 1 : 0;
 }

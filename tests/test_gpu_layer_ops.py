@@ -212,3 +212,60 @@ def test_multi_device_errors(H, oracle, built):
         m.knn_batch_bigarray(1, np.zeros((5, 4), np.float32))
     with pytest.raises(H.InvalidArgument):
         H.MultiHgraph(hg, [0, 0]).knn_batch_bigarray(10, X[:4], ef=5)   # k > ef, message from a worker thread
+
+
+# ---- submit / wait: batches in flight -------------------------------------------------------------------
+def test_submit_wait_equals_synchronous_call(H, oracle, built):
+    """hnsw_search_submit / hnsw_search_wait: several batches in flight on the handle's streams, waited
+    for out of order, give exactly what hnsw_search_batch gives for each of them."""
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    rng = np.random.default_rng(8)
+    batches = [(X[rng.integers(0, g.n, nq)] + rng.integers(0, 2, size=(nq, X.shape[1]))).astype(np.float32)
+               for nq in (1, 700, 5000, 33, 2048, 9)]
+    for rounds in range(2):                                     # the second round reuses pooled request buffers
+        reqs = [H.submit(hg, b, 40, 7) for b in batches]
+        for j in (3, 0, 5, 1, 4, 2):
+            ids, dist, nd, nh = reqs[j].wait(counters=True)
+            want = H.Ohnsw.knn_batch_bigarray(hg, 7, batches[j], ef=40, counters=True)
+            for a, b in zip((ids, dist, nd, nh), want):
+                np.testing.assert_array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+    with pytest.raises(H.InvalidArgument):
+        reqs[0].wait()                                          # a request is waited for once
+    with pytest.raises(H.InvalidArgument):
+        H.submit(hg, batches[1], 5, 7)                          # k > ef
+    r = H.submit(hg, batches[1], 40, 7)                         # never waited for: released with the index
+    del r
+    hg.release()
+
+
+def test_submit_wait_overflow_fallback_is_exact(H, oracle):
+    """The tie-overflow fallback (test_layer_operator_tie_overflow_is_exact's graph) through a request."""
+    n = 229
+    pos = np.zeros(n, np.float32)
+    pos[0] = 20.0
+    pos[1:128] = 10.0
+    pos[128:228] = 9.0 - 0.01 * np.arange(100)
+    pos[228] = 0.1
+    rows = [[] for _ in range(n)]
+    rows[0] = [1] + list(range(2, 65))
+    rows[1] = list(range(65, 128)) + [128]
+    for i in range(99):
+        rows[128 + i] = [129 + i]
+    rows[40] = [228]
+    deg0 = np.array([len(r) for r in rows], np.int32)
+    nbr0 = np.full((n, 64), -1, np.int32)
+    for i, r in enumerate(rows):
+        nbr0[i, :len(r)] = r
+    X = pos[:, None]
+    g = oracle.Graph(n, 0, deg0, nbr0)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    hg = H.Hgraph(X, deg0, nbr0, entry_point=0, max_degree=32)
+    Q = np.zeros((3, 1), np.float32)
+    want = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=10, ef=128, ties=oracle.TIES_CANONICAL)
+    r1, r2 = H.submit(hg, Q, 128, 10), H.submit(hg, Q[:1], 128, 10)
+    ids2, _ = r2.wait()
+    ids1, dist1 = r1.wait()
+    np.testing.assert_array_equal(ids1, want[0])
+    np.testing.assert_array_equal(dist1.view(np.uint32), want[1].view(np.uint32))
+    np.testing.assert_array_equal(ids2, want[0][:1])

@@ -205,3 +205,26 @@ if os.environ.get("PHASES"):
         tot = p0 + p1 + p2
         print("nq=%d: cycles per query (median): pop/filter/compact %.0f (%.0f%%)  rows+arith %.0f (%.0f%%)  accept/insert %.0f (%.0f%%)  total %.0f" %
               (nq, np.median(p0), 100 * p0.sum() / tot.sum(), np.median(p1), 100 * p1.sum() / tot.sum(), np.median(p2), 100 * p2.sum() / tot.sum(), np.median(tot)), flush=True)
+
+if os.environ.get("SUBMIT_WAIT"):
+    # host-buffer batches in flight (hnsw_search_submit / hnsw_search_wait) against the synchronous call
+    nq, ef, k, nb = 10000, 128, 10, 16
+    Qs = [make(nq, 200 + i).cpu().numpy() for i in range(nb)]
+    H.Ohnsw.knn_batch_bigarray(hg, k, Qs[0], ef=ef)
+    t = time.perf_counter()
+    for i in range(nb):
+        H.Ohnsw.knn_batch_bigarray(hg, k, Qs[i], ef=ef)
+    sync_ms = (time.perf_counter() - t) / nb * 1e3
+    for depth in (1, 2, 3):
+        for rep in range(2):
+            t = time.perf_counter()
+            inflight = []
+            for i in range(nb):
+                inflight.append(H.submit(hg, Qs[i], ef, k))
+                if len(inflight) > depth:
+                    inflight.pop(0).wait()
+            while inflight:
+                inflight.pop(0).wait()
+            dt = (time.perf_counter() - t) / nb * 1e3
+        print("host buffers, %d batch(es) in flight beyond the one being waited for: %.3f ms per 10k batch = %.0f q/s (synchronous call %.3f ms)" %
+              (depth, dt, nq / dt * 1e3, sync_ms), flush=True)
