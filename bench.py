@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=4000, help="queries timed on the CPU restatement")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the same steps alternated over two HIP streams (extra object `pipelined`, never `value`); "
+                         "off by default so that the default run's kernel trace holds serialized launches only")
     ap.add_argument("--dataset", default=None,
                     help="optional real data instead of the synthetic C2 set: an ann-benchmarks .hdf5 file, or a "
                          "directory holding *base.fvecs and *query.fvecs (TEXMEX); n and d come from the file")
@@ -261,13 +264,13 @@ def main():
     qps = world * nq * args.steps / wall
     log("ef=%d: %.0f q/s, %.3f ms/step, kernel %.3f ms" % (ef, qps, 1e3 * wall / args.steps, kern_ms))
 
-    # ---- extra (N = 1, not `value`): the same steps alternated over two HIP streams --------------
+    # ---- extra (--pipelined, N = 1, not `value`): the same steps alternated over two HIP streams ----
     # A single 10 k-query launch ends with a drain phase (the last queries to start run on a nearly
     # empty chip at their serial hop latency); a caller that keeps batches coming can start batch
     # i+1 while batch i drains.  The OCaml drop-in call is synchronous, so `value` stays the
     # serialized number; this is the sustained rate of the device-pointer entry point.
     pipelined = None
-    if world == 1 and args.steps >= 4:
+    if world == 1 and args.pipelined:
         side = [torch.cuda.Stream(device=dev) for _ in range(2)]
         def run_pipelined(steps):
             for i in range(steps):
