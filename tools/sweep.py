@@ -34,7 +34,9 @@ X = Xd.cpu().numpy()
 t = time.time(); hg = H.Ohnsw.build_batch_bigarray(X, M, efc, seed=1, metric=METRIC); print("build %.2fs (n=%d d=%d M=%d efC=%d metric=%d %s)" % (time.time() - t, n, d, M, efc, METRIC, KIND), flush=True)
 stream = torch.cuda.current_stream()
 
-_orc = {}
+# hooks called after every run(); registered by a wrapper that executes this file (the oracle is test
+# infrastructure and is only touched from tests/)
+POST_RUN = globals().get("POST_RUN", [])
 
 def run(nq, ef, k=K, vt=0, reps=5):
     Qd = make(nq, 2)
@@ -56,37 +58,8 @@ def run(nq, ef, k=K, vt=0, reps=5):
     rec = bench.recall_ids(ids.cpu().numpy()[:ns], gt)
     print("nq=%7d ef=%4d vt=%2d: %8.3f ms  %10.0f q/s  n_dist(gpu)=%.0f hops=%.0f  gpu-bytes %.2f TB/s  recall %.3f" %
           (nq, ef, vt, ms, nq / ms * 1e3, ndm, nhm, bq * nq / ms / 1e9, rec), flush=True)
-    if os.environ.get("PARITY"):
-        # bit parity with the CPU oracle (the checker) on a sample, at this full size
-        from oracle import oracle as o
-        if "g" not in _orc:
-            hg.export()
-            _orc["sp"] = (o.Space.ip if METRIC else o.Space.l2)(X, arith=o.TREE16)
-            _orc["g"] = o.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, hg.upper)
-        np_ = int(os.environ["PARITY"])
-        go(True); torch.cuda.synchronize()
-        oi, od, ond, onh = o.Ohnsw.knn_batch_bigarray(_orc["g"], _orc["sp"], Qd[:np_].cpu().numpy(), k=k, ef=ef, ties=o.TIES_CANONICAL, counters=True)
-        gi, gd = ids[:np_].cpu().numpy(), dist[:np_].cpu().numpy()
-        print("   parity on %d queries: ids %s, distance bits %s, hop counts %s; oracle n_dist %.0f (GPU re-evaluations +%.1f%%)" %
-              (np_, np.array_equal(gi, oi), np.array_equal(gd.view(np.uint32), od.view(np.uint32)),
-               np.array_equal(nh[:np_].cpu().numpy(), onh), ond.mean(), 100 * (nd[:np_].float().mean().item() / ond.mean() - 1)), flush=True)
-
-def oracle_ndist(ef, k, ns=200):
-    """exact-visited-set evaluation count from the CPU oracle (checker) on the same graph"""
-    from oracle import oracle as o
-    if "g" not in _orc:
-        hg.export()
-        _orc["sp"] = (o.Space.ip if METRIC else o.Space.l2)(X, arith=o.TREE16)
-        _orc["g"] = o.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, hg.upper)
-    Qs = make(max(ns, 64), 2)[:ns].cpu().numpy()
-    r = o.Ohnsw.knn_batch_bigarray(_orc["g"], _orc["sp"], Qs, k=k, ef=ef, ties=o.TIES_CANONICAL, counters=True)
-    return float(r[2].mean()), float(r[3].mean())
-
-if os.environ.get("ORACLE"):
-    for spec in sys.argv[1:]:
-        nq, ef, vt = (int(x) for x in spec.split(","))
-        nd, nh = oracle_ndist(ef, K)
-        print("oracle (exact visited set) ef=%d: n_dist=%.0f n_hops=%.0f" % (ef, nd, nh), flush=True)
+    for hook in POST_RUN:   # e.g. tests/sweep_with_oracle.py compares a sample with the CPU oracle
+        hook(dict(nq=nq, ef=ef, k=k, Qd=Qd, ids=ids, dist=dist, nd=nd, nh=nh, go=go, hg=hg, X=X, metric=METRIC, make=make))
 
 for spec in sys.argv[1:]:
     nq, ef, vt = (int(x) for x in spec.split(","))
