@@ -47,6 +47,17 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".ml")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "liboracle" not in txt and "hnsw_oracle" not in txt and "from oracle" not in txt, f
+    # ... and outside tests/ only the places the rules allow use it: bench.py's cpu_baseline leg and
+    # __graft_entry__ (builds the checker; smoke() checks against it).  tools/ never does.
+    import re
+    pat = re.compile(r"(from\s+oracle\b|import\s+oracle\b|liboracle|hnsw_oracle)")
+    users = []
+    for dp, dn, fs in os.walk(ROOT):
+        dn[:] = [x for x in dn if x not in (".git", "gpurun_out", "__pycache__", "tests", "oracle", "build")]
+        for f in fs:
+            if f.endswith((".py", ".sh", ".hip", ".h", ".hpp", ".cpp", ".c")) and pat.search(open(os.path.join(dp, f), errors="ignore").read()):
+                users.append(os.path.relpath(os.path.join(dp, f), ROOT))
+    assert sorted(users) == ["__graft_entry__.py", "bench.py"], users
 
 
 def test_fails_loudly_without_device(H):
