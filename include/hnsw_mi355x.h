@@ -102,7 +102,13 @@ typedef struct hnsw_index_desc {
  * FUNCTOR = Nearest.insert_distance (lib/hnsw.ml:494-506): accept iff the element is not farther
  * than max(W), which under the (distance, node id) order means: a node tied with max(W) but with
  * a smaller id takes its place.  Use FUNCTOR for Hnsw.Ba / Hnsw_algo.Knn.knn. */
-enum { HNSW_SEM_OHNSW = 0, HNSW_SEM_FUNCTOR = 1 };
+enum { HNSW_SEM_OHNSW = 0, HNSW_SEM_FUNCTOR = 1,
+       /* FUNCTOR, and the result is what Hnsw.Nearest.nearest_k (lib/hnsw.ml:522-525) returns: when
+        * ef > k that is the k FARTHEST members of W, nearest of those first -- the reference's
+        * actual behaviour of Hnsw.Ba.knn / knn_batch with ~num_neighbours_search > ~num_neighbours,
+        * a defect its author's notes acknowledge.  For callers that need the reference's output
+        * bit for bit; knn entry points only. */
+       HNSW_SEM_FUNCTOR_NEAREST_K = 2 };
 
 typedef struct hnsw_search_params {
     int32_t ef;   /* ~num_neighbours_search (lib/hnsw.ml:763); Ohnsw: ef == k (ohnsw.ml:859) */

@@ -25,7 +25,7 @@ OK, ERR_BAD_ARG, ERR_EMPTY_INDEX, ERR_DEGREE_OVERFLOW = 0, -1, -2, -3
 ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED = -4, -5, -6, -7
 METRIC_L2, METRIC_IP = 0, 1
 FILL_OHNSW, FILL_BA = 0, 1
-SEM_OHNSW, SEM_FUNCTOR = 0, 1
+SEM_OHNSW, SEM_FUNCTOR, SEM_FUNCTOR_NEAREST_K = 0, 1, 2
 
 # every symbol include/hnsw_mi355x.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -496,16 +496,18 @@ class Ba:
     ~num_neighbours_search (ef) and ~num_neighbours (k)."""
 
     @staticmethod
-    def knn(hgraph, point, num_neighbours_search, num_neighbours):
-        """-> [{node; distance_to_target}] nearest first (lib/hnsw.ml:763-767)."""
+    def knn(hgraph, point, num_neighbours_search, num_neighbours, nearest_k_compat=False):
+        """-> [{node; distance_to_target}] nearest first (lib/hnsw.ml:763-767).  nearest_k_compat=True
+        reproduces Nearest.nearest_k (lib/hnsw.ml:522-525): the k FARTHEST of W when ef > k."""
         ids, dist = _search(hgraph, _np.asarray(point, _np.float32)[None, :], num_neighbours_search,
-                            num_neighbours, FILL_BA, sem=SEM_FUNCTOR)
+                            num_neighbours, FILL_BA, sem=SEM_FUNCTOR_NEAREST_K if nearest_k_compat else SEM_FUNCTOR)
         return [(int(i), float(d)) for i, d in zip(ids[0], dist[0]) if i >= hgraph.id_base]
 
     @staticmethod
-    def knn_batch(hgraph, batch, num_neighbours_search, num_neighbours):
+    def knn_batch(hgraph, batch, num_neighbours_search, num_neighbours, nearest_k_compat=False):
         """-> distances [nq][k] fp32, +inf where fewer than k were found (lib/hnsw.ml:769-777)."""
-        return _search(hgraph, batch, num_neighbours_search, num_neighbours, FILL_BA, sem=SEM_FUNCTOR)[1]
+        return _search(hgraph, batch, num_neighbours_search, num_neighbours, FILL_BA,
+                       sem=SEM_FUNCTOR_NEAREST_K if nearest_k_compat else SEM_FUNCTOR)[1]
 
     @staticmethod
     def search(hgraph, layer, start_nodes, targets, size_nearest):

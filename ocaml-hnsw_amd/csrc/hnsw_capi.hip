@@ -107,7 +107,8 @@ int check_params(const hnsw_index *idx, const hnsw_search_params *p) {
                     "(lib/hnsw_algo.ml:257-258); rejected", p->k, p->ef);
     if (p->ef > 1024) return fail(HNSW_ERR_UNSUPPORTED, "ef=%d > 1024 not supported", p->ef);
     if (p->fill != HNSW_FILL_OHNSW && p->fill != HNSW_FILL_BA) return fail(HNSW_ERR_BAD_ARG, "bad fill %d", p->fill);
-    if (p->semantics != HNSW_SEM_OHNSW && p->semantics != HNSW_SEM_FUNCTOR) return fail(HNSW_ERR_BAD_ARG, "bad semantics %d", p->semantics);
+    if (p->semantics != HNSW_SEM_OHNSW && p->semantics != HNSW_SEM_FUNCTOR && p->semantics != HNSW_SEM_FUNCTOR_NEAREST_K)
+        return fail(HNSW_ERR_BAD_ARG, "bad semantics %d", p->semantics);
     if (idx->iv.entry_point < 0) return fail(HNSW_ERR_EMPTY_INDEX, "knn: empty hgraph");
     return HNSW_OK;
 }

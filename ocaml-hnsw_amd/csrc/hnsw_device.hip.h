@@ -50,7 +50,7 @@ struct SearchArgs {
     int64_t q_stride;
     int64_t nq;
     int32_t ef, k, fill;
-    int32_t sem;             // 0 = Ohnsw accept rule, 1 = functor (Nearest.insert_distance) rule
+    int32_t sem;             // 0 = Ohnsw accept rule, 1 = functor (Nearest.insert_distance) rule, 2 = 1 + nearest_k's output
     int32_t vt_bits;         // log2 of the LDS visited-cache entries
     int32_t *out_ids;
     float *out_dist;
@@ -603,8 +603,9 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     if (a.sem) search_layer<NCH, RB, NSLOT, METRIC, 1>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status);
     else search_layer<NCH, RB, NSLOT, METRIC, 0>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
 
-    // results: W[0..k) ascending (lib/ohnsw.ml:886-893)
-    const int wbase = NSLOT * 64 - a.ef;
+    // results: W[0..k) ascending (lib/ohnsw.ml:886-893); sem 2: nearest_k's k farthest of W, lib/hnsw.ml:522-525
+    int wbase = NSLOT * 64 - a.ef;
+    if (a.sem == 2) { const int cnt = wlist_count(w); wbase += cnt > a.k ? cnt - a.k : 0; }
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int idx = s * 64 + lane - wbase;

@@ -243,8 +243,11 @@ let ohnsw_knn_batch_bigarray (t : t) ~k (batch : Lacaml.S.mat) =
 
 (* Hnsw.Ba.knn_batch : t -> Lacaml.S.mat -> num_neighbours_search:int -> num_neighbours:int
    -> Lacaml.S.mat (lib/hnsw.ml:769-777): distances only, +inf filled (:771). *)
-let ba_knn_batch (t : t) (batch : Lacaml.S.mat) ~num_neighbours_search ~num_neighbours =
-  snd (search ~semantics:1 (* Nearest.insert_distance rule *) t batch ~ef:num_neighbours_search ~k:num_neighbours ~fill:1)
+let ba_knn_batch ?(nearest_k_compat = false) (t : t) (batch : Lacaml.S.mat) ~num_neighbours_search ~num_neighbours =
+  (* semantics 1 = Nearest.insert_distance rule; 2 = the same + Nearest.nearest_k's output (the k
+     farthest of W when num_neighbours_search > num_neighbours, lib/hnsw.ml:522-525) for callers
+     that need the reference's result bit for bit *)
+  snd (search ~semantics:(if nearest_k_compat then 2 else 1) t batch ~ef:num_neighbours_search ~k:num_neighbours ~fill:1)
 
 (* Ohnsw.search_k (lib/ohnsw.ml:543-588) on one layer for ONE target: the start MinQueue as a node
    list, the result MinQueue as an ascending (node, distance) list.  ~semantics:1 is

@@ -481,3 +481,27 @@ def test_beyond_the_supported_range_is_refused(H, oracle, tiny):
         H.Hgraph(np.zeros((4, 1025), np.float32), np.zeros(4, np.int32), np.full((4, 2), -1, np.int32), entry_point=0).to_device(0)
     with pytest.raises(H.Failure, match="max_degree0=65"):
         H.Hgraph(np.zeros((4, 8), np.float32), np.zeros(4, np.int32), np.full((4, 65), -1, np.int32), entry_point=0).to_device(0)
+
+
+def test_nearest_k_compat_reproduces_the_reference_output(H, oracle):
+    """Hnsw.Ba.knn* with ~num_neighbours_search > ~num_neighbours returns, in the reference, the k FARTHEST
+    members of W (Nearest.nearest_k, lib/hnsw.ml:522-525).  HNSW_SEM_FUNCTOR_NEAREST_K reproduces that
+    output; the default does not."""
+    rng = np.random.default_rng(17)
+    X = rng.integers(0, 9, size=(3000, 10)).astype(np.float32)
+    Q = rng.integers(0, 9, size=(60, 10)).astype(np.float32)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 8, 50, seed=6)
+    hg1 = _hgraph(H, X, g, id_base=1, M=8)
+    for ef, k in ((40, 7), (130, 20), (10, 10), (5000 // 50, 64)):
+        want_d, want_i = oracle.Functor.knn_batch(g, sp, Q, ef, k, ties=oracle.TIES_CANONICAL,
+                                                  bug_compat_farthest_k=True, with_ids=True)
+        got = H.Ba.knn_batch(hg1, Q, ef, k, nearest_k_compat=True)
+        np.testing.assert_array_equal(got.view(np.uint32), want_d.view(np.uint32))
+        one = H.Ba.knn(hg1, Q[3], ef, k, nearest_k_compat=True)
+        assert [n for n, _ in one] == [int(x) + 1 for x in want_i[3] if x >= 0]
+        plain = H.Ba.knn_batch(hg1, Q, ef, k)
+        if ef > k:
+            assert (plain[:, 0] <= got[:, 0]).all() and (plain[:, 0] < got[:, 0]).any()
+        else:
+            np.testing.assert_array_equal(plain.view(np.uint32), got.view(np.uint32))
