@@ -249,10 +249,14 @@ def main():
         run_steps(ef_, warmup)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         sync()
+        hg.set_option("time_kernels", 1)     # HIP events around the library's own launches, on the launch stream
+        hg.kernel_times()
         t = time.perf_counter()
         run_steps(ef_, steps, ev)
         sync()
         wall = time.perf_counter() - t
+        lib_times.update(zip(("search_ms", "prepass_ms", "calls"), hg.kernel_times()))
+        hg.set_option("time_kernels", 0)
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         if multi:
             w = torch.tensor([wall], dtype=torch.float64, device=cdev)
@@ -260,9 +264,12 @@ def main():
             wall = float(w[0])
         return wall, kern_ms
 
+    lib_times = {}
     wall, kern_ms = timed(ef, args.steps, args.warmup)
     qps = world * nq * args.steps / wall
-    log("ef=%d: %.0f q/s, %.3f ms/step, kernel %.3f ms" % (ef, qps, 1e3 * wall / args.steps, kern_ms))
+    search_ms, prepass_ms = lib_times["search_ms"], lib_times["prepass_ms"]
+    log("ef=%d: %.0f q/s, %.3f ms/step; per step: ordering pre-pass %.3f ms + search kernel %.3f ms (device call %.3f ms)" %
+        (ef, qps, 1e3 * wall / args.steps, prepass_ms, search_ms, kern_ms))
 
     # ---- extra (--pipelined, N = 1, not `value`): the same steps alternated over two HIP streams ----
     # A single 10 k-query launch ends with a drain phase (the last queries to start run on a nearly
@@ -334,6 +341,7 @@ def main():
     if rank == 0:
         S = 2 * args.M
         n_dist_mean, n_hops_mean = float(gpu_nd.mean()), float(gpu_nh.mean())
+        n_upper_mean = None
         src = "gpu counters (include re-evaluations)"
         if not args.no_cpu:
             from oracle import oracle as o
@@ -342,9 +350,10 @@ def main():
             sp = o.Space.l2(X, arith=o.TREE16)
             g = o.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, hg.upper)
             t = time.perf_counter()
-            oids, odist, ond, onh = o.Ohnsw.knn_batch_bigarray(g, sp, Qs, k=k, ef=ef, ties=o.TIES_CANONICAL, counters=True)
+            oids, odist, ond, onh, onu = o.Ohnsw.knn_batch_bigarray(g, sp, Qs, k=k, ef=ef, ties=o.TIES_CANONICAL, split=True)
             cpu_s = time.perf_counter() - t
             n_dist_mean, n_hops_mean = float(ond.mean()), float(onh.mean())
+            n_upper_mean = float(onu.mean())
             src = "oracle counters on %d queries" % sample
             checks["parity_queries"] = sample
             checks["parity_ids_equal"] = bool(np.array_equal(oids, got[:sample]))
@@ -364,22 +373,39 @@ def main():
             log("cpu restatement: %.1f q/s on %d queries; parity ids=%s dist=%s" %
                 (sample / cpu_s, sample, checks["parity_ids_equal"], checks["parity_dist_bits_equal"]))
         # B_q = n_dist*(4d+4) + n_hops*4S + 4d + 8k   
-        bq = n_dist_mean * (4 * d + 4) + n_hops_mean * 4 * S + 4 * d + 8 * k
-        achieved = bq * nq / (kern_ms * 1e-3) / 1e9
+        # B_q = n_dist*(4d+4) + n_hops*4S + 4d + 8k   for the whole query.  When the batch was
+        # ordered longest-first the descent ran in its own kernel: the search kernel then does the layer-0
+        # part of it (the evaluations after the descent, the hops' adjacency rows, the query, the results,
+        # 16 B of hand-over per query), and its own duration is what the library's HIP events measured.
+        bq_total = n_dist_mean * (4 * d + 4) + n_hops_mean * 4 * S + 4 * d + 8 * k
+        ordered = prepass_ms > 0
+        if ordered and n_upper_mean is not None:
+            bq = (n_dist_mean - n_upper_mean) * (4 * d + 4) + n_hops_mean * 4 * S + 4 * d + 8 * k + 16
+            kernel_ms, kernel_name = search_ms, "hnsw_search_kernel<2,4,2,0>"
+        elif ordered:      # no oracle counters: the pre-pass and the search kernel together
+            bq, kernel_ms, kernel_name = bq_total, search_ms + prepass_ms, "hnsw_descent_kernel + radix sort + hnsw_search_kernel<2,4,2,0>"
+        else:
+            bq, kernel_ms, kernel_name = bq_total, search_ms, "hnsw_search_kernel<2,4,2,0>"
+        achieved = bq * nq / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                if tj.get("workload") == "C2" and tj.get("nq") == nq and tj.get("ef") == ef:
+                if tj.get("workload") == "C2" and tj.get("nq") == nq and tj.get("ef") == ef and bool(tj.get("ordered")) == ordered:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "hnsw_search_kernel<2,4,2,0>", "kernel_ms": round(kern_ms, 4),
+                    "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
                     "bytes_per_query": round(bq, 1), "n_dist_per_query": round(n_dist_mean, 1),
-                    "n_hops_per_query": round(n_hops_mean, 1), "counters": src}
+                    "n_hops_per_query": round(n_hops_mean, 1), "counters": src,
+                    "step": {"device_call_ms": round(kern_ms, 4), "prepass_ms": round(prepass_ms, 4),
+                             "prepass": "hnsw_descent_kernel + radix sort (longest-first ordering)" if ordered else None,
+                             "bytes_per_query_whole_path": round(bq_total, 1),
+                             "n_dist_before_layer0_per_query": None if n_upper_mean is None else round(n_upper_mean, 1),
+                             "achieved_whole_path": round(bq_total * nq / (kern_ms * 1e-3) / 1e9, 1)}}
 
     if rank == 0:
         out = {

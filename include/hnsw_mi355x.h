@@ -137,9 +137,18 @@ int32_t hnsw_device_count(int32_t *count);
 int32_t hnsw_index_create(const hnsw_index_desc *desc, int32_t device, hnsw_index **out);
 int32_t hnsw_index_destroy(hnsw_index *idx);
 int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info);
-/* Tuning knobs that never change results: "vt_bits" = log2 entries of the per-query LDS
- * visited cache (0 = automatic). */
+/* Knobs that never change results:
+ *   "vt_bits"       log2 entries of the per-query LDS visited cache (0 = automatic);
+ *   "order_queries" a batch larger than the device holds at once is searched longest walk first (a
+ *                   descent pre-pass + a sort decide the order; per-query results are unchanged, the
+ *                   launch's drain phase gets shorter): -1 = automatic (default), 0 = never, 1 = always;
+ *   "time_kernels"  1 = bracket the launches of every hnsw_search_batch_device call with HIP events
+ *                   on the caller's stream (read back with hnsw_index_kernel_times). */
 int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value);
+/* Mean durations (ms) over the device-entry calls recorded since the last call of this function
+ * (option "time_kernels"): the search kernel itself, and the ordering pre-pass (descent kernel +
+ * sort; 0 when the batch was searched in the given order).  Waits for the recorded calls. */
+int32_t hnsw_index_kernel_times(hnsw_index *idx, double *search_ms, double *prepass_ms, int32_t *calls);
 
 /* Batched search, host buffers.  queries: [nq][q_stride] fp32 (a Lacaml.S.mat d x nq).
  * out_ids [nq][k] int32 (id_base-based), out_dist [nq][k] fp32, ascending.

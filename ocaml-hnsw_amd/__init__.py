@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
     "hnsw_index_layer_stats", "hnsw_index_save", "hnsw_index_load",
     "hnsw_search_layer_batch", "hnsw_search_one_batch",
-    "hnsw_search_submit", "hnsw_search_wait",
+    "hnsw_search_submit", "hnsw_search_wait", "hnsw_index_kernel_times",
     "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
 ]
 
@@ -128,6 +128,8 @@ def load():
         getattr(L, f).restype = i32
     L.hnsw_search_layer_batch.argtypes = [vp, i32, vp, i64, i64, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hnsw_search_one_batch.argtypes = [vp, i32, vp, i64, i64, vp, vp, vp]
+    L.hnsw_index_kernel_times.argtypes = [vp, vp, vp, vp]
+    L.hnsw_index_kernel_times.restype = i32
     L.hnsw_search_submit.argtypes = [vp, vp, i64, i64, vp, vp]
     L.hnsw_search_wait.argtypes = [vp, vp, vp, vp, vp]
     L.hnsw_search_submit.restype = L.hnsw_search_wait.restype = i32
@@ -318,6 +320,13 @@ class Hgraph:
 
     def set_option(self, name, value):
         _check(load().hnsw_index_set_option(self.handle, name.encode(), int(value)))
+
+    def kernel_times(self):
+        """(search kernel ms, ordering pre-pass ms, calls) averaged over the device-entry calls since the
+        last call (needs set_option("time_kernels", 1)); waits for them."""
+        s_, p_, n_ = _C.c_double(0), _C.c_double(0), _C.c_int32(0)
+        _check(load().hnsw_index_kernel_times(self.handle, _C.byref(s_), _C.byref(p_), _C.byref(n_)))
+        return s_.value, p_.value, n_.value
 
     def release(self):
         if self._index is not None:

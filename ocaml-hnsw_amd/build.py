@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libhnsw_mi355x.so")
-SOURCES = ["hnsw_capi.hip", "hnsw_build.hip", "hnsw_layer_ops.hip", "hnsw_multi.hip"]
+SOURCES = ["hnsw_capi.hip", "hnsw_build.hip", "hnsw_layer_ops.hip", "hnsw_multi.hip", "hnsw_order.hip"]
 DEPS = SOURCES + ["hnsw_device.hip.h", "hnsw_build_device.hip.h", "hnsw_internal.h",
         os.path.join(ROOT, "include", "hnsw_mi355x.h")]
 

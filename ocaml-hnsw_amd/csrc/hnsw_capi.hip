@@ -98,6 +98,43 @@ hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t q
     return hipGetLastError();
 }
 
+// how many one-wave workgroups of the search kernel for this ef are resident on the device at once
+template <int NCH, int RB, int NSLOT>
+int occupancy_of(size_t lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, 0>, 64, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    return nb;
+}
+template <int NCH, int RB>
+int occupancy_slot(int nslot, size_t lds) {
+    switch (nslot) {
+    case 1: return occupancy_of<NCH, RB, 1>(lds);
+    case 2: return occupancy_of<NCH, RB, 2>(lds);
+    case 4: return occupancy_of<NCH, RB, 4>(lds);
+    case 8: return occupancy_of<NCH, RB, 8>(lds);
+    default: return occupancy_of<NCH, RB, 16>(lds);
+    }
+}
+int64_t resident_queries(hnsw_index *idx, int ef) {
+    // cached in the handle; the answer depends on the kernel variant's registers and LDS
+    const int nslot = pick_nslot(ef), nch = pick_nch(idx->iv.nchunks);
+    const size_t lds = hnsw_dev::wave_lds_words(search_vt_bits(idx, ef)) * sizeof(uint32_t);
+    if (idx->resident_queries && idx->resident_nslot == nslot && idx->resident_lds == lds) return idx->resident_queries;
+    int per_cu = 0;
+    switch (nch) {
+    case 1: per_cu = occupancy_slot<1, 8>(nslot, lds); break;
+    case 2: per_cu = occupancy_slot<2, HNSW_RB_NCH2>(nslot, lds); break;
+    case 4: per_cu = occupancy_slot<4, 2>(nslot, lds); break;
+    case 8: per_cu = occupancy_slot<8, 1>(nslot, lds); break;
+    default: per_cu = occupancy_slot<16, 1>(nslot, lds); break;
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, idx->device) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
+    const int64_t v = (per_cu > 0 && cus > 0) ? (int64_t)per_cu * cus : (int64_t)1 << 40;   // unknown: never reorder
+    idx->resident_queries = v; idx->resident_nslot = nslot; idx->resident_lds = lds;
+    return v;
+}
+
 int check_params(const hnsw_index *idx, const hnsw_search_params *p) {
     if (!idx) return fail(HNSW_ERR_BAD_ARG, "null index");
     if (!p) return fail(HNSW_ERR_BAD_ARG, "null params");
@@ -247,6 +284,7 @@ int32_t hnsw_index_destroy(hnsw_index *idx) {
         delete r;
     }
     for (hipStream_t st : idx->hs) if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : idx->tev) (void)hipEventDestroy(e);
     delete idx;
     return HNSW_OK;
 }
@@ -260,6 +298,8 @@ int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info) {
 int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) {
     if (!idx || !name) return fail(HNSW_ERR_BAD_ARG, "null argument");
     if (!strcmp(name, "vt_bits")) { idx->vt_bits_override = (int)value; return HNSW_OK; }
+    if (!strcmp(name, "time_kernels")) { idx->time_kernels = value != 0; return HNSW_OK; }
+    if (!strcmp(name, "order_queries")) { idx->order_mode = value < 0 ? -1 : (value ? 1 : 0); return HNSW_OK; }
     return fail(HNSW_ERR_BAD_ARG, "unknown option %s", name);
 }
 
@@ -287,7 +327,54 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
     a.Q = d_queries; a.q_stride = q_stride; a.nq = nq; a.ef = params->ef; a.k = params->k; a.fill = params->fill; a.sem = params->semantics;
     a.vt_bits = search_vt_bits(idx, params->ef);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_ndist; a.out_nhops = d_nhops; a.out_status = d_status;
-    return launch_search_args(idx, a, (hipStream_t)stream);
+    // A batch larger than the chip holds at once is searched longest walk first (hnsw_order.hip):
+    // per-query results are unchanged, the launch's drain phase is made of short walks.
+    void *block = nullptr;
+    hipEvent_t *ev = nullptr;
+    if (idx->time_kernels && idx->tev_used + 3 <= 3 * 4096) {
+        while (idx->tev.size() < idx->tev_used + 3) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            idx->tev.push_back(e);
+        }
+        ev = &idx->tev[idx->tev_used];
+        idx->tev_used += 3;
+        HIP_TRY(hipEventRecord(ev[0], (hipStream_t)stream));
+    }
+    const int mode = idx->order_mode >= 0 ? idx->order_mode : env_int("HNSW_ORDER_QUERIES", -1);
+    if (mode != 0 && (mode == 1 || nq > resident_queries(idx, params->ef))) {
+        rc = order_longest_first(idx, d_queries, nq, q_stride, (hipStream_t)stream, &block, &a.qmap, &a.pre_entry, &a.pre_key, &a.pre_nd);
+        if (rc) return rc;
+    }
+    if (ev) {
+        HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
+        idx->tev_ordered.resize(idx->tev_used / 3);
+        idx->tev_ordered[idx->tev_used / 3 - 1] = block != nullptr;
+    }
+    rc = launch_search_args(idx, a, (hipStream_t)stream);
+    if (ev) HIP_TRY(hipEventRecord(ev[2], (hipStream_t)stream));
+    if (block) (void)hipFreeAsync(block, (hipStream_t)stream);
+    return rc;
+}
+
+int32_t hnsw_index_kernel_times(hnsw_index *idx, double *search_ms, double *prepass_ms, int32_t *calls) {
+    if (!idx) return fail(HNSW_ERR_BAD_ARG, "null index");
+    HIP_TRY(hipSetDevice(idx->device));
+    double s = 0, p = 0;
+    const size_t n = idx->tev_used / 3;
+    for (size_t i = 0; i < n; ++i) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventSynchronize(idx->tev[3 * i + 2]));
+        HIP_TRY(hipEventElapsedTime(&a, idx->tev[3 * i], idx->tev[3 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, idx->tev[3 * i + 1], idx->tev[3 * i + 2]));
+        if (idx->tev_ordered[i]) p += a;
+        s += b;
+    }
+    idx->tev_used = 0;
+    if (search_ms) *search_ms = n ? s / (double)n : 0.0;
+    if (prepass_ms) *prepass_ms = n ? p / (double)n : 0.0;
+    if (calls) *calls = (int32_t)n;
+    return HNSW_OK;
 }
 
 int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,

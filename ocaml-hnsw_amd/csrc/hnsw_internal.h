@@ -82,10 +82,25 @@ struct hnsw_index {
     std::vector<hnsw_request *> free_requests;               // finished requests keep their buffers for the next submit
     std::vector<hnsw_request *> all_requests;                // every request ever created (released with the index)
     int live_requests = 0, next_stream = 0;
+    int64_t resident_queries = 0;        // how many one-wave workgroups of the search kernel the chip holds (0 = not measured yet)
+    int resident_nslot = 0; size_t resident_lds = 0;   // ... for this kernel variant / LDS size
+    bool time_kernels = false;           // option "time_kernels": event triples around the launches of each device-entry call
+    std::vector<hipEvent_t> tev;         // [3 * recorded calls]: before the pre-pass, before the search kernel, after it
+    size_t tev_used = 0;
+    std::vector<char> tev_ordered;       // per recorded call: did the ordering pre-pass run
+    int order_mode = -1;                 // option "order_queries": -1 automatic (batches larger than resident_queries), 0 never, 1 always
     int vt_bits_override = 0;
 };
 
 namespace hnsw_host {
+
+// Longest-first ordering of a large batch (hnsw_order.hip): runs the descent kernel and a radix sort
+// on `st`; on success *block holds one stream-ordered allocation (release it with hipFreeAsync on
+// `st` after the search kernel has been enqueued) whose parts are returned in the other pointers.
+// Returns HNSW_OK with *block == nullptr when the device has no stream-ordered allocator.
+int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, hipStream_t st,
+                        void **block, const int32_t **qmap, const int32_t **pre_entry, const uint32_t **pre_key,
+                        const uint32_t **pre_nd);
 
 // log2 entries of the per-query LDS visited cache (never changes results)
 inline int search_vt_bits(const hnsw_index *idx, int ef) {

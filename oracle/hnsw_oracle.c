@@ -531,7 +531,7 @@ static int32_t ohnsw_knn_view(const graph_view *g, int32_t max_layer, int64_t en
     mheap_init(&resq, &s->ar, CMP_NEAREST, ties);                  /* :869 */
     mheap_init(&wq, &s->ar, CMP_NEAREST, ties);                    /* :870 */
     elt e = { node, sp_dist(sp, target, sp_value(sp, node)) };     /* :871 */
-    if (ctr) ctr->n_dist++;
+    if (ctr) { ctr->n_dist++; ctr->n_dist_upper = ctr->n_dist; }
     mheap_add(&wq, e);
     ohnsw_search_k(g, 0, sp, s->visited, &wq, target, ef, &maxq, &resq, ctr); /* :872-874 */
     return drain_ascending(&resq, k, out_nodes, out_dist);
@@ -548,26 +548,33 @@ int32_t og_ohnsw_knn(const og_graph *g, og_space *sp, const void *target, int32_
 
 /* knn_batch_bigarray, lib/ohnsw.ml:877-897: sequential loop over query columns, one Visited
  * for the whole batch (:882), results popped ascending into distances.{i,j} / ids.(j-1).(i-1). */
-int32_t og_ohnsw_knn_batch(const og_graph *g, og_space *sp, const float *Q, int64_t nq,
-                           int64_t q_stride, int32_t ef, int32_t k, int32_t ties,
-                           int32_t *out_ids, float *out_dist, uint32_t *out_ndist,
-                           uint32_t *out_nhops) {
+int32_t og_ohnsw_knn_batch_split(const og_graph *g, og_space *sp, const float *Q, int64_t nq,
+                                 int64_t q_stride, int32_t ef, int32_t k, int32_t ties,
+                                 int32_t *out_ids, float *out_dist, uint32_t *out_ndist,
+                                 uint32_t *out_nhops, uint32_t *out_ndist_upper) {
     if (g->entry_point < 0) return -1;
     scratch *s = scratch_create(g->view.n);
     int64_t *nodes = (int64_t *)malloc(sizeof(int64_t) * (size_t)k);
     double *dists = (double *)malloc(sizeof(double) * (size_t)k);
     for (int64_t j = 0; j < nq; ++j) {
         for (int32_t i = 0; i < k; ++i) { out_dist[j * k + i] = NAN; out_ids[j * k + i] = -1; } /* :880-881 */
-        og_counters ctr = { 0, 0, 0 };
+        og_counters ctr = { 0, 0, 0, 0 };
         int32_t cnt = ohnsw_knn_view(&g->view, g->max_layer, g->entry_point, sp, s,
                                      (const void *)(Q + j * q_stride), ef, k, ties, nodes, dists, &ctr);
         for (int32_t i = 0; i < cnt; ++i) { out_dist[j * k + i] = (float)dists[i]; out_ids[j * k + i] = (int32_t)nodes[i]; }
         if (out_ndist) out_ndist[j] = (uint32_t)ctr.n_dist;
         if (out_nhops) out_nhops[j] = (uint32_t)ctr.n_hops;
+        if (out_ndist_upper) out_ndist_upper[j] = (uint32_t)ctr.n_dist_upper;
     }
     free(nodes); free(dists);
     scratch_destroy(s);
     return 0;
+}
+int32_t og_ohnsw_knn_batch(const og_graph *g, og_space *sp, const float *Q, int64_t nq,
+                           int64_t q_stride, int32_t ef, int32_t k, int32_t ties,
+                           int32_t *out_ids, float *out_dist, uint32_t *out_ndist,
+                           uint32_t *out_nhops) {
+    return og_ohnsw_knn_batch_split(g, sp, Q, nq, q_stride, ef, k, ties, out_ids, out_dist, out_ndist, out_nhops, NULL);
 }
 
 /* The same batch loop with the queries split over host threads (each with its own Visited and

@@ -81,6 +81,8 @@ typedef struct og_counters {
     uint64_t n_dist; /* distance evaluations (unit of work of the roofline) */
     uint64_t n_hops; /* candidates expanded on layer 0                                 */
     uint64_t n_hops_upper;
+    uint64_t n_dist_upper; /* of n_dist, those spent before the layer-0 loop starts (descent + the
+                              evaluation of the layer-0 start node, lib/ohnsw.ml:865-871)        */
 } og_counters;
 
 /* ---- imperative path: lib/ohnsw.ml -------------------------------------------------------- */
@@ -106,6 +108,13 @@ int32_t og_ohnsw_knn_batch(const og_graph *g, og_space *sp, const float *Q, int6
                            int64_t q_stride, int32_t ef, int32_t k, int32_t ties,
                            int32_t *out_ids, float *out_dist, uint32_t *out_ndist,
                            uint32_t *out_nhops);
+
+/* the same, with the per-query split of the evaluations: out_ndist_upper (optional) = those spent before
+ * the layer-0 loop (what a separate descent pass does) */
+int32_t og_ohnsw_knn_batch_split(const og_graph *g, og_space *sp, const float *Q, int64_t nq,
+                                 int64_t q_stride, int32_t ef, int32_t k, int32_t ties,
+                                 int32_t *out_ids, float *out_dist, uint32_t *out_ndist,
+                                 uint32_t *out_nhops, uint32_t *out_ndist_upper);
 
 /* the same over `nthreads` host threads (CPU baseline on all cores; the reference is 1 thread) */
 int32_t og_ohnsw_knn_batch_mt(const og_graph *g, og_space *sp, const float *Q, int64_t nq,

@@ -41,7 +41,8 @@ class _Space(C.Structure):
 
 
 class _Counters(C.Structure):
-    _fields_ = [("n_dist", C.c_uint64), ("n_hops", C.c_uint64), ("n_hops_upper", C.c_uint64)]
+    _fields_ = [("n_dist", C.c_uint64), ("n_hops", C.c_uint64), ("n_hops_upper", C.c_uint64),
+                ("n_dist_upper", C.c_uint64)]
 
 
 _lib = None
@@ -68,6 +69,8 @@ def lib():
     L.og_ohnsw_knn.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.og_ohnsw_knn_batch.restype = i32
     L.og_ohnsw_knn_batch.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp]
+    L.og_ohnsw_knn_batch_split.restype = i32
+    L.og_ohnsw_knn_batch_split.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp]
     L.og_ohnsw_knn_batch_mt.restype = i32
     L.og_ohnsw_knn_batch_mt.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp]
     L.og_functor_search_one.restype = i64
@@ -300,8 +303,10 @@ class Ohnsw:
         return (res, c) if counters else res
 
     @staticmethod
-    def knn_batch_bigarray(graph, space, batch, k, ef=None, ties=TIES_HEAP, counters=False):
-        """-> (ids [nq][k] int32, -1 filled; distances [nq][k] float32, NaN filled)"""
+    def knn_batch_bigarray(graph, space, batch, k, ef=None, ties=TIES_HEAP, counters=False, split=False):
+        """-> (ids [nq][k] int32, -1 filled; distances [nq][k] float32, NaN filled)
+        counters: + per-query evaluations and layer-0 hops; split: + the evaluations spent before the
+        layer-0 loop (descent + start node)"""
         ef = k if ef is None else ef
         Q = np.ascontiguousarray(batch, dtype=np.float32)
         nq = Q.shape[0]
@@ -309,10 +314,13 @@ class Ohnsw:
         dist = np.empty((nq, k), np.float32)
         nd = np.zeros(nq, np.uint32)
         nh = np.zeros(nq, np.uint32)
-        r = lib().og_ohnsw_knn_batch(graph._h, space.ref(), _ptr(Q), nq, Q.shape[1] if nq else 0,
-                                     ef, k, ties, _ptr(ids), _ptr(dist), _ptr(nd), _ptr(nh))
+        nu = np.zeros(nq, np.uint32)
+        r = lib().og_ohnsw_knn_batch_split(graph._h, space.ref(), _ptr(Q), nq, Q.shape[1] if nq else 0,
+                                           ef, k, ties, _ptr(ids), _ptr(dist), _ptr(nd), _ptr(nh), _ptr(nu))
         if r < 0:
             raise ValueError("knn: empty hgraph")
+        if split:
+            return ids, dist, nd, nh, nu
         return (ids, dist, nd, nh) if counters else (ids, dist)
 
 

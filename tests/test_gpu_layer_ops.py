@@ -269,3 +269,73 @@ def test_submit_wait_overflow_fallback_is_exact(H, oracle):
     np.testing.assert_array_equal(ids1, want[0])
     np.testing.assert_array_equal(dist1.view(np.uint32), want[1].view(np.uint32))
     np.testing.assert_array_equal(ids2, want[0][:1])
+
+
+# ---- longest-first ordering of large batches --------------------------------------------------------------
+def test_longest_first_ordering_changes_nothing_but_the_order(H, oracle, built):
+    """Option "order_queries": a descent pre-pass + a sort decide in which order the queries of a batch are
+    launched (farthest layer-0 entry first).  Results AND counters per query must be exactly those of the
+    unordered launch -- for every kernel variant touched: several W sizes, both accept rules, both
+    metrics, a graph without upper layers, tiny batches, and through the host-buffer and request paths."""
+    X, sp, g = built
+    rng = np.random.default_rng(12)
+    Q = (X[rng.integers(0, g.n, 3000)] + rng.integers(0, 2, size=(3000, X.shape[1]))).astype(np.float32)
+    hg = _hgraph(H, X, g, M=6)
+    hg1 = _hgraph(H, X, g, id_base=1, M=6)
+    for ef, k in ((10, 10), (100, 20), (200, 7), (600, 50)):
+        for nq in (1, 5, 3000):
+            hg.set_option("order_queries", 0)
+            plain = H.Ohnsw.knn_batch_bigarray(hg, k, Q[:nq], ef=ef, counters=True)
+            hg.set_option("order_queries", 1)
+            ordered = H.Ohnsw.knn_batch_bigarray(hg, k, Q[:nq], ef=ef, counters=True)
+            for a, b in zip(plain, ordered):
+                np.testing.assert_array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+    hg.set_option("order_queries", 1)
+    oi, od, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q[:300], k=20, ef=100, ties=oracle.TIES_CANONICAL, counters=True)
+    gi, gd, gnd, gnh = H.Ohnsw.knn_batch_bigarray(hg, 20, Q[:300], ef=100, counters=True)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd.view(np.uint32), od.view(np.uint32))
+    np.testing.assert_array_equal(gnh, onh)
+    # functor rule, 1-based ids, request path
+    hg1.set_option("order_queries", 0)
+    want = H.Ba.knn_batch(hg1, Q, 64, 9)
+    hg1.set_option("order_queries", 1)
+    np.testing.assert_array_equal(H.Ba.knn_batch(hg1, Q, 64, 9).view(np.uint32), want.view(np.uint32))
+    r = H.submit(hg1, Q, 64, 9, fill=H.FILL_BA, sem=H.SEM_FUNCTOR)
+    np.testing.assert_array_equal(r.wait()[1].view(np.uint32), want.view(np.uint32))
+    # inner product, and a graph with no upper layer at all (the "descent" is the entry point's distance)
+    Xn = X / np.maximum(np.linalg.norm(X, axis=1, keepdims=True), 1e-6)
+    spi = oracle.Space.ip(Xn.astype(np.float32), arith=oracle.TREE16)
+    gi_ = oracle.build_ohnsw(spi, 6, 40, seed=2)
+    hgi = _hgraph(H, Xn.astype(np.float32), gi_, metric=1, M=6)
+    flat = H.Hgraph(X, g.deg0, g.nbr0, entry_point=g.entry_point, max_degree=6)
+    for h_, q_ in ((hgi, (Q / np.maximum(np.linalg.norm(Q, axis=1, keepdims=True), 1e-6)).astype(np.float32)), (flat, Q)):
+        h_.set_option("order_queries", 0)
+        a = H.Ohnsw.knn_batch_bigarray(h_, 10, q_, ef=50, counters=True)
+        h_.set_option("order_queries", 1)
+        b = H.Ohnsw.knn_batch_bigarray(h_, 10, q_, ef=50, counters=True)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
+
+
+def test_kernel_times_diagnostic(H, oracle, built):
+    import torch
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    dev = torch.device("cuda", 0)
+    Qd = torch.from_numpy(X[:2000].copy()).to(dev)
+    ids = torch.empty((2000, 5), dtype=torch.int32, device=dev)
+    dist = torch.empty((2000, 5), dtype=torch.float32, device=dev)
+    hg.set_option("time_kernels", 1)
+    for mode, expect_prepass in ((0, False), (1, True)):
+        hg.set_option("order_queries", mode)
+        assert hg.kernel_times()[2] >= 0                      # reset
+        for _ in range(3):
+            H.search_batch_device(hg, Qd.data_ptr(), 2000, X.shape[1], 30, 5, ids.data_ptr(), dist.data_ptr())
+        s_ms, p_ms, calls = hg.kernel_times()
+        assert calls == 3 and s_ms > 0
+        assert (p_ms > 0) == expect_prepass
+    hg.set_option("time_kernels", 0)
+    H.search_batch_device(hg, Qd.data_ptr(), 2000, X.shape[1], 30, 5, ids.data_ptr(), dist.data_ptr())
+    torch.cuda.synchronize()
+    assert hg.kernel_times()[2] == 0
