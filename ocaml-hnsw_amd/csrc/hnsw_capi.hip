@@ -285,6 +285,7 @@ int32_t hnsw_index_destroy(hnsw_index *idx) {
     }
     for (hipStream_t st : idx->hs) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : idx->tev) (void)hipEventDestroy(e);
+    for (auto &o : idx->order_scratch) if (o.p) (void)hipFree(o.p);
     delete idx;
     return HNSW_OK;
 }
@@ -353,7 +354,6 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
     }
     rc = launch_search_args(idx, a, (hipStream_t)stream);
     if (ev) HIP_TRY(hipEventRecord(ev[2], (hipStream_t)stream));
-    if (block) (void)hipFreeAsync(block, (hipStream_t)stream);
     return rc;
 }
 

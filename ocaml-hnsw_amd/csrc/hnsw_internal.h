@@ -88,6 +88,10 @@ struct hnsw_index {
     std::vector<hipEvent_t> tev;         // [3 * recorded calls]: before the pre-pass, before the search kernel, after it
     size_t tev_used = 0;
     std::vector<char> tev_ordered;       // per recorded call: did the ordering pre-pass run
+    // scratch of the ordering pre-pass, one block per caller stream (kept between calls: work on one
+    // stream is ordered, so the block is free again when the next call on that stream needs it)
+    struct OrderScratch { hipStream_t st; void *p; size_t bytes; };
+    std::vector<OrderScratch> order_scratch;
     int order_mode = -1;                 // option "order_queries": -1 automatic (batches larger than resident_queries), 0 never, 1 always
     int vt_bits_override = 0;
 };
@@ -95,9 +99,8 @@ struct hnsw_index {
 namespace hnsw_host {
 
 // Longest-first ordering of a large batch (hnsw_order.hip): runs the descent kernel and a radix sort
-// on `st`; on success *block holds one stream-ordered allocation (release it with hipFreeAsync on
-// `st` after the search kernel has been enqueued) whose parts are returned in the other pointers.
-// Returns HNSW_OK with *block == nullptr when the device has no stream-ordered allocator.
+// on `st`; on success *block points to the handle's scratch for that stream (nothing to release)
+// whose parts are returned in the other pointers.
 int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, hipStream_t st,
                         void **block, const int32_t **qmap, const int32_t **pre_entry, const uint32_t **pre_key,
                         const uint32_t **pre_nd);

@@ -30,20 +30,26 @@ int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, i
                         void **block, const int32_t **qmap, const int32_t **pre_entry, const uint32_t **pre_key,
                         const uint32_t **pre_nd) {
     *block = nullptr;
-    int pools = 0;
-    if (hipDeviceGetAttribute(&pools, hipDeviceAttributeMemoryPoolsSupported, idx->device) != hipSuccess || !pools) {
-        (void)hipGetLastError();
-        return HNSW_OK;                               // no stream-ordered allocator: the caller searches in the given order
-    }
     const size_t n = (size_t)nq, slot = (n * 4 + 255) & ~(size_t)255;
     size_t temp_bytes = 0;
     if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                            (const int32_t *)nullptr, (int32_t *)nullptr, (int)nq, 0, 32, st) != hipSuccess)
         return fail(HNSW_ERR_HIP, "radix sort sizing failed");
     temp_bytes = (temp_bytes + 255) & ~(size_t)255;
-    char *base = nullptr;
-    hipError_t e = hipMallocAsync((void **)&base, 7 * slot + temp_bytes, st);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(e == hipErrorOutOfMemory ? HNSW_ERR_OOM : HNSW_ERR_HIP, "hipMallocAsync failed: %s", hipGetErrorString(e)); }
+    const size_t need = 7 * slot + temp_bytes;
+    // the handle keeps one scratch block per caller stream; it only ever grows
+    hnsw_index::OrderScratch *sc = nullptr;
+    for (auto &o : idx->order_scratch) if (o.st == st) sc = &o;
+    if (!sc) { idx->order_scratch.push_back({st, nullptr, 0}); sc = &idx->order_scratch.back(); }
+    if (sc->bytes < need) {
+        if (sc->p) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(sc->p); sc->p = nullptr; sc->bytes = 0; }
+        const size_t grow = need + need / 4;
+        hipError_t me = hipMalloc(&sc->p, grow);
+        if (me != hipSuccess) { (void)hipGetLastError(); sc->p = nullptr; return fail(me == hipErrorOutOfMemory ? HNSW_ERR_OOM : HNSW_ERR_HIP, "hipMalloc(%zu) for the ordering pre-pass failed", grow); }
+        sc->bytes = grow;
+    }
+    char *base = (char *)sc->p;
+    hipError_t e;
     int32_t *entry = (int32_t *)(base + 0 * slot);
     uint32_t *key = (uint32_t *)(base + 1 * slot), *nd = (uint32_t *)(base + 2 * slot);
     uint32_t *sortkey = (uint32_t *)(base + 3 * slot), *sorted = (uint32_t *)(base + 4 * slot);
@@ -54,7 +60,7 @@ int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, i
                                            : launch_descent<1>(nch, idx->iv, d_queries, q_stride, nq, entry, key, nd, sortkey, index, st);
     if (e == hipSuccess)
         e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t *)sortkey, sorted, (const int32_t *)index, order, (int)nq, 0, 32, st);
-    if (e != hipSuccess) { (void)hipFreeAsync(base, st); return fail(HNSW_ERR_HIP, "ordering pre-pass failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(HNSW_ERR_HIP, "ordering pre-pass failed: %s", hipGetErrorString(e));
     *block = base; *qmap = order; *pre_entry = entry; *pre_key = key; *pre_nd = nd;
     return HNSW_OK;
 }
