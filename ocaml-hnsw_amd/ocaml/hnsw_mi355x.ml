@@ -70,6 +70,11 @@ let hnsw_search_one_batch =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_search_one_batch"
     (index @-> int32_t @-> ptr float @-> int64_t @-> int64_t @-> ptr int64_t @-> ptr int64_t
      @-> ptr float @-> returning int32_t)
+let hnsw_index_set_option =
+  foreign ~from:lib "hnsw_index_set_option" (index @-> string @-> int64_t @-> returning int32_t)
+let hnsw_index_kernel_times =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_index_kernel_times"
+    (index @-> ptr double @-> ptr double @-> ptr int32_t @-> returning int32_t)
 type request = unit ptr
 let request : request typ = ptr void
 let hnsw_search_submit =
