@@ -346,6 +346,7 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
     if (mode != 0 && (mode == 1 || nq > resident_queries(idx, params->ef))) {
         rc = order_longest_first(idx, d_queries, nq, q_stride, (hipStream_t)stream, &block, &a.qmap, &a.pre_entry, &a.pre_key, &a.pre_nd);
         if (rc) return rc;
+        a.q_limit = nq;
     }
     if (ev) {
         HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
@@ -422,7 +423,7 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
                               a.vt_bits = search_vt_bits(idx, params->ef);
                               a.out_ids = (int32_t *)idx->sIds.p; a.out_dist = (float *)idx->sDist.p;
                               a.out_ndist = (uint32_t *)idx->sNd.p; a.out_nhops = (uint32_t *)idx->sNh.p; a.out_status = (uint32_t *)idx->sSt.p;
-                              a.qmap = qmap; a.ovf_g = slab; a.ovf_gcap = cap;
+                              a.qmap = qmap; a.q_limit = nq; a.ovf_g = slab; a.ovf_gcap = cap;
                               return launch_search_args(idx, a, nullptr);
                           }, &n_rerun);
     if (rc) return rc;
@@ -485,7 +486,7 @@ int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uin
                                   a.vt_bits = search_vt_bits(idx, r->params.ef);
                                   a.out_ids = (int32_t *)r->ids.p; a.out_dist = (float *)r->dist.p;
                                   a.out_ndist = (uint32_t *)r->nd.p; a.out_nhops = (uint32_t *)r->nh.p; a.out_status = (uint32_t *)r->st.p;
-                                  a.qmap = qmap; a.ovf_g = slab; a.ovf_gcap = cap;
+                                  a.qmap = qmap; a.q_limit = nq; a.ovf_g = slab; a.ovf_gcap = cap;
                                   return launch_search_args(idx, a, st);
                               });
     if (rc) return done(rc);

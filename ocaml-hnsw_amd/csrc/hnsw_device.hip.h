@@ -55,7 +55,8 @@ struct SearchArgs {
     int32_t *out_ids;
     float *out_dist;
     uint32_t *out_ndist, *out_nhops, *out_status;
-    const int32_t *qmap;     // optional: block b searches query qmap[b] (re-run of flagged queries)
+    const int32_t *qmap;     // optional: block b searches query qmap[b] (re-run of flagged queries, ordered launches)
+    int64_t q_limit;         // with qmap: indices outside [0, q_limit) are skipped (0 = not checked)
     uint32_t *ovf_g;         // optional: [grid][ovf_gcap] global overflow slabs
     int32_t ovf_gcap;
     // optional: the descent was done by hnsw_descent_kernel (longest-first ordering of a large batch):
@@ -576,6 +577,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     const int lane = threadIdx.x;
     if ((int64_t)blockIdx.x >= a.nq) return;
     const int64_t q = a.qmap ? a.qmap[blockIdx.x] : (int64_t)blockIdx.x;
+    if (a.q_limit && (q < 0 || q >= a.q_limit)) return;     // never follow a bad map entry into memory
     WaveCtx cx = make_ctx(lds, a.vt_bits, lane);
     if (a.ovf_g) { cx.ovf.g = a.ovf_g + (int64_t)blockIdx.x * a.ovf_gcap; cx.ovf.gcap = a.ovf_gcap; }
 #ifdef HNSW_TIMING
