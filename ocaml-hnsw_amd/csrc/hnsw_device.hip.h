@@ -97,6 +97,22 @@ __device__ __forceinline__ float reduce16(float v) {
     v = dpp_add<0x121>(v); // row_ror:1
     return v;
 }
+// minimum over the wave (wave-uniform result): row_ror mins inside the four 16-lane rows, then the
+// four row results through scalar registers -- no LDS round trips
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+    return t < v ? t : v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_min_u32<0x128>(v);
+    v = dpp_min_u32<0x124>(v);
+    v = dpp_min_u32<0x122>(v);
+    v = dpp_min_u32<0x121>(v);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
 // lane i <- lane i-1; lane 0 <- carry (wave_shr:1, bound_ctrl off keeps `old` in lane 0)
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t carry) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138, 0xF, 0xF, false);
@@ -446,15 +462,13 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
             eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, cnt, cx.r, cx.l16);
             __syncthreads();
             n_dist += cnt;
-            uint64_t best = (cx.lane < cnt) ? (((uint64_t)cx.cand_key[cx.lane] << 32) | (uint32_t)cx.lane) : ~0ull;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const uint64_t other = __shfl_xor(best, o);
-                best = other < best ? other : best;
-            }
-            const uint32_t bkey = (uint32_t)(best >> 32);
-            if (bkey < cur_key) { cur = cx.cand_id[(int)(best & 63u)]; cur_key = bkey; } // strict, :502
-            else break;
+            // the nearest neighbour, the first in row order among equals
+            const uint32_t my = (cx.lane < cnt) ? cx.cand_key[cx.lane] : KEY_INF;
+            const uint32_t bkey = wave_min_u32(my);
+            if (bkey < cur_key) {                                         // strict, :502
+                const int bi = __builtin_ctzll(__ballot(cx.lane < cnt && my == bkey));
+                cur = cx.cand_id[bi]; cur_key = bkey;
+            } else break;
         }
     }
 }
