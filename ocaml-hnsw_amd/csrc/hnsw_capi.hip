@@ -344,7 +344,7 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
     }
     const int mode = idx->order_mode >= 0 ? idx->order_mode : env_int("HNSW_ORDER_QUERIES", -1);
     if (mode != 0 && (mode == 1 || nq > resident_queries(idx, params->ef))) {
-        rc = order_longest_first(idx, d_queries, nq, q_stride, (hipStream_t)stream, &block, &a.qmap, &a.pre_entry, &a.pre_key, &a.pre_nd);
+        rc = order_longest_first(idx, d_queries, nq, q_stride, (hipStream_t)stream, &block, &a.qmap, &a.pre_entry, &a.pre_key, &a.pre_nd, &a.pre_layer);
         if (rc) return rc;
         a.q_limit = nq;
     }

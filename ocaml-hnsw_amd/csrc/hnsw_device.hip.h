@@ -64,6 +64,7 @@ struct SearchArgs {
     const int32_t *pre_entry;
     const uint32_t *pre_key;
     const uint32_t *pre_nd;
+    int32_t pre_layer;       // the pre-pass descended through layers max_layer..pre_layer; this kernel continues below
 };
 
 // ---- distance keys -------------------------------------------------------------------------
@@ -467,7 +468,7 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
             const uint32_t bkey = wave_min_u32(my);
             if (bkey < cur_key) {                                         // strict, :502
                 const int bi = __builtin_ctzll(__ballot(cx.lane < cnt && my == bkey));
-                cur = cx.cand_id[bi]; cur_key = bkey;
+                cur = uniform(cx.cand_id[bi]); cur_key = bkey;          // scalar: its row offset comes through the scalar cache
             } else break;
         }
     }
@@ -608,6 +609,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     uint32_t cur_key;
     if (a.pre_entry) {                       // descent already done (hnsw_descent_kernel)
         cur = a.pre_entry[q]; cur_key = a.pre_key[q]; n_dist = a.pre_nd[q];
+        if (a.pre_layer > 1) greedy_descend<NCH, RB, METRIC>(iv, qv, a.pre_layer - 1, 1, cur, cur_key, cx, n_dist);
     } else {
         // entry point
         cur = iv.entry_point;
@@ -665,7 +667,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
 // start first and the drain is made of short ones.  Per-query results do not depend on the order.
 template <int NCH, int RB, int METRIC>
 __global__ void __launch_bounds__(64)
-hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq,
+hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq, int32_t to_layer,
                     int32_t *out_entry, uint32_t *out_key, uint32_t *out_nd,
                     uint32_t *out_sortkey, int32_t *out_index) {
     extern __shared__ uint32_t lds[];
@@ -682,7 +684,7 @@ hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_
     __syncthreads();
     uint32_t cur_key = cx.cand_key[0];
     uint32_t n_dist = 1;
-    greedy_descend<NCH, RB, METRIC>(iv, qv, iv.max_layer, 1, cur, cur_key, cx, n_dist);
+    greedy_descend<NCH, RB, METRIC>(iv, qv, iv.max_layer, to_layer, cur, cur_key, cx, n_dist);
     if (lane == 0) {
         out_entry[q] = cur; out_key[q] = cur_key; out_nd[q] = n_dist;
         out_sortkey[q] = ~cur_key;           // ascending sort of this = farthest entry first

@@ -103,7 +103,7 @@ namespace hnsw_host {
 // whose parts are returned in the other pointers.
 int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, hipStream_t st,
                         void **block, const int32_t **qmap, const int32_t **pre_entry, const uint32_t **pre_key,
-                        const uint32_t **pre_nd);
+                        const uint32_t **pre_nd, int32_t *pre_layer);
 
 // log2 entries of the per-query LDS visited cache (never changes results)
 inline int search_vt_bits(const hnsw_index *idx, int ef) {
