@@ -194,6 +194,33 @@ let flatten_ba (h : Hnsw.Ba.Hgraph.t) ~num_connections:m : flat =
   in
   { deg0; nbr0; upper; max_layer; entry_point = G.entry_point h (* -1 when empty, lib/hnsw.ml:391 *) }
 
+(* The inverse: rebuild an Ohnsw.Hgraph.t from the flattened tables (e.g. an index built on the device by
+   hnsw_build and fetched with hnsw_index_export_*), so that the OCaml builder can keep inserting into
+   it.  Every Neighbours.t gets its list in the stored order (Neighbours.iter order = search_k's
+   fold order, :127,:570): Neighbours.add conses (:116-118), so a row is pushed back to front.  The
+   tables hold symmetric links already, so the rows are written with Vector.set, not with
+   Graph.set_connections (which would add every link twice, :182-196). *)
+let unflatten_ohnsw (distance : 'a Ohnsw.distance) (value : 'a Ohnsw.value) (f : flat) : 'a Ohnsw.Hgraph.t =
+  let h = Ohnsw.Hgraph.create distance value in
+  let n = A1.dim f.deg0 in
+  for _ = 1 to n do ignore (Ohnsw.Hgraph.add_node h) done;          (* lib/ohnsw.ml:328-330 *)
+  Ohnsw.Hgraph.set_max_layer h f.max_layer;                            (* :347-351 *)
+  let neighbours_of_row (nbr : (int32, _, _) A2.t) r deg =
+    let nb = Ohnsw.Neighbours.create () in
+    for j = deg - 1 downto 0 do Ohnsw.Neighbours.add nb (Int32.to_int nbr.{r, j}) done;
+    nb in
+  let g0 = Ohnsw.Hgraph.layer h 0 in
+  for i = 0 to n - 1 do
+    Ohnsw.Vector.set g0 i (neighbours_of_row f.nbr0 i (Int32.to_int f.deg0.{i}))
+  done;
+  Array.iteri (fun l (nodes, deg, nbr) ->
+      let g = Ohnsw.Hgraph.layer h (l + 1) in
+      for r = 0 to A1.dim nodes - 1 do
+        Ohnsw.Vector.set g (Int64.to_int nodes.{r}) (neighbours_of_row nbr r (Int32.to_int deg.{r}))
+      done) f.upper;
+  if f.entry_point >= 0 then Ohnsw.Hgraph.set_entry_point h f.entry_point;   (* :341-344 *)
+  h
+
 (* ---- device-resident index ------------------------------------------------------------------ *)
 type t = { handle : index; k_base : int; dim : int }
 
