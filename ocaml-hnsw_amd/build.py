@@ -9,7 +9,10 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libhnsw_mi355x.so")
 SOURCES = ["hnsw_capi.hip", "hnsw_build.hip", "hnsw_layer_ops.hip", "hnsw_multi.hip", "hnsw_order.hip"]
-DEPS = SOURCES + ["hnsw_device.hip.h", "hnsw_build_device.hip.h", "hnsw_internal.h",
+# the knn kernel's variants: one object per (metric, accept rule, row shape), see hnsw_search_variants.hip
+VARIANT_SOURCE = "hnsw_search_variants.hip"
+VARIANTS = [(m, s, f) for m in (0, 1) for s in (0, 1) for f in (0, 1)]
+DEPS = SOURCES + [VARIANT_SOURCE, "hnsw_device.hip.h", "hnsw_build_device.hip.h", "hnsw_internal.h",
         os.path.join(ROOT, "include", "hnsw_mi355x.h")]
 
 
@@ -38,7 +41,7 @@ def build(force=False, verbose=False, resource_log=None):
     if os.environ.get("HNSW_RB_NCH2"):
         base += ["-DHNSW_RB_NCH2=" + os.environ["HNSW_RB_NCH2"]]
     if os.environ.get("HNSW_SEARCH_MIN_WAVES"):
-        base += ["-DHNSW_SEARCH_MIN_WAVES=" + os.environ["HNSW_SEARCH_MIN_WAVES"]]
+        base += ["-DHNSW_SEARCH_MIN_WAVES(NCH,NSLOT,METRIC,FULL)=" + os.environ["HNSW_SEARCH_MIN_WAVES"]]
     extra = os.environ.get("HNSW_EXTRA_CFLAGS", "").split()   # experiments: variant builds
     base += extra
     lib_out = os.environ.get("HNSW_LIB_OUT") or LIB
@@ -46,20 +49,30 @@ def build(force=False, verbose=False, resource_log=None):
         base += ["-Rpass-analysis=kernel-resource-usage"]
     objdir = os.path.join(HERE, "build") if lib_out == LIB else lib_out + ".obj"
     os.makedirs(objdir, exist_ok=True)
-    procs = []
-    for s_ in SOURCES:  # one hipcc per translation unit, in parallel
-        obj = os.path.join(objdir, s_ + ".o")
-        cmd = base + ["-c", os.path.join(CSRC, s_), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        log = open(resource_log + "." + s_, "w") if resource_log else None
-        procs.append((subprocess.Popen(cmd, stderr=log), obj, cmd, log))
-    objs = []
-    for pr, obj, cmd, log in procs:
+    units = [(s_, s_, []) for s_ in SOURCES]
+    units += [("hnsw_search_variants_%d_%d_%d" % v, VARIANT_SOURCE,
+               ["-DHNSW_V_METRIC=%d" % v[0], "-DHNSW_V_SEMF=%d" % v[1], "-DHNSW_V_FULL=%d" % v[2]]) for v in VARIANTS]
+    jobs = max(1, int(os.environ.get("HNSW_BUILD_JOBS", os.cpu_count() or 4)))
+    pending = list(units)
+    running, objs, logs = [], [], []
+    while pending or running:   # one hipcc per translation unit, at most `jobs` at a time
+        while pending and len(running) < jobs:
+            name, src, defs = pending.pop(0)
+            obj = os.path.join(objdir, name + ".o")
+            cmd = base + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            log = open(resource_log + "." + name, "w") if resource_log else None
+            if log:
+                logs.append(resource_log + "." + name)
+            running.append((subprocess.Popen(cmd, stderr=log), obj, cmd, log))
+        pr, obj, cmd, log = running.pop(0)
         rc = pr.wait()
         if log:
             log.close()
         if rc != 0:
+            for other in running:
+                other[0].kill()
             raise subprocess.CalledProcessError(rc, cmd)
         objs.append(obj)
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_out]
@@ -68,8 +81,9 @@ def build(force=False, verbose=False, resource_log=None):
     subprocess.check_call(link)
     if resource_log:
         with open(resource_log, "w") as f:
-            for s_ in SOURCES:
-                f.write(open(resource_log + "." + s_).read())
+            for part in logs:
+                f.write(open(part).read())
+                os.remove(part)
     return lib_out
 
 

@@ -170,7 +170,7 @@ int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_strid
     bv.iv = idx->iv; bv.nbr0_w = (int32_t *)idx->dNbr0; bv.nbrU_w = (int32_t *)idx->dNbrU;
     bv.efc = efc; bv.cand_stride = cand_stride;
     bv.vt_bits = efc <= 256 ? 11 : 12;
-    while (bv.vt_bits < 16 && ((int64_t)1 << (bv.vt_bits + 15)) < n) ++bv.vt_bits;
+    while (bv.vt_bits < 16 && ((int64_t)0xFFFF << (bv.vt_bits - 1)) < n) ++bv.vt_bits;   // tags identify ids exactly, 0xFFFF = empty way
 
     HIP_TRY_B(hipStreamCreate(&st));
     HIP_TRY_B(hipMalloc(&dNodes, (size_t)bmax * 4));

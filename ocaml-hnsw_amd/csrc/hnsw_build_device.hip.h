@@ -77,7 +77,7 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
     WList<NSLOT> w;
     wlist_init(w, bv.efc, lane);
     wlist_insert(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);                         // :802
-    { uint32_t hw; const uint32_t hc = vt_hash(cx, (uint32_t)cur); (void)visited_mem(cx, hc, hw); visited_add_masked(cx, hc, hw, lane == 0); }
+    { uint32_t hw; (void)visited_mem(cx, (uint32_t)cur, hw); visited_add_masked(cx, (uint32_t)cur, hw, lane == 0); }
     __syncthreads();
 
     for (int layer = (lvl < top ? lvl : top); layer >= 0; --layer) {                         // :806
@@ -86,8 +86,8 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
         // on an upper layer is either in W or rejected for good (max(W) never grows).
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s)
-            if ((uint32_t)(w.key[s] >> 32) < DUMMY_HI && w.key[s] != KEY64_PAD) w.key[s] &= ~1ull;
-        if (wlist_full(w)) w.wmax64 &= ~1ull;
+            if (w.hi[s] < DUMMY_HI && w.lo[s] != PAD_LO) w.lo[s] &= ~1u;
+        if (wlist_full(w)) w.wmax_lo &= ~1u;
         w.ovf_cnt = 0;
         search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, layer, w, bv.efc, cx, n_dist, n_hops, status); // :811
         const int rec = bt.rec_of[(int64_t)i * bt.lcap + layer];
@@ -96,9 +96,9 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 const int idx = s * 64 + lane - wbase;
-                const uint32_t hi = (uint32_t)(w.key[s] >> 32);
+                const uint32_t hi = w.hi[s];
                 if (idx >= 0 && hi < DUMMY_HI) {
-                    bt.cand_id[(int64_t)rec * bv.cand_stride + idx] = (int32_t)key_id(w.key[s]);
+                    bt.cand_id[(int64_t)rec * bv.cand_stride + idx] = (int32_t)key_id(w.lo[s]);
                     bt.cand_key[(int64_t)rec * bv.cand_stride + idx] = hi;
                 }
             }
@@ -151,7 +151,7 @@ __device__ __forceinline__ int select_heuristic(const IndexView &iv, const int32
             }
             acc = reduce16(acc);
             const uint32_t key_cs = dist_to_key<METRIC>(acc);
-            reject = __ballot(valid && !(ckey < key_cs)) != 0ull;      // :657-659, strict
+            reject = ballot(valid && !(ckey < key_cs)) != 0ull;      // :657-659, strict
         }
         if (!reject) {
             __syncthreads();
@@ -231,8 +231,8 @@ build_merge_kernel(const BuildView bv, const MergeArgs ma) {
     {
         const int j = e + lane;
         const bool mine = j < ma.n_edges && (int)(ma.edges[j] >> 32) == nb && ma.edges[j] != ~0ull;
-        const uint64_t m = __ballot(mine);
-        np = __popcll(m);                                               // contiguous from lane 0
+        const uint64_t m = ballot(mine);
+        np = popc(m);                                               // contiguous from lane 0
         if (mine) u_id[lane] = (int)(ma.edges[j] & 0xFFFFFFFFu);
         for (int j2 = e + 64; j2 < ma.n_edges; ++j2) {                   // rare: hub with > 64 new links
             const uint64_t k2 = ma.edges[j2];
@@ -247,9 +247,9 @@ build_merge_kernel(const BuildView bv, const MergeArgs ma) {
     int32_t *row = row_ptr_w(bv, ma.layer, nb, width);
     const int old = lane < width ? row[lane] : -1;
     const bool ovalid = old >= 0;
-    const uint64_t om = __ballot(ovalid);
-    const int no = __popcll(om);
-    const int opos = __popcll(om & ((1ull << lane) - 1ull));
+    const uint64_t om = ballot(ovalid);
+    const int no = popc(om);
+    const int opos = popc(om & ((1ull << lane) - 1ull));
     __syncthreads();
     if (ovalid) u_id[np + opos] = old;
     __syncthreads();
@@ -392,9 +392,9 @@ __global__ void __launch_bounds__(256) build_compact_kernel(int32_t *rows, int64
     if (rrow >= nrows) return;
     int32_t *row = rows + rrow * width;
     const int v = lane < width ? row[lane] : -1;
-    const uint64_t m = __ballot(v >= 0);
-    const int pos = __popcll(m & ((1ull << lane) - 1ull));
-    const int cnt = __popcll(m);
+    const uint64_t m = ballot(v >= 0);
+    const int pos = popc(m & ((1ull << lane) - 1ull));
+    const int cnt = popc(m);
     if (v >= 0) tmp[wv][pos] = v;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

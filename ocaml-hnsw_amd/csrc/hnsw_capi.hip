@@ -50,38 +50,28 @@ int upload_vectors(const float *vectors, int64_t n, int d, int64_t row_stride, v
 } // namespace hnsw_host
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
+// the knn kernel's variants live in hnsw_search_variants.hip, one object per (metric, accept rule, row shape)
+#define HNSW_DECL_VARIANT(m, s, f)                                                                          \
+    namespace hnsw_host {                                                                                    \
+    hipError_t search_launch_##m##_##s##_##f(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st); \
+    int search_occupancy_##m##_##s##_##f(int nch, int nslot, size_t lds);                                    \
+    }
+HNSW_DECL_VARIANT(0, 0, 0) HNSW_DECL_VARIANT(0, 0, 1) HNSW_DECL_VARIANT(0, 1, 0) HNSW_DECL_VARIANT(0, 1, 1)
+HNSW_DECL_VARIANT(1, 0, 0) HNSW_DECL_VARIANT(1, 0, 1) HNSW_DECL_VARIANT(1, 1, 0) HNSW_DECL_VARIANT(1, 1, 1)
+#undef HNSW_DECL_VARIANT
+
 namespace {
 
-template <int NCH, int RB, int NSLOT, int METRIC>
-hipError_t launch_search(const IndexView &iv, const SearchArgs &a, hipStream_t st) {
-    const size_t lds = hnsw_dev::wave_lds_words(a.vt_bits) * sizeof(uint32_t);
-    hipLaunchKernelGGL((hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, METRIC>), dim3((unsigned)a.nq),
-                       dim3(64), lds, st, iv, a);
-    return hipGetLastError();
-}
+typedef hipError_t (*search_launch_fn)(int, int, const IndexView &, const SearchArgs &, hipStream_t);
+typedef int (*search_occupancy_fn)(int, int, size_t);
+const search_launch_fn k_launch[2][2][2] = {
+    {{search_launch_0_0_0, search_launch_0_0_1}, {search_launch_0_1_0, search_launch_0_1_1}},
+    {{search_launch_1_0_0, search_launch_1_0_1}, {search_launch_1_1_0, search_launch_1_1_1}}};
+const search_occupancy_fn k_occupancy[2][2][2] = {
+    {{search_occupancy_0_0_0, search_occupancy_0_0_1}, {search_occupancy_0_1_0, search_occupancy_0_1_1}},
+    {{search_occupancy_1_0_0, search_occupancy_1_0_1}, {search_occupancy_1_1_0, search_occupancy_1_1_1}}};
 
-template <int NCH, int RB, int METRIC>
-hipError_t dispatch_slot(int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st) {
-    switch (nslot) {
-    case 1: return launch_search<NCH, RB, 1, METRIC>(iv, a, st);
-    case 2: return launch_search<NCH, RB, 2, METRIC>(iv, a, st);
-    case 4: return launch_search<NCH, RB, 4, METRIC>(iv, a, st);
-    case 8: return launch_search<NCH, RB, 8, METRIC>(iv, a, st);
-    default: return launch_search<NCH, RB, 16, METRIC>(iv, a, st);
-    }
-}
-
-template <int METRIC>
-hipError_t dispatch_nch(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st) {
-    switch (nch) {
-    case 1: return dispatch_slot<1, 8, METRIC>(nslot, iv, a, st);
-    case 2: return dispatch_slot<2, HNSW_RB_NCH2, METRIC>(nslot, iv, a, st);
-    case 4: return dispatch_slot<4, 2, METRIC>(nslot, iv, a, st);
-    case 8: return dispatch_slot<8, 1, METRIC>(nslot, iv, a, st);
-    default: return dispatch_slot<16, 1, METRIC>(nslot, iv, a, st);
-    }
-}
-
+inline int variant_full(const hnsw_index *idx) { return idx->iv.nchunks == 16 * pick_nch(idx->iv.nchunks) ? 1 : 0; }
 
 template <int METRIC>
 hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq,
@@ -99,39 +89,16 @@ hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t q
 }
 
 // how many one-wave workgroups of the search kernel for this ef are resident on the device at once
-template <int NCH, int RB, int NSLOT>
-int occupancy_of(size_t lds) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, 0>, 64, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
-    return nb;
-}
-template <int NCH, int RB>
-int occupancy_slot(int nslot, size_t lds) {
-    switch (nslot) {
-    case 1: return occupancy_of<NCH, RB, 1>(lds);
-    case 2: return occupancy_of<NCH, RB, 2>(lds);
-    case 4: return occupancy_of<NCH, RB, 4>(lds);
-    case 8: return occupancy_of<NCH, RB, 8>(lds);
-    default: return occupancy_of<NCH, RB, 16>(lds);
-    }
-}
-int64_t resident_queries(hnsw_index *idx, int ef) {
+int64_t resident_queries(hnsw_index *idx, int ef, int semf) {
     // cached in the handle; the answer depends on the kernel variant's registers and LDS
     const int nslot = pick_nslot(ef), nch = pick_nch(idx->iv.nchunks);
     const size_t lds = hnsw_dev::wave_lds_words(search_vt_bits(idx, ef)) * sizeof(uint32_t);
-    if (idx->resident_queries && idx->resident_nslot == nslot && idx->resident_lds == lds) return idx->resident_queries;
-    int per_cu = 0;
-    switch (nch) {
-    case 1: per_cu = occupancy_slot<1, 8>(nslot, lds); break;
-    case 2: per_cu = occupancy_slot<2, HNSW_RB_NCH2>(nslot, lds); break;
-    case 4: per_cu = occupancy_slot<4, 2>(nslot, lds); break;
-    case 8: per_cu = occupancy_slot<8, 1>(nslot, lds); break;
-    default: per_cu = occupancy_slot<16, 1>(nslot, lds); break;
-    }
+    if (idx->resident_queries && idx->resident_nslot == nslot * 2 + semf && idx->resident_lds == lds) return idx->resident_queries;
+    const int per_cu = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)](nch, nslot, lds);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, idx->device) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
     const int64_t v = (per_cu > 0 && cus > 0) ? (int64_t)per_cu * cus : (int64_t)1 << 40;   // unknown: never reorder
-    idx->resident_queries = v; idx->resident_nslot = nslot; idx->resident_lds = lds;
+    idx->resident_queries = v; idx->resident_nslot = nslot * 2 + semf; idx->resident_lds = lds;
     return v;
 }
 
@@ -307,8 +274,7 @@ int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) 
 namespace {
 int launch_search_args(hnsw_index *idx, SearchArgs &a, hipStream_t st) {
     const int nch = pick_nch(idx->iv.nchunks), nslot = pick_nslot(a.ef);
-    hipError_t e = idx->info.metric == HNSW_METRIC_L2 ? dispatch_nch<0>(nch, nslot, idx->iv, a, st)
-                                                      : dispatch_nch<1>(nch, nslot, idx->iv, a, st);
+    hipError_t e = k_launch[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][a.sem ? 1 : 0][variant_full(idx)](nch, nslot, idx->iv, a, st);
     if (e != hipSuccess) return fail(HNSW_ERR_HIP, "search kernel launch failed: %s", hipGetErrorString(e));
     return HNSW_OK;
 }
@@ -343,7 +309,7 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
         HIP_TRY(hipEventRecord(ev[0], (hipStream_t)stream));
     }
     const int mode = idx->order_mode >= 0 ? idx->order_mode : env_int("HNSW_ORDER_QUERIES", -1);
-    if (mode != 0 && (mode == 1 || nq > resident_queries(idx, params->ef))) {
+    if (mode != 0 && (mode == 1 || nq > resident_queries(idx, params->ef, params->semantics ? 1 : 0))) {
         rc = order_longest_first(idx, d_queries, nq, q_stride, (hipStream_t)stream, &block, &a.qmap, &a.pre_entry, &a.pre_key, &a.pre_nd, &a.pre_layer);
         if (rc) return rc;
         a.q_limit = nq;

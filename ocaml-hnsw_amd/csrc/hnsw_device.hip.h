@@ -122,6 +122,12 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// v_writelane_b32: lane `lane` of v <- val (both wave-uniform).  This clang has no builtin for it; the
+// LLVM intrinsic is reached through its name, so the compiler still sees it (hazards, scheduling).
+extern "C" __device__ int hnsw_llvm_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t wrlane(uint32_t v, uint32_t val, int lane) {
+    return (uint32_t)hnsw_llvm_writelane((int)val, lane, (int)v);
+}
 
 // ---- row evaluation ------------------------------------------------------------------------
 // Distances of the cnt candidates listed in LDS cand_id[] to the query held in qv; the ordered
@@ -207,33 +213,36 @@ __device__ __forceinline__ void eval_candidates(const IndexView &iv, const float
 }
 
 // ---- W: sorted register-resident list ------------------------------------------------------
-// 64-bit keys: (ordered distance bits << 32) | (id + 1) << 1 | expanded, ascending, slot-major across the
-// wave (position j = slot j / 64, lane j % 64).  W always holds exactly ef entries in the TOP ef
-// positions of its NSLOT*64-position capacity: before ef real nodes have been found the upper ones
-// are +inf dummies (flagged expanded), so "|W| < ef or d < max(W).d" (lib/ohnsw.ml:574) is the
-// single test d < max(W).d, the maximum always sits in the last lane of the last slot, and an
-// insertion is always "shift right from the rank position, the old maximum falls off".
-// Positions below the window hold key 1 (smaller than every real key, flagged expanded).
+// Keys are (hi, lo) = (ordered distance bits, (id + 1) << 1 | expanded), compared as one 64-bit number,
+// ascending, slot-major across the wave (position j = slot j / 64, lane j % 64).  The halves live in
+// separate 32-bit registers: every update (DPP shift, v_writelane, flag bit) is a native 32-bit
+// operation on one half, and the rank of a new key needs the low halves only on an exact distance tie.
+// W always holds exactly ef entries in the TOP ef positions of its NSLOT*64-position capacity: before ef
+// real nodes have been found the upper ones are +inf dummies (flagged expanded), so "|W| < ef or
+// d < max(W).d" (lib/ohnsw.ml:574) is the single test d < max(W).d, the maximum always sits in the last
+// lane of the last slot, and an insertion is always "shift right from the rank position, the old maximum
+// falls off".  Positions below the window hold the pad key (0, 1): smaller than every real key (the id
+// field stores id + 1, so a real low half is >= 2), flagged expanded.
 constexpr uint32_t DUMMY_HI = 0xFFFFFFFEu;
-constexpr uint64_t KEY64_DUMMY = ((uint64_t)DUMMY_HI << 32) | 0xFFFFFFFFull;
-constexpr uint64_t KEY64_PAD = 1ull;
-constexpr uint64_t KEY64_INF = ~0ull;
-// the id field stores id + 1, so every real key is >= 2 > KEY64_PAD even at distance 0, node 0
-__device__ __forceinline__ uint32_t key_id(uint64_t k) { return ((uint32_t)k >> 1) - 1u; }
+constexpr uint32_t DUMMY_LO = 0xFFFFFFFFu;
+constexpr uint32_t PAD_HI = 0u, PAD_LO = 1u;
+__device__ __forceinline__ uint32_t key_id(uint32_t lo) { return (lo >> 1) - 1u; }
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int popc(uint64_t m) { return __builtin_popcountll(m); }
 
 template <int NSLOT> struct WList {
-    uint64_t key[NSLOT];
-    uint64_t slotmax;     // NSLOT > 2 only: lane s holds key[s] of lane 63 (the slot's maximum)
-    uint64_t wmax64;      // key of the top entry = max(W); flag bit kept in sync
-    uint32_t wmax;        // its distance part: the accept threshold (DUMMY_HI while |W| < ef)
-    // entries evicted while tied with max(W) and not yet expanded (still poppable, lib/ohnsw.ml:568)
+    uint32_t hi[NSLOT], lo[NSLOT];
+    uint32_t smax_hi, smax_lo;   // NSLOT > 2 only: lane s holds the key of slot s, lane 63 (the slot's maximum)
+    uint32_t wmax;               // distance part of the top entry = max(W): the accept threshold (DUMMY_HI while |W| < ef)
+    uint32_t wmax_lo;            // its low half; flag bit kept in sync
+    // entries of C that are not in W (see below).  Invariant: ovf_cnt > 0 only while every listed node is
+    // at distance max(W).d (wlist_insert, the only place max(W) changes, empties the list when it drops)
     int ovf_cnt;
-    uint32_t ovf_key;
 };
 
 constexpr int OVF_CAP = 64; // LDS entries
-// the stack of tied evicted entries: OVF_CAP in LDS, then an optional global slab (the exact
-// fallback the host entry point uses for the rare queries that need more)
+// OVF_CAP entries in LDS, then an optional global slab (the exact fallback the host entry point uses
+// for the rare queries that need more)
 struct OvfStore {
     uint32_t *lds;
     uint32_t *g;
@@ -249,86 +258,143 @@ __device__ __forceinline__ uint32_t ovf_get(const OvfStore &ov, int at) {
     return ov.g ? ov.g[at - OVF_CAP] : 0u;
 }
 
-__device__ __forceinline__ uint64_t rdlane64(uint64_t v, int lane) {
-    const uint32_t lo = rdlane((uint32_t)v, lane), hi = rdlane((uint32_t)(v >> 32), lane);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v, uint64_t carry) {
-    const uint32_t lo = wave_shr1((uint32_t)v, (uint32_t)carry);
-    const uint32_t hi = wave_shr1((uint32_t)(v >> 32), (uint32_t)(carry >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
 template <int NSLOT>
 __device__ __forceinline__ void wlist_init(WList<NSLOT> &w, int ef, int lane) {
     const int base = NSLOT * 64 - ef;
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) w.key[s] = (s * 64 + lane) < base ? KEY64_PAD : KEY64_DUMMY;
-    w.slotmax = (lane < NSLOT && (lane + 1) * 64 > base) ? KEY64_DUMMY : (lane < NSLOT ? KEY64_PAD : KEY64_INF);
-    w.wmax64 = KEY64_DUMMY; w.wmax = DUMMY_HI; w.ovf_cnt = 0; w.ovf_key = 0;
+    for (int s = 0; s < NSLOT; ++s) {
+        const bool pad = (s * 64 + lane) < base;
+        w.hi[s] = pad ? PAD_HI : DUMMY_HI;
+        w.lo[s] = pad ? PAD_LO : DUMMY_LO;
+    }
+    // lanes >= NSLOT of the slot maxima hold +inf (never "below K")
+    const bool sm_pad = lane < NSLOT && (lane + 1) * 64 <= base;
+    w.smax_hi = sm_pad ? PAD_HI : (lane < NSLOT ? DUMMY_HI : 0xFFFFFFFFu);
+    w.smax_lo = sm_pad ? PAD_LO : 0xFFFFFFFFu;
+    w.wmax = DUMMY_HI; w.wmax_lo = DUMMY_LO; w.ovf_cnt = 0;
 }
 template <int NSLOT> __device__ __forceinline__ bool wlist_full(const WList<NSLOT> &w) { return w.wmax != DUMMY_HI; }
 // number of real entries
 template <int NSLOT> __device__ __forceinline__ int wlist_count(const WList<NSLOT> &w) {
     int c = 0;
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        const uint32_t hi = (uint32_t)(w.key[s] >> 32);
-        c += __popcll(__ballot(w.key[s] != KEY64_PAD && hi < DUMMY_HI));
-    }
+    for (int s = 0; s < NSLOT; ++s) c += popc(ballot(w.lo[s] != PAD_LO && w.hi[s] < DUMMY_HI));
     return c;
+}
+
+// ---- entries of C that are not in W ---------------------------------------------------------------
+// SEM 0 (Ohnsw): entries evicted from W while tied with the new max(W) and not yet expanded; they are
+// still in the reference's candidate queue and "c.d > max(W).d" (lib/ohnsw.ml:568) is false for them.
+// Evictions come in descending key order, so last-in-first-out IS the canonical (d, id) pop order.
+// SEM 1/2 (functor): additionally every neighbour evaluated while tied with max(W): Nearest.insert_distance
+// answers Inserted without changing W (lib/hnsw.ml:501-504 with the merge of lib/hnsw_algo.ml:25-31), so
+// the node enters VisitMe (lib/hnsw_algo.ml:360-364) and is expanded later although it never sat in W.
+// Here the list is a SET (it doubles as the exact visited check for those nodes -- the LDS visited cache
+// may forget them): entry = id | expanded << 31; evicted entries are kept whether expanded or not.
+// In both modes the list only lives while max(W).d stays what it was when the entries were listed:
+// max(W).d never grows, so once it drops every listed node is farther than max(W) for good.
+__device__ __forceinline__ bool tie_contains(const OvfStore &ov, int cnt, uint32_t id, int lane) {
+    for (int base = 0; base < cnt; base += 64) {
+        const int at = base + lane;
+        const uint32_t e = at < cnt ? ovf_get(ov, at) : 0xFFFFFFFFu;
+        if (ballot((e & 0x7FFFFFFFu) == id)) return true;
+    }
+    return false;
+}
+template <int NSLOT>
+__device__ __forceinline__ void tie_add(WList<NSLOT> &w, const OvfStore &ov, uint32_t entry, int lane, uint32_t &status) {
+    if (ovf_push(ov, w.ovf_cnt, entry, lane)) w.ovf_cnt++;
+    else status |= 1u;
+}
+// SEM 1: the unexpanded entry with the smallest id (canonical (d, id) order of VisitMe among equal
+// distances): returns its id and list position, or -1
+__device__ __forceinline__ int tie_min_unexpanded(const OvfStore &ov, int cnt, int lane, int &pos) {
+    uint32_t best = 0xFFFFFFFFu; int bpos = -1;
+    for (int base = 0; base < cnt; base += 64) {
+        const int at = base + lane;
+        const uint32_t e = at < cnt ? ovf_get(ov, at) : 0xFFFFFFFFu;     // expanded entries have bit 31 set: never the minimum
+        const uint32_t m = wave_min_u32(e);
+        if (m < best && m < 0x80000000u) { best = m; bpos = base + __builtin_ctzll(ballot(e == m)); }
+    }
+    pos = bpos;
+    return bpos >= 0 ? (int)best : -1;
+}
+__device__ __forceinline__ void tie_mark_expanded(const OvfStore &ov, int pos, int lane) {
+    if (lane == 0) {
+        if (pos < OVF_CAP) ov.lds[pos] |= 0x80000000u;
+        else ov.g[pos - OVF_CAP] |= 0x80000000u;
+    }
 }
 
 // Insert (kd, kid) -- both wave-uniform, kd < w.wmax.  Mirrors lib/ohnsw.ml:575-577: push W, pop
 // the farthest.  Duplicates (same id already in W: a re-evaluated node) are ignored.
-template <int NSLOT>
+// Rank = number of keys below (kd, klo): one "hi < kd" ballot per slot; only when some member of W has
+// exactly the distance kd (one more ballot says so) are the low halves compared -- that is also the only
+// case in which the node itself can already be in W.  The shift is a DPP wave_shr:1 per half and slot,
+// the new key then lands in its lane with v_writelane (no per-lane equality selects).
+template <int NSLOT, int SEM = 0>
 __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint32_t kid, int lane,
                                              const OvfStore &ov, uint32_t &status) {
-    const uint64_t K = ((uint64_t)kd << 32) | ((uint64_t)(kid + 1u) << 1);
-    const uint64_t K2 = K + 2;
-    int p = 0, q = 0, first = 0;
+    const uint32_t klo = (kid + 1u) << 1;
+    int p = 0, first = 0;
     if (NSLOT <= 2) {
+        uint64_t eq[NSLOT];
+        bool tie = false;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            p += __popcll(__ballot(w.key[s] < K));
-            q += __popcll(__ballot(w.key[s] < K2));   // counts K and K|1 too
+            p += popc(ballot(w.hi[s] < kd));
+            eq[s] = ballot(w.hi[s] == kd);
+            tie = tie || eq[s] != 0ull;
+        }
+        if (tie) {
+            int q = p;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                p += popc(eq[s] & ballot(w.lo[s] < klo));
+                q += popc(eq[s] & ballot(w.lo[s] < klo + 2u));   // counts the node itself, expanded or not
+            }
+            if (p != q) return;                   // already in W
         }
     } else {
         // the slot holding the rank position: the first whose maximum is not below K
-        first = __popcll(__ballot(w.slotmax < K));   // lanes >= NSLOT hold ~0
+        first = popc(ballot(w.smax_hi < kd || (w.smax_hi == kd && w.smax_lo < klo)));   // lanes >= NSLOT hold +inf
+        int q = 0;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             if (s == first) {
-                p = s * 64 + __popcll(__ballot(w.key[s] < K));
-                q = s * 64 + __popcll(__ballot(w.key[s] < K2));
+                const uint64_t eq = ballot(w.hi[s] == kd);
+                p = s * 64 + popc(ballot(w.hi[s] < kd));
+                q = p + popc(eq & ballot(w.lo[s] < klo + 2u));
+                p += popc(eq & ballot(w.lo[s] < klo));
             }
         }
+        if (p != q) return;                       // already in W
     }
-    if (p != q) return;                           // already in W
-    const uint64_t ev = w.wmax64;                 // the entry that falls off
+    const uint32_t ev_hi = w.wmax, ev_lo = w.wmax_lo;   // the entry that falls off
 #pragma unroll
     for (int s = NSLOT - 1; s >= 0; --s) {
-        if (NSLOT > 2 && s < first) continue;     // slots wholly below the rank stay (uniform)
-        if (NSLOT == 2 && s == 0 && p >= 64) continue;
-        uint64_t carry = 0;
-        if (s > 0) carry = rdlane64(w.key[s - 1], 63);
-        const uint64_t sh = wave_shr1_64(w.key[s], carry);
-        const int idx = s * 64 + lane;
-        w.key[s] = idx < p ? w.key[s] : (idx == p ? K : sh);
+        if (s * 64 + 63 < p) continue;            // slots wholly below the rank stay (uniform)
+        uint32_t sh_hi, sh_lo;
+        if (s > 0) { sh_hi = wave_shr1(w.hi[s], rdlane(w.hi[s - 1], 63)); sh_lo = wave_shr1(w.lo[s], rdlane(w.lo[s - 1], 63)); }
+        else { sh_hi = wave_shr1(w.hi[s], 0); sh_lo = wave_shr1(w.lo[s], 0); }
+        const bool mv = (s * 64 + lane) >= p;     // lane p takes its left neighbour's key here, K below
+        w.hi[s] = mv ? sh_hi : w.hi[s];
+        w.lo[s] = mv ? sh_lo : w.lo[s];
+        if (s * 64 <= p) { w.hi[s] = wrlane(w.hi[s], kd, p - s * 64); w.lo[s] = wrlane(w.lo[s], klo, p - s * 64); }
         if (NSLOT > 2) {
-            const uint64_t mx = rdlane64(w.key[s], 63);
-            w.slotmax = (lane == s) ? mx : w.slotmax;
+            const uint32_t mh = rdlane(w.hi[s], 63), ml = rdlane(w.lo[s], 63);
+            w.smax_hi = (lane == s) ? mh : w.smax_hi;
+            w.smax_lo = (lane == s) ? ml : w.smax_lo;
         }
     }
-    w.wmax64 = rdlane64(w.key[NSLOT - 1], 63);
-    w.wmax = (uint32_t)(w.wmax64 >> 32);
-    if ((uint32_t)(ev >> 32) != w.wmax) {
-        w.ovf_cnt = 0;                            // max(W).d dropped: every stacked entry is dead
-    } else if (!(ev & 1ull)) {                    // rare: evicted while tied with the new max(W), unexpanded
-        if (w.ovf_cnt > 0 && w.ovf_key != w.wmax) w.ovf_cnt = 0;
-        if (ovf_push(ov, w.ovf_cnt, key_id(ev), lane)) w.ovf_cnt++;
-        else status |= 1u;
-        w.ovf_key = w.wmax;
+    w.wmax = rdlane(w.hi[NSLOT - 1], 63);
+    w.wmax_lo = rdlane(w.lo[NSLOT - 1], 63);
+    if (ev_hi != w.wmax) {
+        w.ovf_cnt = 0;                            // max(W).d dropped: every listed entry is dead
+    } else if (SEM != 0) {                        // evicted while tied with the new max(W): stays in C, and visited
+        tie_add(w, ov, key_id(ev_lo) | ((ev_lo & 1u) << 31), lane, status);
+    } else if (!(ev_lo & 1u)) {                   // rare: evicted while tied with the new max(W), unexpanded
+        tie_add(w, ov, key_id(ev_lo), lane, status);
     }
 }
 
@@ -336,77 +402,65 @@ __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint3
 template <int NSLOT>
 __device__ __forceinline__ void wlist_unexpanded_masks(const WList<NSLOT> &w, uint64_t (&m)[NSLOT]) {
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) m[s] = __ballot(((uint32_t)w.key[s] & 1u) == 0u);
+    for (int s = 0; s < NSLOT; ++s) m[s] = ballot((w.lo[s] & 1u) == 0u);
 }
 // First set position over the slot masks: returns the node id there (or -1) and clears that bit.
+// A chain of wave-uniform branches, one per slot (template recursion keeps every slot index a constant, so
+// the masks and keys stay in registers): the taken path is a count-trailing-zeros, one v_readlane and a
+// few scalar operations.
+template <int NSLOT, int S> struct WFirst {
+    static __device__ __forceinline__ int run(const WList<NSLOT> &w, uint64_t (&m)[NSLOT], int &index) {
+        if (m[S] != 0ull) {
+            const int L = __builtin_ctzll(m[S]);
+            m[S] &= m[S] - 1;
+            index = S * 64 + L;
+            return (int)key_id(rdlane(w.lo[S], L));
+        }
+        return WFirst<NSLOT, S + 1>::run(w, m, index);
+    }
+};
+template <int NSLOT> struct WFirst<NSLOT, NSLOT> {
+    static __device__ __forceinline__ int run(const WList<NSLOT> &, uint64_t (&)[NSLOT], int &index) { index = -1; return -1; }
+};
 template <int NSLOT>
 __device__ __forceinline__ int wlist_take_first(const WList<NSLOT> &w, uint64_t (&m)[NSLOT], int &index) {
-    if (NSLOT == 1) {
-        const uint64_t m0 = m[0];
-        const int L = __builtin_ctzll(m0 | (1ull << 63));
-        const int v = (int)(rdlane((uint32_t)w.key[0], L) >> 1) - 1;
-        m[0] = m0 & (m0 - 1);
-        index = m0 ? L : -1;
-        return m0 ? v : -1;
-    }
-    if (NSLOT == 2) {   // straight-line: two readlanes, scalar selects
-        const uint64_t m0 = m[0], m1 = m[1];
-        const bool in0 = m0 != 0ull;
-        const uint64_t mm = in0 ? m0 : m1;
-        const int L = __builtin_ctzll(mm | (1ull << 63));
-        const uint32_t v0 = rdlane((uint32_t)w.key[0], L), v1 = rdlane((uint32_t)w.key[NSLOT - 1], L);
-        const int v = (int)((in0 ? v0 : v1) >> 1) - 1;
-        m[0] = in0 ? (m0 & (m0 - 1)) : m0;
-        m[NSLOT - 1] = in0 ? m1 : (m1 & (m1 - 1));
-        index = mm ? (in0 ? L : 64 + L) : -1;
-        return mm ? v : -1;
-    }
-    int c = -1;
-    index = -1;
-    bool found = false;
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        const bool here = !found && (m[s] != 0ull);
-        const int L = __builtin_ctzll(m[s] | (1ull << 63));
-        const int v = (int)(rdlane((uint32_t)w.key[s], L) >> 1) - 1;
-        c = here ? v : c;
-        index = here ? s * 64 + L : index;
-        m[s] = here ? (m[s] & (m[s] - 1)) : m[s];
-        found = found || here;
-    }
-    return c;
+    return WFirst<NSLOT, 0>::run(w, m, index);
 }
-// mark entry `index` expanded
+// mark entry `index` expanded (pop_min, lib/ohnsw.ml:565); index -1 marks nothing.  Branch-free on
+// purpose: a compare and an OR per slot keep the key registers out of control-flow merges.
 template <int NSLOT>
 __device__ __forceinline__ void wlist_mark_expanded(WList<NSLOT> &w, int index, int lane) {
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) w.key[s] |= (uint64_t)((s * 64 + lane) == index);
-    if (index == NSLOT * 64 - 1) w.wmax64 |= 1ull;
+    for (int s = 0; s < NSLOT; ++s) w.lo[s] |= (uint32_t)((s * 64 + lane) == index);
+    w.wmax_lo |= (uint32_t)(index == NSLOT * 64 - 1);
 }
 
 // ---- per-wave scratch in LDS -------------------------------------------------------------------
 // Visited cache: 2^(vt_bits-1) sets of two 16-bit tags (one 32-bit word per set, newest tag in the
-// low half).  h = (id * odd) mod 2^(vt_bits+15) is a bijection on ids below 2^(vt_bits+15);
-// set = h >> 16, tag = h & 0xFFFF, so (set, tag) identifies the id exactly: a hit is never a false
-// positive.  Tag 0xFFFF marks an empty way; ids that hash to it are simply never cached (a false
-// negative, which is harmless -- see the header comment).
+// low half).  set = id mod #sets, tag = id div #sets: (set, tag) identifies the id exactly, so a hit
+// is never a false positive (node ids are insertion order, i.e. unrelated to the geometry: the low
+// bits spread as well as a hash would, and no multiply sits in front of the LDS read).  The host
+// sizes the cache so that (n-1) div #sets < 0xFFFF: the value 0xFFFF marks an empty way and never
+// equals a real tag.  A miss for a node already evaluated is harmless -- see the header comment.
 struct WaveCtx {
     int lane, r, l16;
     uint32_t *vt;        // visited cache, 1 << (vt_bits - 1) words
-    uint32_t vt_mask;    // 2^(vt_bits+15) - 1
+    uint32_t set_mask;   // #sets - 1
+    int set_bits;        // vt_bits - 1
     int vt_words;
     int32_t *cand_id;    // [64]
     uint32_t *cand_key;  // [64]
     uint32_t *trash;     // [64] write-only sink shared by every masked-off store
     OvfStore ovf;        // lds: [OVF_CAP]
 };
-// 4 KiB of tags at vt_bits = 11 plus 1 KiB: 32 waves per CU fit the 160 KiB LDS
+// 4 KiB of tags at vt_bits = 11 plus 1 KiB: 28 waves per CU fit the 160 KiB LDS
 __host__ __device__ inline size_t wave_lds_words(int vt_bits) { return (((size_t)1 << vt_bits) >> 1) + 192 + OVF_CAP; }
 __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane) {
     WaveCtx cx;
     cx.lane = lane; cx.r = lane >> 4; cx.l16 = lane & 15;
     cx.vt = lds;
-    cx.vt_mask = (vt_bits + 15 >= 32) ? 0xFFFFFFFFu : ((1u << (vt_bits + 15)) - 1u);
+    cx.set_bits = vt_bits - 1;
+    cx.set_mask = (1u << (vt_bits - 1)) - 1u;
     cx.vt_words = 1 << (vt_bits - 1);
     uint32_t *rest = lds + cx.vt_words;
     cx.cand_id = reinterpret_cast<int32_t *>(rest);
@@ -418,20 +472,17 @@ __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane
 __device__ __forceinline__ void visited_clear(const WaveCtx &cx) { // Visited.clear, lib/ohnsw.ml:262
     for (int i = cx.lane; i < cx.vt_words; i += 64) cx.vt[i] = 0xFFFFFFFFu;
 }
-__device__ __forceinline__ uint32_t vt_hash(const WaveCtx &cx, uint32_t id) { return (id * 0x9E3779B1u) & cx.vt_mask; }
 // Visited.mem (lib/ohnsw.ml:259); `word` returns the set's current content for the add that follows
-__device__ __forceinline__ bool visited_mem(const WaveCtx &cx, uint32_t h, uint32_t &word) {
-    word = cx.vt[h >> 16];
-    const uint32_t tag = h & 0xFFFFu;
-    return ((word & 0xFFFFu) == tag || (word >> 16) == tag) && tag != 0xFFFFu;
+__device__ __forceinline__ bool visited_mem(const WaveCtx &cx, uint32_t id, uint32_t &word) {
+    word = cx.vt[id & cx.set_mask];
+    const uint32_t tag = id >> cx.set_bits;
+    return (word & 0xFFFFu) == tag || (word >> 16) == tag;
 }
 // Visited.add (lib/ohnsw.ml:260) for all lanes at once: the new tag enters way 0, way 0 moves to
 // way 1; lanes with on == false store to the scratch sink (no branch)
-__device__ __forceinline__ void visited_add_masked(const WaveCtx &cx, uint32_t h, uint32_t word, bool on) {
-    const uint32_t tag = h & 0xFFFFu;
-    const bool wr = on && tag != 0xFFFFu;
-    uint32_t *slot = wr ? &cx.vt[h >> 16] : &cx.trash[cx.lane];
-    *slot = (word << 16) | tag;
+__device__ __forceinline__ void visited_add_masked(const WaveCtx &cx, uint32_t id, uint32_t word, bool on) {
+    uint32_t *slot = on ? &cx.vt[id & cx.set_mask] : &cx.trash[cx.lane];
+    *slot = (word << 16) | (id >> cx.set_bits);
 }
 
 // neighbour row of node c on `layer` (Graph.adjacent, lib/ohnsw.ml:171); -1 = hole / padding
@@ -453,10 +504,10 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
         for (;;) {
             const int nb = adj_entry(iv, layer, cur, cx.lane);
             const bool valid = nb >= 0;
-            const uint64_t m = __ballot(valid);
-            const int cnt = __popcll(m);
+            const uint64_t m = ballot(valid);
+            const int cnt = popc(m);
             if (cnt == 0) break;
-            const int pos = __popcll(m & ((1ull << cx.lane) - 1ull));
+            const int pos = popc(m & ((1ull << cx.lane) - 1ull));
             __syncthreads();
             if (valid) cx.cand_id[pos] = nb;
             __syncthreads();
@@ -467,9 +518,119 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
             const uint32_t my = (cx.lane < cnt) ? cx.cand_key[cx.lane] : KEY_INF;
             const uint32_t bkey = wave_min_u32(my);
             if (bkey < cur_key) {                                         // strict, :502
-                const int bi = __builtin_ctzll(__ballot(cx.lane < cnt && my == bkey));
+                const int bi = __builtin_ctzll(ballot(cx.lane < cnt && my == bkey));
                 cur = uniform(cx.cand_id[bi]); cur_key = bkey;          // scalar: its row offset comes through the scalar cache
             } else break;
+        }
+    }
+}
+
+// ---- one round of a hop: up to 4*NB fresh neighbours evaluated ------------------------------------
+// The 16-lane group r evaluates candidates base + NB*r + b, b = 0..NB-1 (batch b = one wave-instruction
+// per 256 row bytes: rows of candidates b, NB+b, 2NB+b, 3NB+b).  Straight-line: the NB ids come from LDS
+// (every lane of a group reads its group's entry), the row address is one 64-bit multiply-add per batch
+// (no 32-bit offset limit), all NB*NCH global_load_dwordx4 are issued before the first is consumed, and
+// the keys never travel through LDS: after the DPP reduction every lane of group r holds the key of
+// candidate (r, b); lane 16*r + b keeps it (and the id), so one register pair holds the round's
+// candidates and ASCENDING LANE = ASCENDING ROW ORDER (lane 16*r + b <-> candidate base + NB*r + b).
+// A group whose candidate is past the end of the list re-reads the row of candidate base + b (group 0 of
+// the same batch: same addresses, coalesced, no extra traffic) and its key is forced to +inf.
+template <int NCH, int NB, int METRIC, bool FULL>
+__device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv)[NCH], const WaveCtx &cx,
+                                          int base, int cnt, uint32_t &out_key, uint32_t &out_id) {
+    const int r = cx.r, l16 = cx.l16;
+    const uint32_t stride_b = (uint32_t)iv.stride * 4u;
+    const int mine = base + NB * r;
+    uint32_t id[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int ci = (mine + b < cnt) ? mine + b : base + b;   // base + b < cnt: a round of NB batches has > 4*(NB-1) candidates
+        id[b] = (uint32_t)cx.cand_id[ci];
+    }
+    float4 v[NB][NCH];
+    if (FULL) {
+        const char *xlane = reinterpret_cast<const char *>(iv.X) + 16 * l16;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float4 *row = reinterpret_cast<const float4 *>(xlane + (uint64_t)id[b] * stride_b);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) v[b][i] = row[i * 16];
+        }
+    } else {
+        uint32_t coff[NCH];   // lanes past the row end re-read chunk 0 (coalesced) and are zeroed below
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) coff[i] = ((i * 16 + l16) < iv.nchunks) ? (uint32_t)(i * 16 + l16) * 16u : 0u;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const char *row = reinterpret_cast<const char *>(iv.X) + (uint64_t)id[b] * stride_b;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) v[b][i] = *reinterpret_cast<const float4 *>(row + coff[i]);
+        }
+    }
+    uint32_t kk = KEY_INF, ii = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float4 z = v[b][i];
+            if (!FULL) {  // lanes past the row end: make them add exactly 0 (their qv is 0)
+                const bool cv = (i * 16 + l16) < iv.nchunks;
+                z.x = cv ? z.x : 0.f; z.y = cv ? z.y : 0.f; z.z = cv ? z.z : 0.f; z.w = cv ? z.w : 0.f;
+            }
+            if (METRIC == 0) {
+                float dx = z.x - qv[i].x; acc = __builtin_fmaf(dx, dx, acc);
+                float dy = z.y - qv[i].y; acc = __builtin_fmaf(dy, dy, acc);
+                float dz = z.z - qv[i].z; acc = __builtin_fmaf(dz, dz, acc);
+                float dw = z.w - qv[i].w; acc = __builtin_fmaf(dw, dw, acc);
+            } else {
+                acc = __builtin_fmaf(z.x, qv[i].x, acc);
+                acc = __builtin_fmaf(z.y, qv[i].y, acc);
+                acc = __builtin_fmaf(z.z, qv[i].z, acc);
+                acc = __builtin_fmaf(z.w, qv[i].w, acc);
+            }
+        }
+        const uint32_t key = dist_to_key<METRIC>(reduce16(acc));
+        const bool here = l16 == b;
+        kk = here ? key : kk;
+        ii = here ? id[b] : ii;
+    }
+    out_key = (mine + l16 < cnt) ? kk : KEY_INF;   // lanes l16 >= NB kept KEY_INF
+    out_id = ii;
+}
+
+// The rounds of one hop.  Accept test of lib/ohnsw.ml:574 in row order (= ascending lane), each candidate
+// against the CURRENT W.
+template <int NCH, int RB, int NSLOT, int METRIC, int SEM, bool FULL>
+__device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)[NCH], WList<NSLOT> &w,
+                                         const WaveCtx &cx, int cnt, uint32_t &status) {
+    const int lane = cx.lane;
+    for (int base = 0; base < cnt;) {
+        const int nbb = (cnt - base + 3) >> 2;   // wave-uniform
+        uint32_t ckey, cid;
+        if (RB >= 8 && nbb >= 8) { hop_round<NCH, (RB >= 8 ? 8 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 32; }
+        else if (RB >= 4 && nbb >= 4) { hop_round<NCH, (RB >= 4 ? 4 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 16; }
+        else if (RB >= 3 && nbb >= 3) { hop_round<NCH, (RB >= 3 ? 3 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 12; }
+        else if (RB >= 2 && nbb >= 2) { hop_round<NCH, (RB >= 2 ? 2 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 8; }
+        else { hop_round<NCH, 1, METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 4; }
+        uint64_t pass = ballot(SEM ? ckey <= w.wmax : ckey < w.wmax);
+        while (pass) {
+            const int i = __builtin_ctzll(pass);
+            pass &= pass - 1;
+            const uint32_t kd = rdlane(ckey, i);
+            if (kd < w.wmax) {
+                wlist_insert<NSLOT, SEM>(w, kd, rdlane(cid, i), lane, cx.ovf, status);     // :575-577
+            } else if (SEM && kd == w.wmax && wlist_full(w)) {
+                // Nearest.insert_distance on a tie with max(W): Inserted, W unchanged (lib/hnsw.ml:501-504):
+                // the node joins C only.  It may be a node the visited cache forgot: still in W, or listed.
+                const uint32_t kid = rdlane(cid, i);
+                const uint32_t klo1 = ((kid + 1u) << 1) | 1u;
+                bool known = false;
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) known = known || (ballot(w.hi[s] == kd && (w.lo[s] | 1u) == klo1) != 0ull);
+                if (!known && w.ovf_cnt > 0) { __syncthreads(); known = tie_contains(cx.ovf, w.ovf_cnt, kid, lane); }
+                if (!known) tie_add(w, cx.ovf, kid, lane, status);
+            }
         }
     }
 }
@@ -479,18 +640,27 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
 // While the rows of a hop are in flight, the adjacency row of the then-nearest unexpanded
 // candidate is fetched too: if it is still the nearest after this hop's insertions (the common
 // case once the search has converged) the next hop starts without a dependent round trip.
-template <int NCH, int RB, int NSLOT, int METRIC, int sem = 0>
+//
+// SEM 0: Ohnsw, accept iff d < max(W).d (lib/ohnsw.ml:574).
+// SEM 1: the functor path, Hnsw_algo.Search.search (lib/hnsw_algo.ml:350-391) with
+// Nearest.insert_distance (lib/hnsw.ml:494-506): d < max(W).d replaces the maximum; d == max(W).d is
+// answered Inserted but leaves W as it is (the merge of lib/hnsw_algo.ml:25-31 puts the new element on
+// top and remove_max takes it off again), and the node is still pushed to VisitMe (:360-364) and expanded
+// later; d > max(W).d is Too_far.  Order among equal distances (the in-tree pairing heap's, restated only
+// in the oracle's TIES_HEAP mode) is fixed to (d, id) here: VisitMe pops the smallest id first, a
+// replacement evicts the largest id of the farthest class.
+// ROWS: 1 = every float4 chunk of the 16 x NCH lane grid lies inside a row (d in 64*NCH-3 .. 64*NCH: no
+// masking), 0 = ragged rows, -1 = decided at run time (the builder and the layer operators; the knn
+// kernel is instantiated per case so that neither pays for the other's registers).
+template <int NCH, int RB, int NSLOT, int METRIC, int SEM = 0, int ROWS = -1>
 __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (&qv)[NCH], int layer,
                                              WList<NSLOT> &w, int ef, const WaveCtx &cx,
                                              uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-    // sem 0: Ohnsw, accept iff d < max(W).d (lib/ohnsw.ml:574).  sem 1: the functor path's
-    // Nearest.insert_distance (lib/hnsw.ml:494-506) under the canonical order: accept iff the
-    // element is not farther than max(W) in (d, id), i.e. its full key is below the top key --
-    // a node tied in distance with max(W) but with a smaller id replaces it.
     const int lane = cx.lane;
+    const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
     int pref_id = -1, pref_nb = -1;
 #ifdef HNSW_PHASE_TIMING   // measurement build: shader-clock cycles per phase, summed over the query's hops
-    uint64_t tp0 = 0, tp1 = 0, tp2 = 0, tmark = clock64();
+    uint64_t tp0 = 0, tp1 = 0, tmark = clock64();
 #define HNSW_PHASE(acc) do { const uint64_t tn__ = clock64(); acc += tn__ - tmark; tmark = tn__; } while (0)
 #else
 #define HNSW_PHASE(acc) do { } while (0)
@@ -500,61 +670,68 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         wlist_unexpanded_masks(w, um);
         int cidx;
         int c = wlist_take_first(w, um, cidx);                           // pop_min, :565
-        if (c >= 0) wlist_mark_expanded(w, cidx, lane);
-        else {
-            // no unexpanded member of W: only entries evicted while tied with max(W) can still
-            // satisfy "not (c.d > max(W).d)" (:568)
-            if (w.ovf_cnt > 0 && w.ovf_key == w.wmax) { __syncthreads(); c = uniform((int)ovf_get(cx.ovf, --w.ovf_cnt)); }
-            else break;
+        if (SEM == 0) {
+            wlist_mark_expanded(w, cidx, lane);
+            if (c < 0) {
+                // no unexpanded member of W: only entries evicted while tied with max(W) can still
+                // satisfy "not (c.d > max(W).d)" (:568)
+                if (w.ovf_cnt > 0) { __syncthreads(); c = uniform((int)ovf_get(cx.ovf, --w.ovf_cnt)); }
+                else break;
+            }
+        } else {
+            // VisitMe.pop_nearest in (d, id) order: members of W below max(W).d first; among the nodes AT
+            // max(W).d the smallest id, whether it sits in W or only in the list
+            bool from_w = c >= 0;
+            if (w.ovf_cnt > 0) {
+                uint32_t chi = 0;
+                if (c >= 0) {
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) if ((cidx >> 6) == s) chi = rdlane(w.hi[s], cidx & 63);
+                }
+                if (c < 0 || chi == w.wmax) {
+                    __syncthreads();
+                    int tpos;
+                    const int t = tie_min_unexpanded(cx.ovf, w.ovf_cnt, lane, tpos);
+                    if (t >= 0 && (c < 0 || t < c)) {
+                        tie_mark_expanded(cx.ovf, tpos, lane);
+                        __syncthreads();
+                        c = t; from_w = false;
+                        wlist_unexpanded_masks(w, um);                   // the W member was not taken
+                    }
+                }
+            }
+            if (c < 0) break;
+            wlist_mark_expanded(w, from_w ? cidx : -1, lane);
         }
         n_hops++;
         int nb;
         if (c == pref_id) { nb = pref_nb; status += 256u; }              // Graph.adjacent, :570 (bits 8..: prefetch hits)
         else nb = adj_entry(iv, layer, c, lane);
-        const bool valid = nb >= 0;
-        const uint32_t h = vt_hash(cx, (uint32_t)nb);
         uint32_t vword;
-        const bool fresh = valid && !visited_mem(cx, h, vword);          // Visited.mem, :571
-        const uint64_t m = __ballot(fresh);
-        const int cnt = __popcll(m);
+        const bool seen = visited_mem(cx, (uint32_t)nb, vword);          // Visited.mem, :571 (a hole reads some set: harmless)
+        const bool fresh = (nb >= 0) & !seen;
+        const uint64_t m = ballot(fresh);
+        const int cnt = popc(m);
         // issued only now so that it shares its flight with this hop's rows (loads return in order)
         int pidx;
         pref_id = wlist_take_first(w, um, pidx);                         // the next nearest unexpanded
         if (pref_id >= 0) pref_nb = adj_entry(iv, layer, pref_id, lane);
         if (cnt == 0) { HNSW_PHASE(tp0); continue; }
-        const int pos = __popcll(m & ((1ull << lane) - 1ull));
+        const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
         __syncthreads();
-        // lanes without a fresh neighbour write to scratch entries past the live ones (no branch)
         if (fresh) {                                                     // Visited.add, :572
-            if ((h & 0xFFFFu) != 0xFFFFu) cx.vt[h >> 16] = (vword << 16) | (h & 0xFFFFu);
+            cx.vt[(uint32_t)nb & cx.set_mask] = (vword << 16) | ((uint32_t)nb >> cx.set_bits);
             cx.cand_id[pos] = nb;
         }
         __syncthreads();
-        HNSW_PHASE(tp0);                                                 // pop + adjacency + filter + compaction
-        eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, cnt, cx.r, cx.l16); // :573
-        __syncthreads();
         n_dist += cnt;
-        const uint32_t my_key = cx.cand_key[lane];
-#ifdef HNSW_PHASE_TIMING
-        asm volatile("" :: "v"(my_key));
-#endif
-        HNSW_PHASE(tp1);                                                 // row loads + arithmetic + keys back from LDS
-        const uint32_t my_id = (uint32_t)cx.cand_id[lane];
-        // :574 accept iff |W| < ef or d < max(W).d -- tested in row order against the CURRENT W
-        const uint64_t my_key64 = ((uint64_t)my_key << 32) | ((uint64_t)(my_id + 1u) << 1);
-        uint64_t pass = __ballot(lane < cnt && (sem ? (my_key64 < w.wmax64) : (my_key < w.wmax)));
-        while (pass) {
-            const int i = __builtin_ctzll(pass);
-            pass &= pass - 1;
-            const uint32_t kd = rdlane(my_key, i);
-            const uint32_t kid = rdlane(my_id, i);
-            if (sem ? !((((uint64_t)kd << 32) | ((uint64_t)(kid + 1u) << 1)) < w.wmax64) : !(kd < w.wmax)) continue;
-            wlist_insert(w, kd, kid, lane, cx.ovf, status);                    // :575-577
-        }
-        HNSW_PHASE(tp2);                                                 // accept tests + insertions
+        HNSW_PHASE(tp0);                                                 // pop + adjacency + filter + compaction
+        if (ROWS == 1 || (ROWS < 0 && full_rows)) hop_eval<NCH, RB, NSLOT, METRIC, SEM, true>(iv, qv, w, cx, cnt, status);   // :573-577
+        else hop_eval<NCH, RB, NSLOT, METRIC, SEM, false>(iv, qv, w, cx, cnt, status);
+        HNSW_PHASE(tp1);                                                 // rows + arithmetic + accept tests + insertions
     }
 #ifdef HNSW_PHASE_TIMING
-    n_dist = (uint32_t)tp0; n_hops = (uint32_t)tp1; status = (uint32_t)tp2 << 8;   // reported through the counters
+    n_dist = (uint32_t)tp0; n_hops = (uint32_t)tp1; status = 0;   // reported through the counters
 #endif
 #undef HNSW_PHASE
 }
@@ -582,11 +759,15 @@ __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv,
 }
 
 // ---- the search kernel: Ohnsw.knn (lib/ohnsw.ml:859-875) per query -------------------------------
+// waves per SIMD the register allocator must leave room for: the L2 variants for d <= 128 with W in at most two key
+// registers per lane and unmasked rows fit 72 VGPRs (7 waves/SIMD, 7168 resident queries) without
+// spilling (8 waves would spill; the other variants are left to the allocator)
 #ifndef HNSW_SEARCH_MIN_WAVES
-#define HNSW_SEARCH_MIN_WAVES 1
+#define HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, FULL) (((NCH) <= 2 && (NSLOT) <= 2 && (METRIC) == 0 && (FULL)) ? 7 : 1)
 #endif
-template <int NCH, int RB, int NSLOT, int METRIC>
-__global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES)
+// SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); FULL: see search_layer's ROWS
+template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, bool FULL>
+__global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, FULL))
 hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
@@ -624,12 +805,10 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
 
     WList<NSLOT> w;
     wlist_init(w, a.ef, lane);
-    wlist_insert(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);         // :871, seeds W :555-557
-    { uint32_t hw; const uint32_t hc = vt_hash(cx, (uint32_t)cur); (void)visited_mem(cx, hc, hw); visited_add_masked(cx, hc, hw, lane == 0); }
+    wlist_insert<NSLOT, SEMF>(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);         // :871, seeds W :555-557
+    { uint32_t hw; (void)visited_mem(cx, (uint32_t)cur, hw); visited_add_masked(cx, (uint32_t)cur, hw, lane == 0); }
     __syncthreads();
-    // the two accept rules are separate instantiations: no per-hop cost for the choice
-    if (a.sem) search_layer<NCH, RB, NSLOT, METRIC, 1>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status);
-    else search_layer<NCH, RB, NSLOT, METRIC, 0>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
+    search_layer<NCH, RB, NSLOT, METRIC, SEMF, FULL ? 1 : 0>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
 
     // results: W[0..k) ascending (lib/ohnsw.ml:886-893); sem 2: nearest_k's k farthest of W, lib/hnsw.ml:522-525
     int wbase = NSLOT * 64 - a.ef;
@@ -640,8 +819,8 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
         if (idx >= 0 && idx < a.k) {
             int32_t oid = -1;
             float od = a.fill == 0 ? __uint_as_float(0x7FC00000u) : __uint_as_float(0x7F800000u);
-            const uint32_t hi = (uint32_t)(w.key[s] >> 32);
-            if (hi < DUMMY_HI) { oid = (int32_t)key_id(w.key[s]) + iv.id_base; od = key_to_dist<METRIC>(hi); }
+            const uint32_t hi = w.hi[s];
+            if (hi < DUMMY_HI) { oid = (int32_t)key_id(w.lo[s]) + iv.id_base; od = key_to_dist<METRIC>(hi); }
             a.out_ids[q * a.k + idx] = oid;
             a.out_dist[q * a.k + idx] = od;
         }

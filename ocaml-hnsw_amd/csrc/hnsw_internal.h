@@ -116,7 +116,7 @@ inline int search_vt_bits(const hnsw_index *idx, int ef) {
         b = ef <= 256 ? 11 : 12;
     }
     b = std::max(4, std::min(16, b));
-    while (b < 16 && ((int64_t)1 << (b + 15)) < idx->iv.n) ++b;   // tags must identify ids exactly
+    while (b < 16 && ((int64_t)0xFFFF << (b - 1)) < idx->iv.n) ++b;   // 16-bit tags must identify ids exactly, 0xFFFF = empty way
     return b;
 }
 

@@ -64,10 +64,9 @@ hnsw_layer_search_kernel(const IndexView iv, const LayerSearchArgs a) {
         n_dist += cnt;
         const uint32_t my_key = cx.cand_key[lane];
         const uint32_t my_id = (uint32_t)cx.cand_id[lane];
-        const uint32_t h = vt_hash(cx, my_id);
         uint32_t vword;
-        (void)visited_mem(cx, h, vword);
-        visited_add_masked(cx, h, vword, lane < cnt);
+        (void)visited_mem(cx, lane < cnt ? my_id : 0u, vword);
+        visited_add_masked(cx, my_id, vword, lane < cnt);
         for (int i = 0; i < cnt; ++i)
             wlist_insert(w, rdlane(my_key, i), rdlane(my_id, i), lane, cx.ovf, status);
         __syncthreads();
@@ -82,13 +81,13 @@ hnsw_layer_search_kernel(const IndexView iv, const LayerSearchArgs a) {
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int idx = s * 64 + lane - wbase;
-        const uint32_t hi = (uint32_t)(w.key[s] >> 32);
+        const uint32_t hi = w.hi[s];
         const bool real = idx >= 0 && idx < a.k && hi < DUMMY_HI;
         found += __popcll(__ballot(real));
         if (idx >= 0 && idx < a.k) {
             int32_t oid = iv.id_base - 1;
             float od = a.fill == 0 ? __uint_as_float(0x7FC00000u) : __uint_as_float(0x7F800000u);
-            if (real) { oid = (int32_t)key_id(w.key[s]) + iv.id_base; od = key_to_dist<METRIC>(hi); }
+            if (real) { oid = (int32_t)key_id(w.lo[s]) + iv.id_base; od = key_to_dist<METRIC>(hi); }
             a.out_ids[q * a.k + idx] = oid;
             a.out_dist[q * a.k + idx] = od;
         }

@@ -1,0 +1,83 @@
+// hnsw_search_variants.hip -- instantiations of hnsw_search_kernel (hnsw_device.hip.h) for ONE
+// (metric, accept rule, row shape) triple; build.py compiles this file once per triple
+// (-DHNSW_V_METRIC= -DHNSW_V_SEMF= -DHNSW_V_FULL=), in parallel.  Each object exports a launcher and an
+// occupancy query over the (NCH, NSLOT) grid; hnsw_capi.hip picks the object by the triple.
+// The triple is a compile-time parameter of the kernel because the register allocation of a kernel is
+// that of its worst path: with both accept rules and both row shapes in one kernel the d = 128 Ohnsw
+// variant needed 88 VGPRs (5 waves/SIMD); on its own it needs 64 (8 waves/SIMD).
+#include "hnsw_internal.h"
+
+#ifndef HNSW_V_METRIC
+#error "compile with -DHNSW_V_METRIC=0|1 -DHNSW_V_SEMF=0|1 -DHNSW_V_FULL=0|1"
+#endif
+
+using hnsw_dev::IndexView;
+using hnsw_dev::SearchArgs;
+
+namespace {
+
+constexpr int M_ = HNSW_V_METRIC, S_ = HNSW_V_SEMF;
+constexpr bool F_ = HNSW_V_FULL != 0;
+
+template <int NCH, int RB, int NSLOT>
+hipError_t launch_one(const IndexView &iv, const SearchArgs &a, hipStream_t st) {
+    const size_t lds = hnsw_dev::wave_lds_words(a.vt_bits) * sizeof(uint32_t);
+    hipLaunchKernelGGL((hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_>), dim3((unsigned)a.nq),
+                       dim3(64), lds, st, iv, a);
+    return hipGetLastError();
+}
+template <int NCH, int RB, int NSLOT>
+int occupancy_one(size_t lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_>, 64, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    return nb;
+}
+
+template <int NCH, int RB>
+hipError_t launch_slot(int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st) {
+    switch (nslot) {
+    case 1: return launch_one<NCH, RB, 1>(iv, a, st);
+    case 2: return launch_one<NCH, RB, 2>(iv, a, st);
+    case 4: return launch_one<NCH, RB, 4>(iv, a, st);
+    case 8: return launch_one<NCH, RB, 8>(iv, a, st);
+    default: return launch_one<NCH, RB, 16>(iv, a, st);
+    }
+}
+template <int NCH, int RB>
+int occupancy_slot(int nslot, size_t lds) {
+    switch (nslot) {
+    case 1: return occupancy_one<NCH, RB, 1>(lds);
+    case 2: return occupancy_one<NCH, RB, 2>(lds);
+    case 4: return occupancy_one<NCH, RB, 4>(lds);
+    case 8: return occupancy_one<NCH, RB, 8>(lds);
+    default: return occupancy_one<NCH, RB, 16>(lds);
+    }
+}
+
+} // namespace
+
+#define HNSW_V_CAT2(a, b, c, d) a##b##_##c##_##d
+#define HNSW_V_CAT(a, b, c, d) HNSW_V_CAT2(a, b, c, d)
+
+namespace hnsw_host {
+
+hipError_t HNSW_V_CAT(search_launch_, HNSW_V_METRIC, HNSW_V_SEMF, HNSW_V_FULL)(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st) {
+    switch (nch) {
+    case 1: return launch_slot<1, 8>(nslot, iv, a, st);
+    case 2: return launch_slot<2, HNSW_RB_NCH2>(nslot, iv, a, st);
+    case 4: return launch_slot<4, 2>(nslot, iv, a, st);
+    case 8: return launch_slot<8, 1>(nslot, iv, a, st);
+    default: return launch_slot<16, 1>(nslot, iv, a, st);
+    }
+}
+int HNSW_V_CAT(search_occupancy_, HNSW_V_METRIC, HNSW_V_SEMF, HNSW_V_FULL)(int nch, int nslot, size_t lds) {
+    switch (nch) {
+    case 1: return occupancy_slot<1, 8>(nslot, lds);
+    case 2: return occupancy_slot<2, HNSW_RB_NCH2>(nslot, lds);
+    case 4: return occupancy_slot<4, 2>(nslot, lds);
+    case 8: return occupancy_slot<8, 1>(nslot, lds);
+    default: return occupancy_slot<16, 1>(nslot, lds);
+    }
+}
+
+} // namespace hnsw_host

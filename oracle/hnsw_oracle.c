@@ -625,10 +625,24 @@ int32_t og_ohnsw_knn_batch_mt(const og_graph *g, og_space *sp, const float *Q, i
 /* Nearest (W): lib/hnsw.ml:470-526 -- bounded max-heap + size. */
 typedef struct nearest_t { ph_ctx c; ph_node *heap; int32_t size, max_size; } nearest_t;
 
-/* insert_distance, lib/hnsw.ml:494-506.  Returns 1 = Inserted, 0 = Too_far. */
+/* insert_distance, lib/hnsw.ml:494-506.  Returns 1 = Inserted, 0 = Too_far.
+ * The reference compares DISTANCES only (MaxHeap.Element.compare = Float.compare on
+ * distance_to_target, lib/hnsw_algo.ml:126-131): farther => Too_far; otherwise add |> remove_max.
+ * On an exact tie with max(W) the merge of lib/hnsw_algo.ml:25-31 puts the new element on top (the
+ * else-branch wins on equality) and remove_max takes it off again: W is unchanged, yet the answer is
+ * Inserted, so the caller still pushes the node to VisitMe (lib/hnsw_algo.ml:360-364).
+ * TIES_HEAP runs exactly that code on the in-tree pairing heap.  TIES_CANONICAL keeps the same
+ * three-way rule on distances and only fixes what the pairing heap's shape decides -- WHICH of
+ * several equally far elements remove_max takes -- to the largest node id. */
 static int nearest_insert_distance(nearest_t *q, elt element) {
     if (q->size < q->max_size) { q->heap = ph_add(&q->c, q->heap, element); q->size++; return 1; } /* :496-497 */
     if (!q->heap) return 0;                                                                      /* :499 */
+    if (q->c.canonical) {
+        if (element.dist > q->heap->e.dist) return 0;                                            /* :501 is_further */
+        if (element.dist == q->heap->e.dist) return 1;                                           /* :503 add |> remove_max = identity */
+        q->heap = ph_remove_top(&q->c, ph_add(&q->c, q->heap, element));                         /* :503 */
+        return 1;
+    }
     /* is_further element max = MaxHeap compare element max < 0 (hnsw_algo.ml:131) */
     if (!(elt_compare(&q->c, &element, &q->heap->e) < 0)) {                                      /* :501 */
         q->heap = ph_remove_top(&q->c, ph_add(&q->c, q->heap, element));                         /* :503 */

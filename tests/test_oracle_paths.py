@@ -149,3 +149,21 @@ def test_c1_configuration_regression_pin(oracle):
     assert got == want
     assert got["seq_f32"]["ids_sha256"] == got["tree16"]["ids_sha256"]      # the summation order moves no neighbour here
     assert 0.6 < got["seq_f32"]["recall_at_10"] < 0.9                        # ef = 32 on structureless data
+
+
+def test_functor_tie_with_max_w_is_inserted_but_w_keeps_the_incumbent(oracle):
+    """lib/hnsw.ml:494-506 + lib/hnsw_algo.ml:25-32, 360-364: a neighbour tied with max(W) is answered
+    Inserted (so it is expanded later) while W keeps the incumbent.  Both tie modes of the oracle's functor
+    path follow that rule (TIES_CANONICAL only fixes the order among equal keys); the imperative path's
+    strict `<` (lib/ohnsw.ml:574) drops the twin."""
+    vals = np.array([[5.0], [2.0], [-2.0], [0.5]], np.float32)   # node 3 is reachable only through node 2
+    g = oracle.Graph.from_lists([[1, 2], [0], [0, 3], [2]], entry_point=0)
+    sp = oracle.Space.l2(vals, arith=oracle.SEQ_F32)
+    Q = np.zeros((1, 1), np.float32)
+    for ties in (oracle.TIES_HEAP, oracle.TIES_CANONICAL):
+        od, oi = oracle.Functor.knn_batch(g, sp, Q, 1, 1, ties=ties, with_ids=True)
+        assert oi[0, 0] == 3 and od[0, 0] == 0.5
+        res = oracle.Functor.search(g, sp, [0], Q[0], 1, ties=ties)
+        assert res == [(3, 0.5)]
+    oi, od = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=1, ef=1, ties=oracle.TIES_CANONICAL)
+    assert oi[0, 0] == 1 and od[0, 0] == 2.0

@@ -25,9 +25,21 @@ for f in find("trace/**/*kernel_trace.csv"):
     if rows:
         durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
         r0 = rows[0]
-        out.append("== hnsw_search_kernel dispatches: n=%d avg=%.1f us min=%.1f us max=%.1f us  VGPR=%s SGPR=%s LDS=%s grid=%s wg=%s" % (
-            len(durs), sum(durs) / len(durs) / 1e3, min(durs) / 1e3, max(durs) / 1e3, r0.get("VGPR_Count"),
-            r0.get("SGPR_Count"), r0.get("LDS_Block_Size"), r0.get("Grid_Size"), r0.get("Workgroup_Size")))
+        # resource columns as rocprofv3 names them; the compiler's own table (build.py --resources) is the
+        # authority for registers: the trace reports allocation granules / accumulation offsets, not counts
+        def col(*names):
+            for nme in names:
+                if r0.get(nme) not in (None, ""):
+                    return r0.get(nme)
+            return "n/a"
+        by_name = defaultdict(list)
+        for r, du in zip(rows, durs):
+            by_name[r["Kernel_Name"].split("(")[0]].append(du)
+        for nme, ds in sorted(by_name.items()):
+            out.append("== %s dispatches: n=%d avg=%.1f us min=%.1f us max=%.1f us" % (nme[-60:], len(ds), sum(ds) / len(ds) / 1e3, min(ds) / 1e3, max(ds) / 1e3))
+        out.append("   (trace columns of the first dispatch: arch_vgpr=%s accum_vgpr=%s sgpr=%s lds=%s grid=%s wg=%s)" % (
+            col("Arch_VGPR_Count", "VGPR_Count"), col("Accum_VGPR_Count"), col("SGPR_Count"), col("LDS_Block_Size", "LDS_Block_Size_v"),
+            col("Grid_Size", "Grid_Size_X"), col("Workgroup_Size", "Workgroup_Size_X")))
 for pdir in find("pmc_*/"):
     for f in find(os.path.relpath(pdir, d) + "/**/*counter_collection.csv"):
         acc = defaultdict(lambda: [0.0, 0])
