@@ -11,6 +11,13 @@ all-gathered over RCCL (weak scaling: per-GPU work fixed).
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`value` is measured on the device-pointer entry point (hnsw_search_batch_device: queries resident in HBM,
+results left in HBM -- the line says so in `protocol`).  The same run also reports, as extra objects:
+`drop_in` (the synchronous host-buffer call hnsw_search_batch = what Ohnsw.knn_batch_bigarray becomes:
+H2D + ordering pre-pass + kernel + D2H, as benchmark/benchmark.ml:89-96 times it, and the
+submit/wait form with two requests in flight), `secondary` (a harder SIFT-like set), and for N > 1
+`strong` (C4 as BASELINE.json words it: ONE 10 k batch split over the N GPUs).
+
 Prints ONE JSON line on rank 0.  The oracle (oracle/) is used only as the checker and as the
 `cpu_baseline` leg (a single-thread C restatement of the reference's OCaml CPU path).
 """
@@ -121,6 +128,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=4000, help="queries timed on the CPU restatement")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the harder SIFT-like data point (object `secondary`)")
     ap.add_argument("--pipelined", action="store_true",
                     help="also time the same steps alternated over two HIP streams (extra object `pipelined`, never `value`); "
                          "off by default so that the default run's kernel trace holds serialized launches only")
@@ -181,6 +189,9 @@ def main():
         # every rank searches its own shard of the global batch of world * nq queries
         Qall = make_sift_like(world * nq, d, seed=2, device=dev)
     Qd = Qall[rank * nq:(rank + 1) * nq].contiguous()
+    if multi:   # every rank generated its own copy of the data: the copies must be identical
+        import ocaml_hnsw_amd.sharding as sharding
+        sharding.assert_same_on_all_ranks(dist, cdev, {"X": Xd, "Q": Qall})
     X = Xd.cpu().numpy()
     log("data: n=%d d=%d nq/gpu=%d (%.1fs)" % (n, d, nq, time.time() - t0))
 
@@ -193,7 +204,6 @@ def main():
         if multi or not args.no_cpu:
             hg.export()
     if multi:
-        import ocaml_hnsw_amd.sharding as sharding
         deg0, nbr0, upper, entry = sharding.replicate_graph(dist, cdev, hg if rank == 0 else None, args.M)
         if rank != 0:
             hg = H.Hgraph(X, deg0, nbr0, upper, entry_point=entry, id_base=0, max_degree=args.M).to_device(gpu)
@@ -210,6 +220,7 @@ def main():
     ids_d, dist_d = ids_v[0], dist_v[0]
     nd_d = torch.zeros(nq, dtype=torch.int32, device=dev)
     nh_d = torch.zeros(nq, dtype=torch.int32, device=dev)
+    st_d = torch.zeros(nq, dtype=torch.int32, device=dev)   # per-query status: bit 0 = tie-overflow list outgrew its LDS slots
     if multi:
         all_res = [torch.empty(world * 2 * nres, dtype=torch.int32, device=cdev) for _ in range(2)]
     stream = torch.cuda.current_stream()
@@ -217,7 +228,7 @@ def main():
     def search(ef_, counters=False, slot=0):
         H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(),
                               nd_d.data_ptr() if counters else 0, nh_d.data_ptr() if counters else 0,
-                              0, stream.cuda_stream)
+                              st_d.data_ptr(), stream.cuda_stream)
 
     def gather(slot):
         """the exchange step: per-shard results -> every rank (one RCCL all-gather over xGMI), async"""
@@ -296,18 +307,107 @@ def main():
 
     # ---- recall@10 on rank 0 (exact ground truth on the GPU) ----
     checks = {}
+    strong = None
     if multi:   # the gathered table holds every rank's [ids | distances] block at its place
         last = (args.steps - 1) & 1
         blocks = all_res[last].view(world, 2 * nres)
         checks["gathered_shard_matches"] = bool(torch.equal(blocks[rank].to(dev), res[last]))
         checks["gathered_all_shards_nonempty"] = bool((blocks[:, :nres] >= 0).any(dim=1).all())
+        # the gathered result must equal ONE device's search of the whole global batch (rank 0 does it)
+        if rank == 0:
+            gq = world * nq
+            g_ids = torch.empty((gq, k), dtype=torch.int32, device=dev)
+            g_dd = torch.empty((gq, k), dtype=torch.float32, device=dev)
+            H.search_batch_device(hg, Qall.data_ptr(), gq, d, ef, k, g_ids.data_ptr(), g_dd.data_ptr(), 0, 0, 0, stream.cuda_stream)
+            torch.cuda.synchronize()
+            b_ids = blocks[:, :nres].reshape(gq, k).to(dev)
+            b_dd = blocks[:, nres:].reshape(gq, k).to(dev)
+            checks["gathered_equals_single_device"] = bool(torch.equal(b_ids, g_ids) and torch.equal(b_dd, g_dd.view(torch.int32)))
+            del g_ids, g_dd, b_ids, b_dd
+
+        # ---- strong scaling, as BASELINE.json words C4: ONE nq-query batch split over the N GPUs, results
+        #      all-gathered so that every GPU holds the full [nq][k] table.  Never `value` (the driver computes
+        #      scaling from the weak line); nq / N queries per GPU is far below the 7168 resident: a latency point.
+        lo_s, hi_s = sharding.shard_bounds(nq, world, rank)
+        s_ids = torch.empty((max(hi_s - lo_s, 1), k), dtype=torch.int32, device=dev)
+        s_dd = torch.empty((max(hi_s - lo_s, 1), k), dtype=torch.float32, device=dev)
+        Qg = Qall[:nq]
+
+        def search_shard(lo, hi):
+            if hi > lo:
+                H.search_batch_device(hg, Qg[lo:hi].data_ptr(), hi - lo, d, ef, k, s_ids.data_ptr(), s_dd.data_ptr(), 0, 0, 0, stream.cuda_stream)
+            i_, d_ = s_ids[:hi - lo], s_dd[:hi - lo]
+            if args.backend != "nccl":
+                torch.cuda.synchronize()
+                i_, d_ = i_.cpu(), d_.cpu()
+            return i_, d_
+
+        for _ in range(max(1, args.warmup)):
+            full_i, full_d = sharding.sharded_search(dist, search_shard, nq, k)
+        sync()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            full_i, full_d = sharding.sharded_search(dist, search_shard, nq, k)
+        sync()
+        sw = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=cdev)
+        dist.all_reduce(sw, op=dist.ReduceOp.MAX)
+        swall = float(sw[0])
+        strong = {"value": round(nq * args.steps / swall, 1), "unit": "queries/s", "global_batch": nq, "n_gpus": world,
+                  "ms_per_step": round(1e3 * swall / args.steps, 4), "scaling": "strong",
+                  "what": "one %d-query batch split into %d contiguous shards, per-shard search + all-gather of [ids | distances] per step" % (nq, world)}
+        if rank == 0:
+            one_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+            one_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            H.search_batch_device(hg, Qg.data_ptr(), nq, d, ef, k, one_i.data_ptr(), one_d.data_ptr(), 0, 0, 0, stream.cuda_stream)
+            torch.cuda.synchronize()
+            strong["equals_single_device"] = bool(torch.equal(full_i.to(dev), one_i) and torch.equal(full_d.to(dev).view(torch.int32), one_d.view(torch.int32)))
+            log("strong scaling (one %d-query batch over %d GPUs): %.0f q/s, %.3f ms/step" % (nq, world, strong["value"], strong["ms_per_step"]))
     search(ef, counters=True)
     torch.cuda.synchronize()
     got = ids_d.cpu().numpy()
     got_dist = dist_d.cpu().numpy()
     gpu_nd = nd_d.cpu().numpy().astype(np.int64)
     gpu_nh = nh_d.cpu().numpy().astype(np.int64)
+    # the device-pointer entry point has no exactness fallback: a query whose list of tied, evicted, still
+    # expandable entries outgrew its 64 LDS slots is only FLAGGED there (it may then miss neighbours); the
+    # host-buffer entry point searches such queries again with a global slab.  Count them.
+    flagged = int((st_d & 1).sum().item())
+    checks["tie_overflow_flagged"] = flagged
     ef_ok, qps_ok = None, None
+
+    # ---- the drop-in call: what Ohnsw.knn_batch_bigarray becomes (host matrices in and out, one
+    #      synchronous call per batch, benchmark/benchmark.ml:89-96), PCIe copies included ----
+    drop_in = None
+    if world == 1 and rank == 0:
+        Qh = Qd.cpu().numpy()
+        reps = max(3, min(args.steps, 10))
+        hi_, hd_ = H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef)       # warm-up, and the exact result of every query
+        checks["device_call_equals_drop_in"] = bool(np.array_equal(hi_, got) and np.array_equal(hd_.view(np.uint32), got_dist.view(np.uint32)))
+        t = time.perf_counter()
+        for _ in range(reps):
+            H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef)
+        sync_s = (time.perf_counter() - t) / reps
+        # the same call in two halves (hnsw_search_submit / hnsw_search_wait), two requests in flight
+        inflight = []
+        for _ in range(6):      # warm-up: every pooled request has its device buffers before the clock starts
+            inflight.append(H.submit(hg, Qh, ef, k))
+            if len(inflight) > 2:
+                inflight.pop(0).wait()
+        t = time.perf_counter()
+        for _ in range(reps):
+            inflight.append(H.submit(hg, Qh, ef, k))
+            inflight.pop(0).wait()
+        sub_s = (time.perf_counter() - t) / reps
+        while inflight:
+            inflight.pop(0).wait()
+        drop_in = {"synchronous": {"value": round(nq / sync_s, 1), "unit": "queries/s", "ms_per_batch": round(1e3 * sync_s, 4),
+                                   "what": "hnsw_search_batch: pageable host queries -> H2D -> ordering pre-pass + search kernel -> D2H "
+                                           "-> host ids/distances, one blocking call per %d-query batch (the body of Ohnsw.knn_batch_bigarray)" % nq},
+                   "submit_wait_2_in_flight": {"value": round(nq / sub_s, 1), "unit": "queries/s", "ms_per_batch": round(1e3 * sub_s, 4),
+                                               "what": "hnsw_search_submit / hnsw_search_wait, two requests in flight, same host buffers"},
+                   "batches_timed": reps}
+        log("drop-in (host buffers): synchronous %.0f q/s (%.3f ms/batch), submit/wait x2 %.0f q/s (%.3f ms/batch)" %
+            (nq / sync_s, 1e3 * sync_s, nq / sub_s, 1e3 * sub_s))
     if rank == 0:
         ns = min(1000, nq)
         gt = brute_force_topk(Xd, Qd[:ns], k)
@@ -335,6 +435,91 @@ def main():
                 log("recall@10 >= 0.95 first reached at ef=%d (%.4f): %.0f q/s" % (ef2, r2, qps_ok))
                 break
 
+    # ---- secondary data point (N = 1): a harder SIFT-like set (256 blobs, sigma 40).  The C2 recipe of
+    #      SURVEY 8d (4096 blobs, sigma 25) is benign: recall 1.0 at ef 128 with ~950 evaluations per query,
+    #      where real SIFT1M needs 2500-3500.  Same n, d, M, efConstruction, batch; never `value`. ----
+    secondary = None
+    if world == 1 and rank == 0 and not args.dataset and not args.no_secondary:
+        t0 = time.time()
+        X2d = make_sift_like(n, d, seed=1, device=dev, n_centres=256, sigma=40.0)
+        Q2d = make_sift_like(nq, d, seed=2, device=dev, n_centres=256, sigma=40.0)
+        X2 = X2d.cpu().numpy()
+        hg2 = H.Ohnsw.build_batch_bigarray(X2, args.M, args.efc, seed=1, device=gpu)
+
+        def search2(ef_, counters=False):
+            H.search_batch_device(hg2, Q2d.data_ptr(), nq, d, ef_, k, ids_v[0].data_ptr(), dist_v[0].data_ptr(),
+                                  nd_d.data_ptr() if counters else 0, nh_d.data_ptr() if counters else 0,
+                                  st_d.data_ptr(), stream.cuda_stream)
+
+        def timed2(ef_, steps):
+            search2(ef_)
+            torch.cuda.synchronize()
+            hg2.set_option("time_kernels", 1)
+            hg2.kernel_times()
+            t = time.perf_counter()
+            for _ in range(steps):
+                search2(ef_)
+            torch.cuda.synchronize()
+            w = (time.perf_counter() - t) / steps
+            sm, pm, _ = hg2.kernel_times()
+            hg2.set_option("time_kernels", 0)
+            return w, sm, pm
+
+        ns2 = min(1000, nq)
+        gt2 = brute_force_topk(X2d, Q2d[:ns2], k)
+        steps2 = max(3, args.steps // 2)
+        w2, sm2, pm2 = timed2(ef, steps2)
+        search2(ef, counters=True)
+        torch.cuda.synchronize()
+        got2, got2_d = ids_v[0].cpu().numpy(), dist_v[0].cpu().numpy()
+        rec2 = recall_ids(got2[:ns2], gt2)
+        nd2, nh2 = float(nd_d.float().mean().item()), float(nh_d.float().mean().item())
+        src2 = "gpu counters (include re-evaluations)"
+        sec_checks = {"recall_at_10": round(rec2, 4), "tie_overflow_flagged": int((st_d & 1).sum().item())}
+        nu2 = None
+        if not args.no_cpu:
+            from oracle import oracle as o
+            hg2.export()
+            s2 = min(500, nq)
+            sp2 = o.Space.l2(X2, arith=o.TREE16)
+            g2 = o.Graph(hg2.n, hg2.entry_point, hg2.deg0, hg2.nbr0, hg2.upper)
+            oi2, od2, ond2, onh2, onu2 = o.Ohnsw.knn_batch_bigarray(g2, sp2, Q2d[:s2].cpu().numpy(), k=k, ef=ef, ties=o.TIES_CANONICAL, split=True)
+            nd2, nh2, nu2 = float(ond2.mean()), float(onh2.mean()), float(onu2.mean())
+            src2 = "oracle counters on %d queries" % s2
+            sec_checks["parity_queries"] = s2
+            sec_checks["parity_ids_equal"] = bool(np.array_equal(oi2, got2[:s2]))
+            sec_checks["parity_dist_bits_equal"] = bool(np.array_equal(od2.view(np.uint32), got2_d[:s2].view(np.uint32)))
+            del sp2, g2
+        S2 = 2 * args.M
+        bq2_total = nd2 * (4 * d + 4) + nh2 * 4 * S2 + 4 * d + 8 * k
+        if pm2 > 0 and nu2 is not None:     # ordered launch: the descent ran in its own kernel
+            bq2 = (nd2 - nu2) * (4 * d + 4) + nh2 * 4 * S2 + 4 * d + 8 * k + 16
+            kms2 = sm2
+        else:
+            bq2, kms2 = bq2_total, sm2 + pm2
+        ach2 = bq2 * nq / (kms2 * 1e-3) / 1e9
+        secondary = {"workload": "harder SIFT-like: n=%d d=%d clustered ints 0..218, 256 blobs, sigma 40; M=%d efConstruction=%d, ef=%d k=%d, %d queries"
+                                 % (n, d, args.M, args.efc, ef, k, nq),
+                     "value": round(nq / w2, 1), "unit": "queries/s", "ms_per_step": round(1e3 * w2, 4), "steps": steps2,
+                     "roofline": {"bound": "hbm", "achieved": round(ach2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(ach2 / HBM_PEAK_GBS, 4), "kernel_ms": round(kms2, 4), "bytes_per_query": round(bq2, 1),
+                                  "n_dist_per_query": round(nd2, 1), "n_hops_per_query": round(nh2, 1), "counters": src2},
+                     "checks": sec_checks}
+        if rec2 < 0.95:
+            for ef2 in (160, 192, 256, 320, 384, 512, 768, 1024):
+                search2(ef2)
+                torch.cuda.synchronize()
+                r2 = recall_ids(ids_v[0].cpu().numpy()[:ns2], gt2)
+                if r2 >= 0.95:
+                    w3, _, _ = timed2(ef2, steps2)
+                    secondary["at_recall_0.95"] = {"ef": ef2, "recall_at_10": round(r2, 4), "value": round(nq / w3, 1),
+                                                   "unit": "queries/s", "ms_per_step": round(1e3 * w3, 4)}
+                    break
+        log("secondary (256 blobs, sigma 40): %.0f q/s at ef=%d, recall@10 %.4f, %.0f evaluations/query, frac %.3f (%.1fs)" %
+            (nq / w2, ef, rec2, nd2, ach2 / HBM_PEAK_GBS, time.time() - t0))
+        hg2.release()
+        del X2d, Q2d, X2, hg2
+
     # ---- algorithmic bytes from the CPU oracle's counters on the same graph/queries,
     #      parity spot-check, and the CPU baseline (rank 0) ----
     roofline, cpu_baseline = None, None
@@ -360,18 +545,29 @@ def main():
             checks["parity_dist_bits_equal"] = bool(np.array_equal(odist.view(np.uint32), got_dist[:sample].view(np.uint32)))
             checks["gpu_reevaluation_overhead"] = round(float(gpu_nd[:sample].mean() / max(ond.mean(), 1) - 1), 4)
             if world == 1:
+                # the baseline is timed with the REFERENCE's arithmetic (Lacaml-style sequential fp32 sum, sqrt in
+                # double: oracle SEQ_F32), not with the kernel's summation order used for the parity leg above
+                sp_ref = o.Space.l2(X, arith=o.SEQ_F32)
+                Qall_h = Qd.cpu().numpy()
+                t = time.perf_counter()
+                rids, rdist = o.Ohnsw.knn_batch_bigarray(g, sp_ref, Qall_h, k=k, ef=ef, ties=o.TIES_CANONICAL)
+                ref_s = time.perf_counter() - t
+                # integer-valued data: every summation order is exact, so this leg must reproduce the GPU bit for bit too
+                checks["cpu_reference_arithmetic_ids_equal"] = bool(np.array_equal(rids, got))
                 ncores = host_cores()
                 t = time.perf_counter()
-                mids, _ = o.knn_batch_all_cores(g, sp, Qd.cpu().numpy(), k, ef, ncores)
+                mids, _ = o.knn_batch_all_cores(g, sp_ref, Qall_h, k, ef, ncores)
                 mt_s = time.perf_counter() - t
                 checks["cpu_all_cores_ids_equal"] = bool(np.array_equal(mids, got))
-                cpu_baseline = {"value": round(sample / cpu_s, 1), "unit": "queries/s", "cores": 1, "kind": "port",
-                                "sample": "%d of the %d queries, same graph, ef=%d k=%d, single-thread C restatement "
-                                          "of Ohnsw.knn_batch_bigarray (not OCaml); the reference is single-threaded" % (sample, nq, ef, k),
+                cpu_baseline = {"value": round(nq / ref_s, 1), "unit": "queries/s", "cores": 1, "kind": "port",
+                                "sample": "all %d queries of one batch (%.1f s), same graph, ef=%d k=%d: single-thread C restatement of "
+                                          "Ohnsw.knn_batch_bigarray (not OCaml) with the reference's arithmetic (sequential fp32 "
+                                          "sum, sqrt in double); the reference is single-threaded" % (nq, ref_s, ef, k),
                                 "all_cores": {"value": round(nq / mt_s, 1), "cores": ncores,
                                               "sample": "all %d queries split over %d host threads" % (nq, ncores)}}
-            log("cpu restatement: %.1f q/s on %d queries; parity ids=%s dist=%s" %
-                (sample / cpu_s, sample, checks["parity_ids_equal"], checks["parity_dist_bits_equal"]))
+                log("cpu restatement (reference arithmetic): %.1f q/s single-thread, %.1f q/s on %d threads" % (nq / ref_s, nq / mt_s, ncores))
+            log("parity (kernel summation order) on %d queries: ids=%s dist=%s" %
+                (sample, checks["parity_ids_equal"], checks["parity_dist_bits_equal"]))
         # B_q = n_dist*(4d+4) + n_hops*4S + 4d + 8k   
         # B_q = n_dist*(4d+4) + n_hops*4S + 4d + 8k   for the whole query.  When the batch was
         # ordered longest-first the descent ran in its own kernel: the search kernel then does the layer-0
@@ -381,11 +577,11 @@ def main():
         ordered = prepass_ms > 0
         if ordered and n_upper_mean is not None:
             bq = (n_dist_mean - n_upper_mean) * (4 * d + 4) + n_hops_mean * 4 * S + 4 * d + 8 * k + 16
-            kernel_ms, kernel_name = search_ms, "hnsw_search_kernel<2,4,2,0>"
+            kernel_ms, kernel_name = search_ms, "hnsw_search_kernel<2,4,2,0,0,true>"
         elif ordered:      # no oracle counters: the pre-pass and the search kernel together
             bq, kernel_ms, kernel_name = bq_total, search_ms + prepass_ms, "hnsw_descent_kernel + radix sort + hnsw_search_kernel<2,4,2,0>"
         else:
-            bq, kernel_ms, kernel_name = bq_total, search_ms, "hnsw_search_kernel<2,4,2,0>"
+            bq, kernel_ms, kernel_name = bq_total, search_ms, "hnsw_search_kernel<2,4,2,0,0,true>"
         achieved = bq * nq / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
@@ -421,7 +617,10 @@ def main():
                                       ", RCCL all-gather of results" if world > 1 else ""),
                        "n": n, "d": d, "M": args.M, "ef_construction": args.efc, "ef": ef, "k": k,
                        "queries_per_gpu": nq, "global_batch": world * nq, "parallelism": "replica x%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "pipelined": pipelined, "checks": checks,
+            "protocol": "hnsw_search_batch_device: queries resident in HBM before the timed region, results left in HBM "
+                        "(the host-buffer drop-in call is timed in `drop_in`)",
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "drop_in": drop_in, "secondary": secondary,
+            "strong": strong, "pipelined": pipelined, "checks": checks,
         }
         _restore_stdout(saved_stdout)
         saved_stdout = None

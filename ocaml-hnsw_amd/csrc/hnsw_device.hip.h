@@ -332,11 +332,14 @@ __device__ __forceinline__ void tie_mark_expanded(const OvfStore &ov, int pos, i
 // exactly the distance kd (one more ballot says so) are the low halves compared -- that is also the only
 // case in which the node itself can already be in W.  The shift is a DPP wave_shr:1 per half and slot,
 // the new key then lands in its lane with v_writelane (no per-lane equality selects).
+// (Measured alternative, same results: deciding "my key is above K" per lane and selecting
+// mine / left neighbour / K without any scalar rank -- fewer scalar hand-offs but more vector
+// instructions; 4 % slower on an idle chip, 3 % on the 10 k batch.)
 template <int NSLOT, int SEM = 0>
 __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint32_t kid, int lane,
                                              const OvfStore &ov, uint32_t &status) {
     const uint32_t klo = (kid + 1u) << 1;
-    int p = 0, first = 0;
+    int p = 0;
     if (NSLOT <= 2) {
         uint64_t eq[NSLOT];
         bool tie = false;
@@ -356,8 +359,8 @@ __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint3
             if (p != q) return;                   // already in W
         }
     } else {
-        // the slot holding the rank position: the first whose maximum is not below K
-        first = popc(ballot(w.smax_hi < kd || (w.smax_hi == kd && w.smax_lo < klo)));   // lanes >= NSLOT hold +inf
+        // the slot holding the rank position: the first whose maximum is not below K (slot maxima, one per lane)
+        const int first = popc(ballot(w.smax_hi < kd || (w.smax_hi == kd && w.smax_lo < klo)));   // lanes >= NSLOT hold +inf
         int q = 0;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
@@ -567,28 +570,32 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
             for (int i = 0; i < NCH; ++i) v[b][i] = *reinterpret_cast<const float4 *>(row + coff[i]);
         }
     }
+    // every load above is issued before the first is consumed: without this fence the scheduler may sink
+    // the later loads below the first batches' arithmetic to save registers, which turns one memory round
+    // trip per round into several (measured on the ragged-row inner-product variant: +50 % per query)
+    __builtin_amdgcn_sched_barrier(0);
     uint32_t kk = KEY_INF, ii = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            float4 z = v[b][i];
-            if (!FULL) {  // lanes past the row end: make them add exactly 0 (their qv is 0)
-                const bool cv = (i * 16 + l16) < iv.nchunks;
-                z.x = cv ? z.x : 0.f; z.y = cv ? z.y : 0.f; z.z = cv ? z.z : 0.f; z.w = cv ? z.w : 0.f;
-            }
+            const float4 z = v[b][i];
+            float t = acc;
             if (METRIC == 0) {
-                float dx = z.x - qv[i].x; acc = __builtin_fmaf(dx, dx, acc);
-                float dy = z.y - qv[i].y; acc = __builtin_fmaf(dy, dy, acc);
-                float dz = z.z - qv[i].z; acc = __builtin_fmaf(dz, dz, acc);
-                float dw = z.w - qv[i].w; acc = __builtin_fmaf(dw, dw, acc);
+                float dx = z.x - qv[i].x; t = __builtin_fmaf(dx, dx, t);
+                float dy = z.y - qv[i].y; t = __builtin_fmaf(dy, dy, t);
+                float dz = z.z - qv[i].z; t = __builtin_fmaf(dz, dz, t);
+                float dw = z.w - qv[i].w; t = __builtin_fmaf(dw, dw, t);
             } else {
-                acc = __builtin_fmaf(z.x, qv[i].x, acc);
-                acc = __builtin_fmaf(z.y, qv[i].y, acc);
-                acc = __builtin_fmaf(z.z, qv[i].z, acc);
-                acc = __builtin_fmaf(z.w, qv[i].w, acc);
+                t = __builtin_fmaf(z.x, qv[i].x, t);
+                t = __builtin_fmaf(z.y, qv[i].y, t);
+                t = __builtin_fmaf(z.z, qv[i].z, t);
+                t = __builtin_fmaf(z.w, qv[i].w, t);
             }
+            // lanes past the row end re-read chunk 0: their chunk's contribution is dropped whole (one select
+            // per chunk; the sum a lane keeps is exactly the sum over its valid chunks)
+            acc = (FULL || (i * 16 + l16) < iv.nchunks) ? t : acc;
         }
         const uint32_t key = dist_to_key<METRIC>(reduce16(acc));
         const bool here = l16 == b;
@@ -601,9 +608,17 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
 
 // The rounds of one hop.  Accept test of lib/ohnsw.ml:574 in row order (= ascending lane), each candidate
 // against the CURRENT W.
+#ifdef HNSW_PHASE_TIMING   // measurement build: shader-clock cycles per phase, summed over the query's hops
+struct PhaseClock { uint64_t t[4] = {0, 0, 0, 0}, mark = 0; };
+#define HNSW_PHASE(pc, i) do { const uint64_t tn__ = clock64(); (pc).t[i] += tn__ - (pc).mark; (pc).mark = tn__; } while (0)
+#else
+struct PhaseClock {};
+#define HNSW_PHASE(pc, i) do { } while (0)
+#endif
+
 template <int NCH, int RB, int NSLOT, int METRIC, int SEM, bool FULL>
 __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)[NCH], WList<NSLOT> &w,
-                                         const WaveCtx &cx, int cnt, uint32_t &status) {
+                                         const WaveCtx &cx, int cnt, uint32_t &status, PhaseClock &pc) {
     const int lane = cx.lane;
     for (int base = 0; base < cnt;) {
         const int nbb = (cnt - base + 3) >> 2;   // wave-uniform
@@ -614,6 +629,10 @@ __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)
         else if (RB >= 2 && nbb >= 2) { hop_round<NCH, (RB >= 2 ? 2 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 8; }
         else { hop_round<NCH, 1, METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 4; }
         uint64_t pass = ballot(SEM ? ckey <= w.wmax : ckey < w.wmax);
+#ifdef HNSW_PHASE_TIMING
+        asm volatile("" :: "s"(pass));
+#endif
+        HNSW_PHASE(pc, 2);                                               // ids from LDS, row loads, arithmetic, keys, accept ballot
         while (pass) {
             const int i = __builtin_ctzll(pass);
             pass &= pass - 1;
@@ -659,11 +678,9 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     const int lane = cx.lane;
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
     int pref_id = -1, pref_nb = -1;
-#ifdef HNSW_PHASE_TIMING   // measurement build: shader-clock cycles per phase, summed over the query's hops
-    uint64_t tp0 = 0, tp1 = 0, tmark = clock64();
-#define HNSW_PHASE(acc) do { const uint64_t tn__ = clock64(); acc += tn__ - tmark; tmark = tn__; } while (0)
-#else
-#define HNSW_PHASE(acc) do { } while (0)
+    PhaseClock pc;
+#ifdef HNSW_PHASE_TIMING
+    pc.mark = clock64();
 #endif
     for (;;) {
         uint64_t um[NSLOT];
@@ -712,11 +729,15 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         const bool fresh = (nb >= 0) & !seen;
         const uint64_t m = ballot(fresh);
         const int cnt = popc(m);
+#ifdef HNSW_PHASE_TIMING
+        asm volatile("" :: "s"(m));
+#endif
+        HNSW_PHASE(pc, 0);                                               // pop + adjacency row + visited filter
         // issued only now so that it shares its flight with this hop's rows (loads return in order)
         int pidx;
         pref_id = wlist_take_first(w, um, pidx);                         // the next nearest unexpanded
         if (pref_id >= 0) pref_nb = adj_entry(iv, layer, pref_id, lane);
-        if (cnt == 0) { HNSW_PHASE(tp0); continue; }
+        if (cnt == 0) { HNSW_PHASE(pc, 0); continue; }
         const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
         __syncthreads();
         if (fresh) {                                                     // Visited.add, :572
@@ -725,15 +746,15 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         }
         __syncthreads();
         n_dist += cnt;
-        HNSW_PHASE(tp0);                                                 // pop + adjacency + filter + compaction
-        if (ROWS == 1 || (ROWS < 0 && full_rows)) hop_eval<NCH, RB, NSLOT, METRIC, SEM, true>(iv, qv, w, cx, cnt, status);   // :573-577
-        else hop_eval<NCH, RB, NSLOT, METRIC, SEM, false>(iv, qv, w, cx, cnt, status);
-        HNSW_PHASE(tp1);                                                 // rows + arithmetic + accept tests + insertions
+        HNSW_PHASE(pc, 1);                                               // prefetch issue + compaction through LDS
+        if (ROWS == 1 || (ROWS < 0 && full_rows)) hop_eval<NCH, RB, NSLOT, METRIC, SEM, true>(iv, qv, w, cx, cnt, status, pc);   // :573-577
+        else hop_eval<NCH, RB, NSLOT, METRIC, SEM, false>(iv, qv, w, cx, cnt, status, pc);
+        HNSW_PHASE(pc, 3);                                               // insertions
     }
-#ifdef HNSW_PHASE_TIMING
-    n_dist = (uint32_t)tp0; n_hops = (uint32_t)tp1; status = 0;   // reported through the counters
+#ifdef HNSW_PHASE_TIMING   // reported through the counters: n_dist = phase 0, n_hops = phase 2, status = phase 3 (20 bits) | phase 1 / 64 (12 bits)
+    n_dist = (uint32_t)pc.t[0]; n_hops = (uint32_t)pc.t[2];
+    { const uint64_t t1 = pc.t[1] >> 6; status = ((uint32_t)pc.t[3] & 0xFFFFFu) | ((uint32_t)(t1 > 4095 ? 4095 : t1) << 20); }
 #endif
-#undef HNSW_PHASE
 }
 
 template <int NCH>

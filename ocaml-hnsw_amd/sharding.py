@@ -71,3 +71,31 @@ def all_gather_results(dist, ids, dists, counts=None):
     dist.all_gather(li, pad_i)
     dist.all_gather(ld, pad_d)
     return (torch.cat([t[:c] for t, c in zip(li, counts)]), torch.cat([t[:c] for t, c in zip(ld, counts)]))
+
+
+def sharded_search(dist, search_shard, nq, k):
+    """One sharded pass over a global batch of `nq` queries: this rank searches its contiguous shard
+    (search_shard(lo, hi) -> (ids [hi-lo][k] int32, dists [hi-lo][k] fp32) as torch tensors on the
+    backend's device), then one all-gather leaves the full [nq][k] result on every rank.
+    bench.py's strong-scaling leg and the gloo tests run exactly this function."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_bounds(nq, world, rank)
+    ids, dd = search_shard(lo, hi)
+    counts = [shard_bounds(nq, world, r)[1] - shard_bounds(nq, world, r)[0] for r in range(world)]
+    return all_gather_results(dist, ids, dd, counts)
+
+
+def assert_same_on_all_ranks(dist, dev, tensors):
+    """Every rank generated its own copy of the synthetic data: compare a checksum of each tensor
+    (float64 sum and a strided sample's sum) across ranks and fail loudly on any difference."""
+    import torch
+    world = dist.get_world_size()
+    for name, t in tensors.items():
+        flat = t.reshape(-1)
+        sig = torch.stack([flat.double().sum(), flat[::max(1, flat.numel() // 65536)].double().mul(1.000001).sum(),
+                           torch.tensor(float(flat.numel()), dtype=torch.float64, device=flat.device)]).to(dev)
+        gathered = [torch.empty_like(sig) for _ in range(world)]
+        dist.all_gather(gathered, sig)
+        for r, g in enumerate(gathered):
+            if not torch.equal(g, gathered[0]):
+                raise RuntimeError("rank %d holds different %s than rank 0 (checksums %s vs %s)" % (r, name, g.tolist(), gathered[0].tolist()))

@@ -47,10 +47,22 @@ def _worker(rank, world, port, nq, tmp):
             hg.deg0, hg.nbr0, hg.upper = g0.deg0, g0.nbr0, g0.upper
         deg0, nbr0, upper, entry = sh.replicate_graph(dist, torch.device("cpu"), hg, M)
         g = o.Graph(len(deg0), entry, deg0, nbr0, upper)
-        lo, hi = sh.shard_bounds(nq, world, rank)
-        ids, dd = o.Ohnsw.knn_batch_bigarray(g, sp, Q[lo:hi], k=5, ef=20, ties=o.TIES_CANONICAL)
-        counts = [sh.shard_bounds(nq, world, r)[1] - sh.shard_bounds(nq, world, r)[0] for r in range(world)]
-        ai, ad = sh.all_gather_results(dist, torch.from_numpy(ids), torch.from_numpy(dd), counts)
+        sh.assert_same_on_all_ranks(dist, torch.device("cpu"), {"X": torch.from_numpy(X), "Q": torch.from_numpy(Q)})
+
+        def search_shard(lo, hi):   # the per-shard search: the CPU oracle here, the HIP kernel in bench.py
+            ids, dd = o.Ohnsw.knn_batch_bigarray(g, sp, Q[lo:hi], k=5, ef=20, ties=o.TIES_CANONICAL)
+            return torch.from_numpy(ids), torch.from_numpy(dd)
+        ai, ad = sh.sharded_search(dist, search_shard, nq, 5)    # the function bench.py's strong-scaling leg runs
+        if rank == world - 1:      # a rank with different data must be caught
+            bad = X.copy(); bad[0, 0] += 1.0
+        else:
+            bad = X
+        caught = False
+        try:
+            sh.assert_same_on_all_ranks(dist, torch.device("cpu"), {"X": torch.from_numpy(bad)})
+        except RuntimeError:
+            caught = True
+        assert caught, "differing replicas were not detected"
         if rank == 0:
             fi, fd = o.Ohnsw.knn_batch_bigarray(g0, sp, Q, k=5, ef=20, ties=o.TIES_CANONICAL)
             ok = np.array_equal(ai.numpy(), fi) and np.array_equal(ad.numpy().view(np.uint32), fd.view(np.uint32))
