@@ -19,7 +19,7 @@
  *   hnsw_search_one_batch    Ohnsw.search_one (lib/ohnsw.ml:492-512), Search.search_one
  *                            (lib/hnsw_algo.ml:393-437)
  *   hnsw_search_submit/_wait the same batch call in two halves (several batches in flight)
- *   hnsw_multi_*             the batch entry point over several GPUs from one host process
+ *   hnsw_multi_*             the batch entry point over several GPUs from one host process (RCCL all-gather)
  *   hnsw_distance_batch      Ohnsw.distance_l2 / EuclideanBa.distance (lib/ohnsw.ml:899,
  *                            lib/hnsw.ml:809-815) as timed by bench_dist/bench_dist.ml:22-33
  *
@@ -218,12 +218,19 @@ int32_t hnsw_search_one_batch(hnsw_index *idx, int32_t layer, const float *targe
                               float *out_dist);
 
 /* ---- one host process, several GPUs ------------------------------------------------
- * The index is REPLICATED on every listed device (a device may be listed more than once); a
- * query batch is split into n_devices contiguous shards [g*nq/G, (g+1)*nq/G), each searched on
- * its own device by its own host thread, and the results land in the caller's arrays at the
- * shard's offset -- bit-identical to hnsw_search_batch on one device (each query is an
- * independent traversal, lib/ohnsw.ml:883-895).  No collective: the outputs are host buffers.
- * (One process PER GPU with RCCL all-gather of device-resident results is the other deployment:
+ * An OCaml program is ONE process: this is the form of BASELINE.json's "replicated index, query batch
+ * sharded across the GPUs of one node, RCCL all-gather of per-shard results over xGMI" it can reach.
+ * The index is REPLICATED on every listed device; a query batch is split into n_devices contiguous
+ * shards [g*nq/G, (g+1)*nq/G), shard g is uploaded to and searched on device g (all devices
+ * concurrently, one HIP stream each), and ONE exchange -- ncclAllGather on communicators from
+ * ncclCommInitAll (in-place; unequal shards: one ncclBroadcast per shard inside the same group) --
+ * leaves the full [nq][k] ids and distances resident on EVERY device.  Results are bit-identical to
+ * hnsw_search_batch on one device (each query is an independent traversal, lib/ohnsw.ml:883-895), the
+ * exactness fallback for tie-list overflow runs per shard before the exchange.
+ * RCCL is bound at first use (dlopen librccl.so.1).  A device may be listed more than once (several
+ * replicas on one GPU: a test arrangement); RCCL refuses that, the exchange is then device-to-device
+ * copies.  The caller's host arrays are pinned (hipHostRegister) on first sight and stay pinned until
+ * hnsw_multi_destroy.  (One process PER GPU, each with its own RCCL rank, is the other deployment:
  * ocaml-hnsw_amd/sharding.py and bench.py.) */
 typedef struct hnsw_multi hnsw_multi;
 int32_t hnsw_multi_create(const hnsw_index_desc *desc, const int32_t *devices, int32_t n_devices,
@@ -232,9 +239,19 @@ int32_t hnsw_multi_destroy(hnsw_multi *m);
 int32_t hnsw_multi_num_replicas(const hnsw_multi *m, int32_t *n_devices);
 /* replica g (borrowed: destroyed with the hnsw_multi) */
 int32_t hnsw_multi_replica(hnsw_multi *m, int32_t g, hnsw_index **out);
+/* Ohnsw.knn_batch_bigarray / Hnsw.Ba.knn_batch over all replicas, host arrays in and out: the host
+ * receives the table from one device after the exchange. */
 int32_t hnsw_multi_search_batch(hnsw_multi *m, const float *queries, int64_t nq, int64_t q_stride,
                                 const hnsw_search_params *params, int32_t *out_ids, float *out_dist,
                                 uint32_t *out_ndist, uint32_t *out_nhops);
+/* The same with the results left on the devices: on return (synchronised) d_ids[g] / d_dist[g],
+ * g < n_devices, point to device g's copy of the full [nq][k] table (library-owned, valid until the
+ * next search on this handle).  d_ids / d_dist are caller arrays of n_devices pointers (either may be
+ * NULL). */
+int32_t hnsw_multi_search_batch_device(hnsw_multi *m, const float *queries, int64_t nq, int64_t q_stride,
+                                       const hnsw_search_params *params, int32_t **d_ids, float **d_dist);
+/* device g's copy of the last device-resident result, copied to host arrays [nq][k] (tests, debugging) */
+int32_t hnsw_multi_copy_result(hnsw_multi *m, int32_t g, int32_t *out_ids, float *out_dist);
 
 /* ---- graph construction on the device (next-row scope: the reference's builder stays OCaml;
  * this entry point exists so an index can also be produced where no OCaml build is at hand,

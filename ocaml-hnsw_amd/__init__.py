@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "hnsw_search_layer_batch", "hnsw_search_one_batch",
     "hnsw_search_submit", "hnsw_search_wait", "hnsw_index_kernel_times",
     "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
+    "hnsw_multi_search_batch_device", "hnsw_multi_copy_result",
 ]
 
 
@@ -138,8 +139,11 @@ def load():
     L.hnsw_multi_num_replicas.argtypes = [vp, vp]
     L.hnsw_multi_replica.argtypes = [vp, i32, vp]
     L.hnsw_multi_search_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp]
+    L.hnsw_multi_search_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp]
+    L.hnsw_multi_copy_result.argtypes = [vp, i32, vp, vp]
     for f in ("hnsw_search_layer_batch", "hnsw_search_one_batch", "hnsw_multi_create", "hnsw_multi_destroy",
-              "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch"):
+              "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
+              "hnsw_multi_search_batch_device", "hnsw_multi_copy_result"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -567,6 +571,28 @@ class MultiHgraph:
     def knn_batch_bigarray(self, k, batch, ef=None, counters=False):
         """Ohnsw.knn_batch_bigarray over all replicas (lib/ohnsw.ml:877-897)."""
         return self._search(batch, k if ef is None else ef, k, FILL_OHNSW, SEM_OHNSW, counters)
+
+    def search_device(self, batch, ef, k, fill=FILL_OHNSW, sem=SEM_OHNSW):
+        """hnsw_multi_search_batch_device: sharded search + RCCL all-gather, results left on the devices.
+        -> (d_ids, d_dist): per-device pointers (ints) to each device's full [nq][k] table."""
+        Q, qs = _rows(batch)
+        if Q.ndim != 2 or Q.shape[0] < 1 or Q.shape[1] != self.hgraph.d:
+            raise InvalidArgument("batch must be [nq][d], nq >= 1")
+        G = len(self.devices)
+        pi = (_C.c_void_p * G)()
+        pd = (_C.c_void_p * G)()
+        p = _SearchParams(ef, k, fill, sem)
+        _check(load().hnsw_multi_search_batch_device(self._h, _ptr(Q), Q.shape[0], max(qs, self.hgraph.d), _C.byref(p), pi, pd))
+        self._last = (Q.shape[0], k)
+        return [int(x or 0) for x in pi], [int(x or 0) for x in pd]
+
+    def copy_result(self, g):
+        """device g's copy of the last search_device result -> (ids, dist) host arrays"""
+        nq, k = self._last
+        ids = _np.empty((nq, k), _np.int32)
+        dist = _np.empty((nq, k), _np.float32)
+        _check(load().hnsw_multi_copy_result(self._h, int(g), _ptr(ids), _ptr(dist)))
+        return ids, dist
 
     def knn_batch(self, batch, num_neighbours_search, num_neighbours):
         """Hnsw.Ba.knn_batch over all replicas (lib/hnsw.ml:769-777)."""

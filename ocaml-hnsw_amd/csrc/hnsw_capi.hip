@@ -271,6 +271,27 @@ int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) 
     return fail(HNSW_ERR_BAD_ARG, "unknown option %s", name);
 }
 
+extern "C++" {
+namespace {
+int launch_search_args(hnsw_index *idx, SearchArgs &a, hipStream_t st);
+}
+namespace hnsw_host {
+int search_check(const hnsw_index *idx, const hnsw_search_params *p) { return check_params(idx, p); }
+// the exactness fallback's launch: the `c` flagged queries listed in qmap are searched again with a global
+// slab for their tie lists; results overwrite their rows of d_ids / d_dist (launched on the null stream)
+int search_rerun_device(hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, const hnsw_search_params *p,
+                        int32_t *d_ids, float *d_dist, uint32_t *d_nd, uint32_t *d_nh, uint32_t *d_st,
+                        const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap, hipStream_t st) {
+    SearchArgs a{};
+    a.Q = d_queries; a.q_stride = q_stride; a.nq = c; a.ef = p->ef; a.k = p->k;
+    a.fill = p->fill; a.sem = p->semantics;
+    a.vt_bits = search_vt_bits(idx, p->ef);
+    a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_nd; a.out_nhops = d_nh; a.out_status = d_st;
+    a.qmap = qmap; a.q_limit = nq; a.ovf_g = slab; a.ovf_gcap = cap;
+    return launch_search_args(idx, a, st);
+}
+} // namespace hnsw_host
+} // extern "C++"
 namespace {
 int launch_search_args(hnsw_index *idx, SearchArgs &a, hipStream_t st) {
     const int nch = pick_nch(idx->iv.nchunks), nslot = pick_nslot(a.ef);
@@ -383,14 +404,9 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
     int64_t n_rerun = 0;
     rc = rerun_overflowed(idx, nq, (const uint32_t *)idx->sSt.p,
                           [&](const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap) {
-                              SearchArgs a{};
-                              a.Q = dQ; a.q_stride = q_stride; a.nq = c; a.ef = params->ef; a.k = k;
-                              a.fill = params->fill; a.sem = params->semantics;
-                              a.vt_bits = search_vt_bits(idx, params->ef);
-                              a.out_ids = (int32_t *)idx->sIds.p; a.out_dist = (float *)idx->sDist.p;
-                              a.out_ndist = (uint32_t *)idx->sNd.p; a.out_nhops = (uint32_t *)idx->sNh.p; a.out_status = (uint32_t *)idx->sSt.p;
-                              a.qmap = qmap; a.q_limit = nq; a.ovf_g = slab; a.ovf_gcap = cap;
-                              return launch_search_args(idx, a, nullptr);
+                              return search_rerun_device(idx, dQ, nq, q_stride, params, (int32_t *)idx->sIds.p, (float *)idx->sDist.p,
+                                                         (uint32_t *)idx->sNd.p, (uint32_t *)idx->sNh.p, (uint32_t *)idx->sSt.p,
+                                                         qmap, c, slab, cap, nullptr);
                           }, &n_rerun);
     if (rc) return rc;
     if (n_rerun > 0) {
@@ -446,14 +462,9 @@ int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uin
     // exactness fallback for queries whose tie-overflow stack outgrew its LDS slots (as in hnsw_search_batch)
     int rc = rerun_overflowed(idx, nq, (const uint32_t *)r->st.p,
                               [&](const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap) {
-                                  SearchArgs a{};
-                                  a.Q = (const float *)r->q.p; a.q_stride = r->q_stride; a.nq = c; a.ef = r->params.ef; a.k = k;
-                                  a.fill = r->params.fill; a.sem = r->params.semantics;
-                                  a.vt_bits = search_vt_bits(idx, r->params.ef);
-                                  a.out_ids = (int32_t *)r->ids.p; a.out_dist = (float *)r->dist.p;
-                                  a.out_ndist = (uint32_t *)r->nd.p; a.out_nhops = (uint32_t *)r->nh.p; a.out_status = (uint32_t *)r->st.p;
-                                  a.qmap = qmap; a.q_limit = nq; a.ovf_g = slab; a.ovf_gcap = cap;
-                                  return launch_search_args(idx, a, st);
+                                  return search_rerun_device(idx, (const float *)r->q.p, nq, r->q_stride, &r->params, (int32_t *)r->ids.p,
+                                                             (float *)r->dist.p, (uint32_t *)r->nd.p, (uint32_t *)r->nh.p, (uint32_t *)r->st.p,
+                                                             qmap, c, slab, cap, st);
                               });
     if (rc) return done(rc);
     hipError_t e = hipMemcpyAsync(out_ids, r->ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st);

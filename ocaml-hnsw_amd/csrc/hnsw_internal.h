@@ -105,6 +105,14 @@ int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, i
                         void **block, const int32_t **qmap, const int32_t **pre_entry, const uint32_t **pre_key,
                         const uint32_t **pre_nd, int32_t *pre_layer);
 
+// parameter / handle checks shared by every search entry point (HNSW_ERR_BAD_ARG, HNSW_ERR_EMPTY_INDEX, ...)
+int search_check(const ::hnsw_index *idx, const hnsw_search_params *p);
+// launch of the exactness fallback (see rerun_overflowed): `c` flagged queries, listed in qmap, searched again
+// with a global slab for their tie lists
+int search_rerun_device(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, const hnsw_search_params *p,
+                        int32_t *d_ids, float *d_dist, uint32_t *d_nd, uint32_t *d_nh, uint32_t *d_st,
+                        const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap, hipStream_t st);
+
 // log2 entries of the per-query LDS visited cache (never changes results)
 inline int search_vt_bits(const hnsw_index *idx, int ef) {
     int b = idx->vt_bits_override ? idx->vt_bits_override : env_int("HNSW_VT_BITS", 0);

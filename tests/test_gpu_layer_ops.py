@@ -199,6 +199,31 @@ def test_multi_device_replicas_equal_single_device(H, oracle, built):
     multi1.release()
 
 
+def test_multi_rccl_exchange_leaves_the_full_result_on_every_device(H, oracle, built):
+    """hnsw_multi_search_batch_device: sharded search, then the exchange -- ncclAllGather on communicators
+    from ncclCommInitAll -- leaves the full [nq][k] table on every device.  The box has one GPU, so the RCCL
+    path runs at communicator size 1 (devices [0]: ncclCommInitAll, group, ncclAllGather / ncclBroadcast
+    are all really called); three replicas on device 0 exercise the shard layout and the unequal-shard
+    case through the same-device copy exchange."""
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    rng = np.random.default_rng(5)
+    one = H.MultiHgraph(hg, [0])
+    three = H.MultiHgraph(hg, [0, 0, 0])
+    for nq in (1, 3, 64, 301):
+        Q = (X[rng.integers(0, g.n, nq)] + rng.integers(0, 2, size=(nq, X.shape[1]))).astype(np.float32)
+        want_i, want_d = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=48)
+        for multi in (one, three):
+            d_ids, d_dist = multi.search_device(Q, 48, 10)
+            assert all(d_ids) and all(d_dist) and len(d_ids) == multi.num_replicas()
+            for r in range(multi.num_replicas()):
+                gi, gd = multi.copy_result(r)
+                np.testing.assert_array_equal(gi, want_i)
+                np.testing.assert_array_equal(gd.view(np.uint32), want_d.view(np.uint32))
+    one.release()
+    three.release()
+
+
 def test_multi_device_errors(H, oracle, built):
     X, sp, g = built
     hg = _hgraph(H, X, g, M=6)
