@@ -78,6 +78,19 @@ hipError_t dispatch_k4(int nch, const BuildView &bv, const MergeArgs &ma, hipStr
     return hipGetLastError();
 }
 
+template <int METRIC>
+hipError_t dispatch_link(int nch, const BuildView &bv, const hnsw_dev::LinkArgs &la, hipStream_t st) {
+    dim3 grid(1), block(64);
+    switch (nch) {
+    case 1: hipLaunchKernelGGL((hnsw_dev::build_link_sequential_kernel<1, 8, METRIC>), grid, block, 0, st, bv, la); break;
+    case 2: hipLaunchKernelGGL((hnsw_dev::build_link_sequential_kernel<2, 4, METRIC>), grid, block, 0, st, bv, la); break;
+    case 4: hipLaunchKernelGGL((hnsw_dev::build_link_sequential_kernel<4, 2, METRIC>), grid, block, 0, st, bv, la); break;
+    case 8: hipLaunchKernelGGL((hnsw_dev::build_link_sequential_kernel<8, 1, METRIC>), grid, block, 0, st, bv, la); break;
+    default: hipLaunchKernelGGL((hnsw_dev::build_link_sequential_kernel<16, 1, METRIC>), grid, block, 0, st, bv, la); break;
+    }
+    return hipGetLastError();
+}
+
 #define HIP_TRY_B(expr)                                                                      \
     do {                                                                                     \
         hipError_t e__ = (expr);                                                             \
@@ -89,10 +102,12 @@ hipError_t dispatch_k4(int nch, const BuildView &bv, const MergeArgs &ma, hipStr
 
 } // namespace
 
-extern "C" {
-
-int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_stride,
-                   const hnsw_build_params *p, int32_t device, hnsw_index **out) {
+// One attempt with a removal buffer of rem_scale * (2 * max_batch * 2M) entries; *rem_overflow tells the
+// caller that some step produced more removals than that (the graph is then discarded, never patched).
+static int32_t build_attempt(const float *vectors, int64_t n, int32_t d, int64_t row_stride,
+                             const hnsw_build_params *p, int32_t device, hnsw_index **out,
+                             int64_t rem_scale, bool *rem_overflow) {
+    *rem_overflow = false;
     if (!out || !p) return fail(HNSW_ERR_BAD_ARG, "null argument");
     *out = nullptr;
     if (n < 1 || n > 0x7FFFFFF0LL) return fail(HNSW_ERR_BAD_ARG, "n=%lld out of range", (long long)n);
@@ -138,6 +153,8 @@ int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_strid
     const int nslot = pick_nslot(efc);
     const int64_t maxrec = (int64_t)bmax * lcap;
     const int64_t max_edges = (int64_t)bmax * S0;
+    const int64_t rem_cap = max_edges * 2 * rem_scale;
+    uint32_t rem_over = 0;
     hipStream_t st = nullptr;
     void *dNodes = nullptr, *dRecOf = nullptr, *dRecNode = nullptr, *dCandId = nullptr, *dCandKey = nullptr,
          *dCandCnt = nullptr, *dEdges = nullptr, *dEdgesSorted = nullptr, *dRem = nullptr, *dRemCnt = nullptr, *dTemp = nullptr;
@@ -181,8 +198,9 @@ int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_strid
     HIP_TRY_B(hipMalloc(&dCandCnt, (size_t)maxrec * 4));
     HIP_TRY_B(hipMalloc(&dEdges, (size_t)max_edges * 8));
     HIP_TRY_B(hipMalloc(&dEdgesSorted, (size_t)max_edges * 8));
-    HIP_TRY_B(hipMalloc(&dRem, (size_t)max_edges * 2 * 8));
+    HIP_TRY_B(hipMalloc(&dRem, (size_t)rem_cap * 8));
     HIP_TRY_B(hipMalloc(&dRemCnt, 16));
+    HIP_TRY_B(hipMemset(dRemCnt, 0, 16));
     HIP_TRY_B(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, (uint64_t *)dEdges, (uint64_t *)dEdgesSorted, (int)max_edges, 0, 64, st));
     HIP_TRY_B(hipMalloc(&dTemp, std::max<size_t>(temp_bytes, 16)));
 
@@ -234,17 +252,25 @@ int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_strid
             sa.rec_node = (const int32_t *)dRecNode; sa.rec_begin = rb; sa.rec_end = re; sa.layer = l; sa.R = R;
             sa.edges = (uint64_t *)dEdges;
             HIP_TRY_B(p->metric == HNSW_METRIC_L2 ? dispatch_k2<0>(nch, bv, bt, sa, st) : dispatch_k2<1>(nch, bv, bt, sa, st));
+            if (B == 1) {
+                // a batch of one node: the link step of Ohnsw.insert exactly, neighbour by neighbour (:820-829)
+                hnsw_dev::LinkArgs la{};
+                la.q = (int32_t)pos; la.layer = l; la.R = R;
+                HIP_TRY_B(p->metric == HNSW_METRIC_L2 ? dispatch_link<0>(nch, bv, la, st) : dispatch_link<1>(nch, bv, la, st));
+                continue;
+            }
             const int n_edges = (re - rb) * R;
             size_t tb = temp_bytes;
             HIP_TRY_B(hipcub::DeviceRadixSort::SortKeys(dTemp, tb, (uint64_t *)dEdges, (uint64_t *)dEdgesSorted, n_edges, 0, 64, st));
             HIP_TRY_B(hipMemsetAsync(dRemCnt, 0, 4, st));
             MergeArgs ma{};
             ma.edges = (const uint64_t *)dEdgesSorted; ma.n_edges = n_edges; ma.layer = l; ma.R = R;
-            ma.removals = (uint64_t *)dRem; ma.rem_cnt = (uint32_t *)dRemCnt; ma.rem_cap = (uint32_t)(max_edges * 2);
+            ma.removals = (uint64_t *)dRem; ma.rem_cnt = (uint32_t *)dRemCnt; ma.rem_cap = (uint32_t)rem_cap;
             HIP_TRY_B(p->metric == HNSW_METRIC_L2 ? dispatch_k4<0>(nch, bv, ma, st) : dispatch_k4<1>(nch, bv, ma, st));
-            const unsigned rem_threads = (unsigned)std::min<int64_t>((int64_t)n_edges * 2, max_edges * 2);
+            // one thread per possible removal: the count is only known on the device (clamped to the buffer there)
+            const unsigned rem_threads = (unsigned)std::min<int64_t>(std::max<int64_t>((int64_t)n_edges * 2, 4096), rem_cap);
             hipLaunchKernelGGL(hnsw_dev::build_unlink_kernel, dim3((rem_threads + 255) / 256), dim3(256), 0, st, bv,
-                               (const uint64_t *)dRem, (const uint32_t *)dRemCnt, (uint32_t)(max_edges * 2), l);
+                               (const uint64_t *)dRem, (const uint32_t *)dRemCnt, (uint32_t)rem_cap, l);
             HIP_TRY_B(hipGetLastError());
         }
         if ((int)lvl[(size_t)(end - 1)] > cur_max) { cur_max = lvl[(size_t)(end - 1)]; entry = (int)(end - 1); } // :832-836
@@ -256,6 +282,8 @@ int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_strid
         hipLaunchKernelGGL(hnsw_dev::build_compact_kernel, dim3((unsigned)((rowsU + 3) / 4)), dim3(256), 0, st, (int32_t *)idx->dNbrU, rowsU, SU);
     HIP_TRY_B(hipGetLastError());
     HIP_TRY_B(hipStreamSynchronize(st));
+    HIP_TRY_B(hipMemcpy(&rem_over, (const uint32_t *)dRemCnt + 1, 4, hipMemcpyDeviceToHost));
+    if (rem_over) { *rem_overflow = true; rc = fail(HNSW_ERR_DEGREE_OVERFLOW, "a build step produced %u symmetric removals, more than the %lld the buffer holds", rem_over, (long long)rem_cap); goto done; }
 
     idx->iv.max_layer = cur_max; idx->iv.entry_point = entry;
     {
@@ -277,6 +305,23 @@ done:
     if (rc) { hnsw_index_destroy(idx); return rc; }
     *out = idx;
     return HNSW_OK;
+}
+
+extern "C" {
+
+int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_stride,
+                   const hnsw_build_params *p, int32_t device, hnsw_index **out) {
+    // Removals (links dropped when a neighbour's row is re-selected) are buffered per step; a step that
+    // produces more than the buffer holds invalidates the attempt -- a dropped removal would leave an
+    // asymmetric link, which Graph.Test.invariant (lib/ohnsw.ml:217-225) forbids -- and the build is repeated
+    // with four times the room (deterministic: same graph as if the buffer had been large from the start).
+    int32_t rc = HNSW_OK;
+    for (int64_t scale = 1; scale <= 64; scale *= 4) {
+        bool overflow = false;
+        rc = build_attempt(vectors, n, d, row_stride, p, device, out, scale, &overflow);
+        if (!overflow) return rc;
+    }
+    return rc;   // HNSW_ERR_DEGREE_OVERFLOW with the message of the last attempt
 }
 
 // ---- select_neighbours operator ----------------------------------------------------------------------

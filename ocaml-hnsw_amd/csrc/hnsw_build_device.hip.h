@@ -206,8 +206,11 @@ struct MergeArgs {
     uint32_t rem_cap;
 };
 
-constexpr int PEND_CAP = 64;
-
+// A neighbour's pending new links are merged 64 at a time (a hub can collect more than 64 in one batch of
+// up to 8192 insertions): each chunk is consed onto the row as the sequential builder would have consed
+// those nodes one after the other, and the row is re-selected whenever it outgrows its cap.
+// Removals that do not fit the buffer are counted in rem_cnt[1]: the host then repeats the build with a
+// larger buffer (nothing is ever dropped silently).
 template <int NCH, int RB, int METRIC>
 __global__ void __launch_bounds__(64)
 build_merge_kernel(const BuildView bv, const MergeArgs ma) {
@@ -226,72 +229,200 @@ build_merge_kernel(const BuildView bv, const MergeArgs ma) {
     const int nb = (int)(key >> 32);
     if (e > 0 && (int)(ma.edges[e - 1] >> 32) == nb) return;          // not the head of its segment
 
-    // pending new links of nb (ascending new-node id); beyond PEND_CAP they are refused
-    int np = 0;
-    {
-        const int j = e + lane;
-        const bool mine = j < ma.n_edges && (int)(ma.edges[j] >> 32) == nb && ma.edges[j] != ~0ull;
-        const uint64_t m = ballot(mine);
-        np = popc(m);                                               // contiguous from lane 0
-        if (mine) u_id[lane] = (int)(ma.edges[j] & 0xFFFFFFFFu);
-        for (int j2 = e + 64; j2 < ma.n_edges; ++j2) {                   // rare: hub with > 64 new links
-            const uint64_t k2 = ma.edges[j2];
-            if (k2 == ~0ull || (int)(k2 >> 32) != nb) break;
-            if (lane == 0) {
-                const uint32_t slot = atomicAdd(ma.rem_cnt, 1u);
-                if (slot < ma.rem_cap) ma.removals[slot] = ((k2 & 0xFFFFFFFFull) << 32) | (uint32_t)nb;
-            }
-        }
+    // the segment of nb: its pending new links, ascending new-node id
+    int np_total = 0;
+    for (int base = e;; base += 64) {
+        const int j = base + lane;
+        const bool mine = j < ma.n_edges && ma.edges[j] != ~0ull && (int)(ma.edges[j] >> 32) == nb;
+        const int c = popc(ballot(mine));
+        np_total += c;
+        if (c < 64) break;
     }
     int width;
     int32_t *row = row_ptr_w(bv, ma.layer, nb, width);
-    const int old = lane < width ? row[lane] : -1;
-    const bool ovalid = old >= 0;
-    const uint64_t om = ballot(ovalid);
-    const int no = popc(om);
-    const int opos = popc(om & ((1ull << lane) - 1ull));
-    __syncthreads();
-    if (ovalid) u_id[np + opos] = old;
-    __syncthreads();
-    const int nu = np + no;
-
-    if (nu <= ma.R) {
-        // Neighbours.add conses (lib/ohnsw.ml:116-118): the latest link comes first
-        int v = -1;
-        if (lane < np) v = u_id[np - 1 - lane];
-        else if (lane < nu) v = u_id[lane];
-        __syncthreads();
-        if (lane < width) row[lane] = v;
-        return;
-    }
-
-    // shrink (lib/ohnsw.ml:823-828): distances of the union to nb, ascending (d, id), heuristic
     float4 qv[NCH];
-    load_row<NCH>(qv, iv, nb, lane & 15);
-    eval_candidates<NCH, RB, METRIC>(iv, qv, u_id, u_key, trash, nu, lane >> 4, lane & 15);
-    __syncthreads();
-    for (int j = lane; j < nu; j += 64) {                               // rank sort, nu <= 128
-        const uint64_t mk = ((uint64_t)u_key[j] << 32) | (uint32_t)u_id[j];
-        int rank = 0;
-        for (int t = 0; t < nu; ++t) {
-            const uint64_t ok = ((uint64_t)u_key[t] << 32) | (uint32_t)u_id[t];
-            rank += ok < mk;
+    bool have_q = false;
+
+    for (int c0 = 0; c0 < np_total; c0 += 64) {
+        const int np = np_total - c0 < 64 ? np_total - c0 : 64;
+        __syncthreads();
+        if (lane < np) u_id[lane] = (int)(ma.edges[e + c0 + lane] & 0xFFFFFFFFu);
+        const int old = lane < width ? row[lane] : -1;
+        const bool ovalid = old >= 0;
+        const uint64_t om = ballot(ovalid);
+        const int no = popc(om);
+        const int opos = popc(om & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (ovalid) u_id[np + opos] = old;
+        __syncthreads();
+        const int nu = np + no;
+
+        if (nu <= ma.R) {
+            // Neighbours.add conses (lib/ohnsw.ml:116-118): the latest link comes first
+            int v = -1;
+            if (lane < np) v = u_id[np - 1 - lane];
+            else if (lane < nu) v = u_id[lane];
+            __syncthreads();
+            if (lane < width) row[lane] = v;
+        } else {
+            // shrink (lib/ohnsw.ml:823-828): distances of the union to nb, ascending (d, id), heuristic
+            if (!have_q) { load_row<NCH>(qv, iv, nb, lane & 15); have_q = true; }
+            for (int base = 0; base < nu; base += 64) {
+                const int m = nu - base < 64 ? nu - base : 64;
+                eval_candidates<NCH, RB, METRIC>(iv, qv, u_id + base, u_key + base, trash, m, lane >> 4, lane & 15);
+            }
+            __syncthreads();
+            for (int j = lane; j < nu; j += 64) {                               // rank sort, nu <= 128
+                const uint64_t mk = ((uint64_t)u_key[j] << 32) | (uint32_t)u_id[j];
+                int rank = 0;
+                for (int t = 0; t < nu; ++t) {
+                    const uint64_t ok = ((uint64_t)u_key[t] << 32) | (uint32_t)u_id[t];
+                    rank += ok < mk;
+                }
+                s_id[rank] = u_id[j];
+                s_key[rank] = u_key[j];
+            }
+            __syncthreads();
+            const int kept = select_heuristic<NCH, METRIC>(iv, s_id, s_key, nu, ma.R, k_id, lane);
+            __syncthreads();
+            if (lane < width) row[lane] = lane < kept ? k_id[kept - 1 - lane] : -1;
+            // dropped members lose their link to nb (Graph.set_connections step 2, lib/ohnsw.ml:190-192)
+            for (int j = lane; j < nu; j += 64) {
+                const int x = s_id[j];
+                bool in = false;
+                for (int t = 0; t < kept; ++t) in = in || (k_id[t] == x);
+                if (!in) {
+                    const uint32_t slot = atomicAdd(ma.rem_cnt, 1u);
+                    if (slot < ma.rem_cap) ma.removals[slot] = ((uint64_t)(uint32_t)x << 32) | (uint32_t)nb;
+                    else atomicMax(ma.rem_cnt + 1, slot + 1u);                   // the host repeats the build with more room
+                }
+            }
         }
-        s_id[rank] = u_id[j];
-        s_key[rank] = u_key[j];
+        if (c0 + 64 < np_total) { __threadfence(); __syncthreads(); }           // the next chunk reads the row just written
     }
+}
+
+// ---- sequential linking: the link step of Ohnsw.insert exactly (lib/ohnsw.ml:820-829) ---------------
+// Used for batches of ONE node (max_batch = 1, and the first insertions of every build): one wave walks
+// the new node's neighbours in list order, as the reference does, so the result is the reference's graph
+// link for link, list order included:
+//   * set_connections_for_new_node (:198-202): the new node q is consed onto every neighbour's list FIRST.
+//     A row has no room for a (cap + 1)-th entry, so that cons is kept virtual (vq[i]) until the neighbour
+//     is visited or one of its links is removed -- every reader below sees [q] + row;
+//   * Neighbours.iter neighbours (:821, a snapshot of q's list): a neighbour whose list is longer than the
+//     cap is re-selected from the min-queue of its neighbours (:791-798, :823-827) and set_connections
+//     (:182-196) stores the reduced list and removes the neighbour from every dropped node's list;
+//   * Neighbours.remove (:119-124) rebuilds the list by consing: the survivors end up in REVERSED order.
+// Rows stay compacted (no holes) in this mode.
+struct LinkArgs {
+    int32_t q, layer, R;
+};
+
+template <int NCH, int RB, int METRIC>
+__global__ void __launch_bounds__(64)
+build_link_sequential_kernel(const BuildView bv, const LinkArgs la) {
+    __shared__ int32_t it[64];        // snapshot of q's list
+    __shared__ int32_t vq[64];        // 1 while q still heads it[i]'s list only virtually
+    __shared__ int32_t u_id[128];
+    __shared__ uint32_t u_key[128];
+    __shared__ int32_t s_id[128];
+    __shared__ uint32_t s_key[128];
+    __shared__ int32_t k_id[64];
+    __shared__ uint32_t trash[64];
+    const IndexView &iv = bv.iv;
+    const int lane = threadIdx.x;
+    const int q = la.q, R = la.R;
+    int wq;
+    int32_t *qrow = row_ptr_w(bv, la.layer, q, wq);
+    const int qv0 = lane < wq ? qrow[lane] : -1;
+    const int len = popc(ballot(qv0 >= 0));                       // K2 wrote the list compacted, in list order
+    it[lane] = qv0;
+    vq[lane] = qv0 >= 0 ? 1 : 0;
     __syncthreads();
-    const int kept = select_heuristic<NCH, METRIC>(iv, s_id, s_key, nu, ma.R, k_id, lane);
-    __syncthreads();
-    if (lane < width) row[lane] = lane < kept ? k_id[kept - 1 - lane] : -1;
-    // dropped members lose their link to nb (Graph.set_connections step 2, lib/ohnsw.ml:190-192)
-    for (int j = lane; j < nu; j += 64) {
-        const int x = s_id[j];
-        bool in = false;
-        for (int t = 0; t < kept; ++t) in = in || (k_id[t] == x);
-        if (!in) {
-            const uint32_t slot = atomicAdd(ma.rem_cnt, 1u);
-            if (slot < ma.rem_cap) ma.removals[slot] = ((uint64_t)(uint32_t)x << 32) | (uint32_t)nb;
+
+    // list of node x as the reference sees it now -> u_id[0..n): [q] (if still virtual) + its row
+    auto read_list = [&](int x, int &virt_at) -> int {
+        const uint64_t vm = ballot(it[lane] == x && vq[lane] != 0);
+        virt_at = vm ? __builtin_ctzll(vm) : -1;
+        const int hasq = vm ? 1 : 0;
+        int w;
+        const int32_t *row = row_ptr_w(bv, la.layer, x, w);
+        const int old = lane < w ? row[lane] : -1;
+        const uint64_t om = ballot(old >= 0);
+        const int opos = popc(om & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (old >= 0) u_id[hasq + opos] = old;
+        if (hasq && lane == 0) u_id[0] = q;
+        __syncthreads();
+        return hasq + popc(om);
+    };
+    auto write_row = [&](int x, const int32_t *src, int n, bool reversed) {
+        int w;
+        int32_t *row = row_ptr_w(bv, la.layer, x, w);
+        const int val = lane < n ? src[reversed ? n - 1 - lane : lane] : -1;
+        __syncthreads();
+        if (lane < w) row[lane] = val;
+    };
+
+    for (int i = 0; i < len; ++i) {
+        const int nb = it[i];
+        int virt_at;
+        const int nu = read_list(nb, virt_at);
+        if (nu <= R) {                                              // :823 not over the cap
+            if (virt_at >= 0) {                                     // the cons of :202 becomes physical
+                write_row(nb, u_id, nu, false);
+                if (lane == 0) vq[virt_at] = 0;
+            }
+            __threadfence();
+            __syncthreads();
+            continue;
+        }
+        // :824-827 min_queue_of_neighbours + select_neighbours: distances of the list to nb, ascending (d, id)
+        float4 nv[NCH];
+        load_row<NCH>(nv, iv, nb, lane & 15);
+        for (int base = 0; base < nu; base += 64) {
+            const int m = nu - base < 64 ? nu - base : 64;
+            eval_candidates<NCH, RB, METRIC>(iv, nv, u_id + base, u_key + base, trash, m, lane >> 4, lane & 15);
+        }
+        __syncthreads();
+        for (int j = lane; j < nu; j += 64) {                       // rank sort, nu <= 65
+            const uint64_t mk = ((uint64_t)u_key[j] << 32) | (uint32_t)u_id[j];
+            int rank = 0;
+            for (int t = 0; t < nu; ++t) rank += ((((uint64_t)u_key[t] << 32) | (uint32_t)u_id[t]) < mk);
+            s_id[rank] = u_id[j];
+            s_key[rank] = u_key[j];
+        }
+        __syncthreads();
+        const int kept = select_heuristic<NCH, METRIC>(iv, s_id, s_key, nu, R, k_id, lane);
+        __syncthreads();
+        write_row(nb, k_id, kept, true);                            // the reference conses: list order = reverse selection order
+        if (lane == 0 && virt_at >= 0) vq[virt_at] = 0;
+        __threadfence();
+        __syncthreads();
+        // :190-192 every dropped node loses its link to nb; Neighbours.remove reverses what is left
+        for (int j = 0; j < nu; ++j) {
+            const int x = s_id[j];
+            bool in = false;
+            for (int t = 0; t < kept; ++t) in = in || (k_id[t] == x);
+            if (in) continue;                                       // uniform
+            int xv;
+            const int nx = read_list(x, xv);
+            // survivors, in list order, then reversed
+            const int e = lane < nx ? u_id[lane] : -1;
+            const uint64_t sm = ballot(lane < nx && e != nb);
+            const int spos = popc(sm & ((1ull << lane) - 1ull));
+            const int ns = popc(sm);
+            __syncthreads();
+            if (lane < nx && e != nb) s_key[spos] = (uint32_t)e;    // s_key is free here: reuse it as the survivor list
+            __syncthreads();
+            int w;
+            int32_t *xrow = row_ptr_w(bv, la.layer, x, w);
+            const int val = lane < ns ? (int32_t)s_key[ns - 1 - lane] : -1;
+            __syncthreads();
+            if (lane < w) xrow[lane] = val;
+            if (lane == 0 && xv >= 0) vq[xv] = 0;
+            __threadfence();
+            __syncthreads();
         }
     }
 }
@@ -372,16 +503,16 @@ select_neighbours_kernel(const IndexView iv, const SelectOpArgs sa) {
 // ---- K5: symmetric removals -------------------------------------------------------------------------
 __global__ void build_unlink_kernel(const BuildView bv, const uint64_t *removals, const uint32_t *rem_cnt,
                                     uint32_t rem_cap, int layer) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = *rem_cnt;
-    if (n > rem_cap) n = rem_cap;
-    if (t >= n) return;
-    const uint64_t rk = removals[t];
-    const int x = (int)(rk >> 32), nb = (int)(rk & 0xFFFFFFFFu);
-    int width;
-    int32_t *row = row_ptr_w(bv, layer, x, width);
-    for (int j = 0; j < width; ++j)
-        if (row[j] == nb) row[j] = -1;
+    if (n > rem_cap) n = rem_cap;      // the excess was counted in rem_cnt[1]: the host discards this attempt
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {   // the count is only known here
+        const uint64_t rk = removals[t];
+        const int x = (int)(rk >> 32), nb = (int)(rk & 0xFFFFFFFFu);
+        int width;
+        int32_t *row = row_ptr_w(bv, layer, x, width);
+        for (int j = 0; j < width; ++j)
+            if (row[j] == nb) row[j] = -1;
+    }
 }
 
 // ---- final: close the holes, keep row order ----------------------------------------------------------

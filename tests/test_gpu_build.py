@@ -208,3 +208,60 @@ def test_randomized_builds(H, oracle):
         ids, dist = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=max(k, 30))
         oi, od = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=k, ef=max(k, 30), ties=oracle.TIES_CANONICAL)
         assert np.array_equal(ids, oi) and np.array_equal(dist.view(np.uint32), od.view(np.uint32)), ctx
+
+
+@pytest.mark.parametrize("kind,metric,n,d,M,efc", [
+    ("uniform", 0, 3000, 16, 6, 40),        # generic position: no exact ties
+    ("levels", 0, 2500, 6, 8, 60),          # few distinct coordinates: exact distance ties everywhere
+    ("unit", 1, 3000, 24, 8, 50),           # inner product (distance 1 - <a,b>, negative values possible)
+    ("sift", 0, 2000, 128, 16, 100),        # the C2 shape: integer-valued, d = 128, M = 16
+])
+def test_sequential_build_equals_the_reference_insert_link_for_link(H, oracle, kind, metric, n, d, M, efc):
+    """max_batch = 1: every node is inserted on its own, and the link step runs neighbour by neighbour as
+    Ohnsw.insert does (lib/ohnsw.ml:766-837: set_connections_for_new_node, then the shrink of every
+    over-full neighbour in list order, Neighbours.remove reversing what it keeps).  The device-built graph
+    must then equal the oracle's restatement of that function -- entry point, max layer, layer membership,
+    and every adjacency list in ITERATION ORDER -- which pins the construction search, select_neighbours,
+    the back-link and the shrink kernels against the reference's own control flow."""
+    rng = np.random.default_rng(11)
+    if kind == "uniform":
+        X = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    elif kind == "levels":
+        X = rng.integers(0, 4, size=(n, d)).astype(np.float32)
+    elif kind == "unit":
+        X = rng.normal(size=(n, d))
+        X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+    else:
+        centres = rng.integers(20, 200, size=(32, d))
+        X = np.clip(np.rint(centres[rng.integers(0, 32, n)] + rng.normal(0, 25, size=(n, d))), 0, 218).astype(np.float32)
+    sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
+    want = oracle.build_ohnsw(sp, M, efc, seed=5, ties=oracle.TIES_CANONICAL)
+    hg = H.Ohnsw.build_batch_bigarray(X, M, efc, seed=5, metric=metric, max_batch=1).export()
+    assert hg.entry_point == want.entry_point
+    assert hg.max_layer == want.max_layer
+    np.testing.assert_array_equal(hg.deg0, want.deg0)
+    np.testing.assert_array_equal(hg.nbr0, want.nbr0)                      # rows in iteration order, -1 padded
+    assert len(hg.upper) == len(want.upper)
+    for (nodes, deg, nbr), (wn, wd, wb) in zip(hg.upper, want.upper):
+        np.testing.assert_array_equal(nodes, wn)
+        np.testing.assert_array_equal(deg, wd)
+        np.testing.assert_array_equal(nbr, wb)
+
+
+def test_hub_with_more_than_64_new_links_in_one_batch_stays_symmetric(H, oracle):
+    """One node close to everything collects far more than 64 back-links in a single batch: they are merged
+    64 at a time (nothing is refused or dropped), and the graph keeps the reference's invariants
+    (Graph.Test.invariant, lib/ohnsw.ml:217-225: symmetric links; degree caps)."""
+    rng = np.random.default_rng(3)
+    n, d, M = 6000, 32, 8
+    X = rng.normal(size=(n, d)).astype(np.float32) * 10
+    X[0] = 0.0
+    X[1:] /= np.linalg.norm(X[1:], axis=1, keepdims=True)                  # a shell around the hub at the origin: in 32
+    # dimensions two shell points are about sqrt(2) apart, so the hub (distance 1) is every node's nearest
+    # neighbour and every insertion of a batch links to it
+    hg = H.Ohnsw.build_batch_bigarray(X, M, 60, seed=2, max_batch=4096, batch_div=1).export()
+    sets = [set(hg.nbr0[i, :hg.deg0[i]].tolist()) for i in range(n)]
+    assert all(len(s) == hg.deg0[i] for i, s in enumerate(sets))            # no duplicates
+    assert all(i in sets[j] for i in range(n) for j in sets[i])             # symmetric
+    assert hg.deg0.max() <= 2 * M
+    assert hg.deg0[0] == 2 * M                                              # the hub's row is full, and was re-selected many times
