@@ -93,6 +93,15 @@ let hnsw_multi_search_batch =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_multi_search_batch"
     (multi @-> ptr float @-> int64_t @-> int64_t @-> ptr search_params @-> ptr int32_t @-> ptr float
      @-> ptr uint32_t @-> ptr uint32_t @-> returning int32_t)
+(* sharded search + RCCL all-gather, results left on every device: d_ids / d_dist are arrays of
+   n_devices device pointers written by the library *)
+let hnsw_multi_search_batch_device =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_multi_search_batch_device"
+    (multi @-> ptr float @-> int64_t @-> int64_t @-> ptr search_params @-> ptr (ptr int32_t) @-> ptr (ptr float)
+     @-> returning int32_t)
+let hnsw_multi_copy_result =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_multi_copy_result"
+    (multi @-> int32_t @-> ptr int32_t @-> ptr float @-> returning int32_t)
 
 (* Error convention -> the reference's exceptions (lib/ohnsw.ml:25,343,862) *)
 let check rc =
@@ -107,21 +116,42 @@ module A2 = Bigarray.Array2
 
 type flat = {
   deg0 : (int32, Bigarray.int32_elt, Bigarray.c_layout) A1.t;
-  nbr0 : (int32, Bigarray.int32_elt, Bigarray.c_layout) A2.t;   (* n x 2M, iteration order *)
+  nbr0 : (int32, Bigarray.int32_elt, Bigarray.c_layout) A2.t;   (* n x width0, iteration order *)
   upper : ((int64, Bigarray.int64_elt, Bigarray.c_layout) A1.t
            * (int32, Bigarray.int32_elt, Bigarray.c_layout) A1.t
            * (int32, Bigarray.int32_elt, Bigarray.c_layout) A2.t) array;
   entry_point : int;
   max_layer : int;
+  width0 : int;          (* row width of layer 0: 2M, or the longest list found *)
+  width_upper : int;     (* row width of the layers above: M, or the longest list found *)
 }
 
 (* Ohnsw.Hgraph.t (lib/ohnsw.ml:307-312): every layer is dense over all n nodes (:328-330);
    Graph.iter_neighbours (:176-180) walks nodes, Neighbours.iter (:127) walks a list head first --
    exactly the order search_k folds over (:570).  A list longer than its row raises: the C side
    would refuse it too (HNSW_ERR_DEGREE_OVERFLOW); nothing is ever truncated. *)
-let flatten_ohnsw (h : _ Ohnsw.Hgraph.t) ~num_connections:m : flat =
+(* The row widths: with ~num_connections:m they are the caps the builder guarantees (2m on layer 0, m
+   above, lib/ohnsw.ml:818-828); without it -- an Ohnsw.Hgraph.t does not record M -- they are the
+   longest list found on layer 0 / on the layers above (one pass over the lists). *)
+let ohnsw_widths (h : _ Ohnsw.Hgraph.t) =
+  let n = Ohnsw.Hgraph.num_nodes h in
+  let longest g =
+    let w = ref 1 in
+    for i = 0 to n - 1 do
+      w := max !w (Ohnsw.Neighbours.length (Ohnsw.Graph.adjacent g i))
+    done;
+    !w in
+  let w0 = longest (Ohnsw.Hgraph.layer h 0) in
+  let wu = ref 1 in
+  for l = 1 to Ohnsw.Hgraph.max_layer h do wu := max !wu (longest (Ohnsw.Hgraph.layer h l)) done;
+  w0, !wu
+
+let flatten_ohnsw ?num_connections (h : _ Ohnsw.Hgraph.t) : flat =
   let n = Ohnsw.Hgraph.num_nodes h in
   let max_layer = Ohnsw.Hgraph.max_layer h in
+  let width0, width_upper = match num_connections with
+    | Some m -> 2 * m, m
+    | None -> ohnsw_widths h in
   let row g node width (dst : (int32, _, _) A2.t) r =
     let nb = Ohnsw.Graph.adjacent g node in
     if Ohnsw.Neighbours.length nb > width then invalid_arg "flatten: degree exceeds row width";
@@ -130,10 +160,10 @@ let flatten_ohnsw (h : _ Ohnsw.Hgraph.t) ~num_connections:m : flat =
     !j
   in
   let deg0 = A1.create Bigarray.int32 Bigarray.c_layout n in
-  let nbr0 = A2.create Bigarray.int32 Bigarray.c_layout n (2 * m) in
+  let nbr0 = A2.create Bigarray.int32 Bigarray.c_layout n width0 in
   A2.fill nbr0 (-1l);
   let g0 = Ohnsw.Hgraph.layer h 0 in
-  for i = 0 to n - 1 do deg0.{i} <- Int32.of_int (row g0 i (2 * m) nbr0 i) done;
+  for i = 0 to n - 1 do deg0.{i} <- Int32.of_int (row g0 i width0 nbr0 i) done;
   let upper =
     Array.init max_layer (fun l ->
         let g = Ohnsw.Hgraph.layer h (l + 1) in
@@ -145,14 +175,14 @@ let flatten_ohnsw (h : _ Ohnsw.Hgraph.t) ~num_connections:m : flat =
         let c = List.length ids in
         let nodes = A1.create Bigarray.int64 Bigarray.c_layout c in
         let deg = A1.create Bigarray.int32 Bigarray.c_layout c in
-        let nbr = A2.create Bigarray.int32 Bigarray.c_layout c m in
+        let nbr = A2.create Bigarray.int32 Bigarray.c_layout c width_upper in
         A2.fill nbr (-1l);
         List.iteri (fun s i ->
             nodes.{s} <- Int64.of_int i;
-            deg.{s} <- Int32.of_int (row g i m nbr s)) ids;
+            deg.{s} <- Int32.of_int (row g i width_upper nbr s)) ids;
         (nodes, deg, nbr))
   in
-  { deg0; nbr0; upper; max_layer;
+  { deg0; nbr0; upper; max_layer; width0; width_upper;
     entry_point = (match Ohnsw.Hgraph.entry_point h with Some e -> e | None -> -1) }
 
 (* Hnsw.Ba.Hgraph.t (lib/hnsw.ml:342-348): layers = Map int -> MapGraph.t, a MapGraph holding
@@ -161,10 +191,23 @@ let flatten_ohnsw (h : _ Ohnsw.Hgraph.t) ~num_connections:m : flat =
    neighbours there (MapGraph.adjacent, lib/hnsw.ml:146-149).  NeighbourList.fold walks the list head
    first (lib/hnsw.ml:44-45), which is the order Search.search folds over (lib/hnsw_algo.ml:381-383).
    Pass the result to [create ~id_base:1]. *)
-let flatten_ba (h : Hnsw.Ba.Hgraph.t) ~num_connections:m : flat =
+let ba_widths (h : Hnsw.Ba.Hgraph.t) =
+  let module G = Hnsw.Ba.Hgraph in
+  let longest (g : Hnsw.MapGraph.t) =
+    Base.Map.fold g.Hnsw.MapGraph.connections ~init:1 ~f:(fun ~key:_ ~data w ->
+        max w (Hnsw.NeighbourList.length data)) in
+  let w0 = longest (G.layer h 0) in
+  let wu = ref 1 in
+  for l = 1 to G.max_layer h do wu := max !wu (longest (G.layer h l)) done;
+  w0, !wu
+
+let flatten_ba ?num_connections (h : Hnsw.Ba.Hgraph.t) : flat =
   let module G = Hnsw.Ba.Hgraph in
   let n = G.max_node_id h in                       (* = Values.length, lib/hnsw.ml:394 *)
   let max_layer = G.max_layer h in
+  let width0, width_upper = match num_connections with
+    | Some m -> 2 * m, m
+    | None -> ba_widths h in
   let fill_row (nl : Hnsw.NeighbourList.t) width (dst : (int32, _, _) A2.t) r =
     if Hnsw.NeighbourList.length nl > width then invalid_arg "flatten: degree exceeds row width";
     let j = ref 0 in
@@ -172,27 +215,61 @@ let flatten_ba (h : Hnsw.Ba.Hgraph.t) ~num_connections:m : flat =
     !j
   in
   let deg0 = A1.create Bigarray.int32 Bigarray.c_layout n in
-  let nbr0 = A2.create Bigarray.int32 Bigarray.c_layout n (2 * m) in
+  let nbr0 = A2.create Bigarray.int32 Bigarray.c_layout n width0 in
   A1.fill deg0 0l; A2.fill nbr0 (-1l);
   let g0 = G.layer h 0 in
   Base.Map.iteri g0.Hnsw.MapGraph.connections ~f:(fun ~key ~data ->
-      deg0.{key - 1} <- Int32.of_int (fill_row data (2 * m) nbr0 (key - 1)));
+      deg0.{key - 1} <- Int32.of_int (fill_row data width0 nbr0 (key - 1)));
   let upper =
     Array.init max_layer (fun l ->
         let g = G.layer h (l + 1) in
         let c = Base.Map.length g.Hnsw.MapGraph.connections in
         let nodes = A1.create Bigarray.int64 Bigarray.c_layout c in
         let deg = A1.create Bigarray.int32 Bigarray.c_layout c in
-        let nbr = A2.create Bigarray.int32 Bigarray.c_layout c m in
+        let nbr = A2.create Bigarray.int32 Bigarray.c_layout c width_upper in
         A2.fill nbr (-1l);
         let s = ref 0 in
         Base.Map.iteri g.Hnsw.MapGraph.connections ~f:(fun ~key ~data ->
             nodes.{!s} <- Int64.of_int key;
-            deg.{!s} <- Int32.of_int (fill_row data m nbr !s);
+            deg.{!s} <- Int32.of_int (fill_row data width_upper nbr !s);
             incr s);
         (nodes, deg, nbr))
   in
-  { deg0; nbr0; upper; max_layer; entry_point = G.entry_point h (* -1 when empty, lib/hnsw.ml:391 *) }
+  { deg0; nbr0; upper; max_layer; width0; width_upper;
+    entry_point = G.entry_point h (* -1 when empty, lib/hnsw.ml:391 *) }
+
+(* The inverse for the functor path: rebuild a Hnsw.Ba.Hgraph.t (lib/hnsw.ml:342-348) over the value
+   matrix from flattened tables with 1-based ids.  The record fields are the reference's own: layers is a
+   Map from layer to MapGraph.t = { connections : NeighbourList.t Map.M(Int).t; max_node_id }
+   (lib/hnsw.ml:122-135), a NeighbourList is { list; length } with the list in fold order (head first,
+   lib/hnsw.ml:33-45) -- the row order.  Nodes without links on a layer get no map entry, as
+   MapGraph.adjacent expects (lib/hnsw.ml:146-149); the tables hold symmetric links already. *)
+let unflatten_ba (values : Lacaml.S.mat) (f : flat) : Hnsw.Ba.Hgraph.t =
+  let n = Lacaml.S.Mat.dim2 values in
+  let list_of_row (nbr : (int32, _, _) A2.t) r deg =
+    let l = ref [] in
+    for j = deg - 1 downto 0 do l := Int32.to_int nbr.{r, j} :: !l done;
+    { Hnsw.NeighbourList.list = !l; length = deg } in
+  let graph_of rows =
+    { Hnsw.MapGraph.connections =
+        List.fold_left (fun m (node, nl) -> Base.Map.set m ~key:node ~data:nl)
+          (Base.Map.empty (module Base.Int)) rows;
+      max_node_id = n } in
+  let layer0 =
+    let rows = ref [] in
+    for i = A1.dim f.deg0 - 1 downto 0 do
+      let deg = Int32.to_int f.deg0.{i} in
+      if deg > 0 then rows := (i + 1, list_of_row f.nbr0 i deg) :: !rows
+    done;
+    graph_of !rows in
+  let layers = ref (Base.Map.set (Base.Map.empty (module Base.Int)) ~key:0 ~data:layer0) in
+  Array.iteri (fun l (nodes, deg, nbr) ->
+      let rows = ref [] in
+      for r = A1.dim nodes - 1 downto 0 do
+        rows := (Int64.to_int nodes.{r}, list_of_row nbr r (Int32.to_int deg.{r})) :: !rows
+      done;
+      layers := Base.Map.set !layers ~key:(l + 1) ~data:(graph_of !rows)) f.upper;
+  { Hnsw.Ba.Hgraph.layers = !layers; max_layer = f.max_layer; entry_point = f.entry_point; values }
 
 (* The inverse: rebuild an Ohnsw.Hgraph.t from the flattened tables (e.g. an index built on the device by
    hnsw_build and fetched with hnsw_index_export_*), so that the OCaml builder can keep inserting into
@@ -224,7 +301,7 @@ let unflatten_ohnsw (distance : 'a Ohnsw.distance) (value : 'a Ohnsw.value) (f :
 (* ---- device-resident index ------------------------------------------------------------------ *)
 type t = { handle : index; k_base : int; dim : int }
 
-let create ?(device = 0) ?(metric = 0) ~id_base ~num_connections:m (vectors : Lacaml.S.mat) (f : flat) : t =
+let create ?(device = 0) ?(metric = 0) ~id_base (vectors : Lacaml.S.mat) (f : flat) : t =
   (* a Lacaml.S.mat is a Fortran-layout dim x n Bigarray: in memory, n rows of dim floats *)
   let dim = A2.dim1 vectors and n = A2.dim2 vectors in
   let layers = CArray.make layer_desc (max 1 f.max_layer) in
@@ -239,7 +316,7 @@ let create ?(device = 0) ?(metric = 0) ~id_base ~num_connections:m (vectors : La
   setf d d_n (Int64.of_int n); setf d d_d (Int32.of_int dim);
   setf d d_row_stride (Int64.of_int dim);
   setf d d_metric (Int32.of_int metric); setf d d_id_base (Int32.of_int id_base);
-  setf d d_max_degree0 (Int32.of_int (2 * m)); setf d d_max_degree (Int32.of_int m);
+  setf d d_max_degree0 (Int32.of_int f.width0); setf d d_max_degree (Int32.of_int f.width_upper);
   setf d d_max_layer (Int32.of_int f.max_layer);
   setf d d_entry_point (Int64.of_int f.entry_point);
   setf d d_deg0 (bigarray_start array1 f.deg0); setf d d_nbr0 (bigarray_start array2 f.nbr0);
@@ -263,23 +340,123 @@ let search ?(semantics = 0) t (batch : Lacaml.S.mat) ~ef ~k ~fill =
            (bigarray_start array2 distances) (from_voidp uint32_t null) (from_voidp uint32_t null));
   ids, distances
 
+(* ---- from the reference's own index values, nothing else needed ----------------------------------- *)
+
+(* of_ohnsw : Lacaml.S.vec Ohnsw.Hgraph.t -> t.  An Ohnsw.Hgraph.t (lib/ohnsw.ml:307-312) holds no
+   matrix and no M: the vectors are gathered through its own [value : int -> Lacaml.S.vec] closure
+   (for a graph from build_batch_bigarray that is [fun i -> Mat.col batch (i+1)], :842) into a fresh
+   dim x n matrix, and the row widths are the longest lists found (ohnsw_widths). *)
+let of_ohnsw ?device ?metric (h : Lacaml.S.vec Ohnsw.Hgraph.t) : t =
+  let n = Ohnsw.Hgraph.num_nodes h in
+  if n = 0 then invalid_arg "knn: empty hgraph";                        (* lib/ohnsw.ml:862 *)
+  let value = Ohnsw.Hgraph.value h in
+  let dim = Lacaml.S.Vec.dim (value 0) in
+  let vectors = Lacaml.S.Mat.create dim n in
+  for i = 0 to n - 1 do
+    A1.blit (value i) (Lacaml.S.Mat.col vectors (i + 1))                (* node i <-> column i+1, :842 *)
+  done;
+  create ?device ?metric ~id_base:0 vectors (flatten_ohnsw h)
+
+(* of_ba : Hnsw.Ba.Hgraph.t -> t.  The functor path's Hgraph carries its value matrix
+   (values : BaValues.t = Lacaml.S.mat, lib/hnsw.ml:346 with :296-301); node ids are its columns (1-based). *)
+let of_ba ?device ?metric (h : Hnsw.Ba.Hgraph.t) : t =
+  if Hnsw.Ba.Hgraph.is_empty h then invalid_arg "knn: empty hgraph";
+  create ?device ?metric ~id_base:1 h.Hnsw.Ba.Hgraph.values (flatten_ba h)
+
+(* One device index per live hgraph: an association list of ephemerons keyed by the hgraph value itself
+   (physical equality), so an index is destroyed (Gc.finalise in [create]) once its hgraph is collected.
+   An Ohnsw.Hgraph.t is mutable -- the OCaml builder may keep inserting --, so an entry also records
+   (number of nodes, entry point, max layer) and is rebuilt when they no longer match: every insert adds a
+   node (lib/ohnsw.ml:766-772), so a changed graph always shows. *)
+type cached = { index : t; stamp : int * int * int }
+let cache : (Obj.t, cached) Ephemeron.K1.t list ref = ref []
+
+let cached_index (key : Obj.t) ~(stamp : int * int * int) ~(make : unit -> t) : t =
+  let live = List.filter (fun e -> Ephemeron.K1.check_key e) !cache in
+  let hit = List.find_opt (fun e ->
+      match Ephemeron.K1.get_key e with Some k -> k == key | None -> false) live in
+  match hit with
+  | Some e when (match Ephemeron.K1.get_data e with Some c -> c.stamp = stamp | None -> false) ->
+    cache := live;
+    (match Ephemeron.K1.get_data e with Some c -> c.index | None -> assert false)
+  | _ ->
+    let index = make () in
+    let e = Ephemeron.K1.create () in
+    Ephemeron.K1.set_key e key;
+    Ephemeron.K1.set_data e { index; stamp };
+    cache := e :: List.filter (fun e' -> match hit with Some h -> e' != h | None -> true) live;
+    index
+
+let index_of_ohnsw (h : Lacaml.S.vec Ohnsw.Hgraph.t) : t =
+  let stamp = (Ohnsw.Hgraph.num_nodes h,
+               (match Ohnsw.Hgraph.entry_point h with Some e -> e | None -> -1),
+               Ohnsw.Hgraph.max_layer h) in
+  cached_index (Obj.repr h) ~stamp ~make:(fun () -> of_ohnsw h)
+
+let index_of_ba (h : Hnsw.Ba.Hgraph.t) : t =
+  (* persistent structure: a modified graph is a different value, the stamp is only a cheap guard *)
+  let stamp = (Hnsw.Ba.Hgraph.max_node_id h, Hnsw.Ba.Hgraph.entry_point h, Hnsw.Ba.Hgraph.max_layer h) in
+  cached_index (Obj.repr h) ~stamp ~make:(fun () -> of_ba h)
+
 (* ---- the drop-in bodies ---------------------------------------------------------------------- *)
 
-(* Ohnsw.knn_batch_bigarray : 'a Hgraph.t -> k:int -> Lacaml.S.mat -> int array array * Lacaml.S.mat
-   (lib/ohnsw.ml:877-897): same signature once the index handle is cached next to the hgraph. *)
+(* on an explicit handle *)
 let ohnsw_knn_batch_bigarray (t : t) ~k (batch : Lacaml.S.mat) =
   let ids32, distances = search t batch ~ef:k ~k ~fill:0 (* NaN / -1, :880-881 *) in
   let nq = A2.dim2 batch in
   let ids = Array.init nq (fun j -> Array.init k (fun i -> Int32.to_int ids32.{i + 1, j + 1})) in
   ids, distances
 
+(* Ohnsw.knn_batch_bigarray (lib/ohnsw.ml:877-897) with its exact signature, at the value type the GPU
+   path needs:
+     Lacaml.S.vec Ohnsw.Hgraph.t -> k:int -> Lacaml.S.mat -> int array array * Lacaml.S.mat
+   An empty batch returns empty results, as the reference's fold does; an empty hgraph raises
+   Invalid_argument "knn: empty hgraph" (:862) as soon as there is a query. *)
+let knn_batch_bigarray (hgraph : Lacaml.S.vec Ohnsw.Hgraph.t) ~k (batch : Lacaml.S.mat) :
+  int array array * Lacaml.S.mat =
+  if Lacaml.S.Mat.dim2 batch = 0 then [||], Lacaml.S.Mat.create k 0
+  else ohnsw_knn_batch_bigarray (index_of_ohnsw hgraph) ~k batch
+
 (* Hnsw.Ba.knn_batch : t -> Lacaml.S.mat -> num_neighbours_search:int -> num_neighbours:int
-   -> Lacaml.S.mat (lib/hnsw.ml:769-777): distances only, +inf filled (:771). *)
+   -> Lacaml.S.mat (lib/hnsw.ml:769-777): distances only, +inf filled (:771).
+   semantics 1 = Nearest.insert_distance's rule (lib/hnsw.ml:494-506: a neighbour tied with max(W) is
+   Inserted and expanded, W keeps the incumbent) with (distance, id) order among equal keys; 2 = the same +
+   Nearest.nearest_k's output (the k farthest of W when num_neighbours_search > num_neighbours,
+   lib/hnsw.ml:522-525) for callers that want the reference's defect reproduced. *)
 let ba_knn_batch ?(nearest_k_compat = false) (t : t) (batch : Lacaml.S.mat) ~num_neighbours_search ~num_neighbours =
-  (* semantics 1 = Nearest.insert_distance rule; 2 = the same + Nearest.nearest_k's output (the k
-     farthest of W when num_neighbours_search > num_neighbours, lib/hnsw.ml:522-525) for callers
-     that need the reference's result bit for bit *)
   snd (search ~semantics:(if nearest_k_compat then 2 else 1) t batch ~ef:num_neighbours_search ~k:num_neighbours ~fill:1)
+
+(* ... and with the reference's signature (the body of MakeBatch.knn_batch at Distance = EuclideanBa) *)
+let knn_batch ?nearest_k_compat (hgraph : Hnsw.Ba.Hgraph.t) (batch : Lacaml.S.mat) ~num_neighbours_search ~num_neighbours :
+  Lacaml.S.mat =
+  if Lacaml.S.Mat.dim2 batch = 0 then Lacaml.S.Mat.create num_neighbours 0
+  else ba_knn_batch ?nearest_k_compat (index_of_ba hgraph) batch ~num_neighbours_search ~num_neighbours
+
+(* Hnsw.Make(Batch).knn_batch (lib/hnsw.ml:781-807): the generic front-end returns a Batch.Distances.t filled
+   through Batch.Distances.set with one value_distance list per query.  A Batch whose values are
+   Lacaml.S.vec (the only kind the device path can take: BATCH with type value = Lacaml.S.vec) is served
+   by gathering the batch into a matrix, one device call, and feeding Distances.set row by row. *)
+module MakeBatchGpu (Batch : Hnsw.BATCH with type value = Lacaml.S.vec) = struct
+  let knn_batch (t : t) (batch : Batch.t) ~num_neighbours_search ~num_neighbours : Batch.Distances.t =
+    let nq = Batch.length batch in
+    let distances = Batch.Distances.create ~len_batch:nq ~num_neighbours in
+    if nq > 0 then begin
+      let m = Lacaml.S.Mat.create t.dim nq in
+      ignore (Batch.fold batch ~init:1 ~f:(fun j (row : Lacaml.S.vec) ->
+          A1.blit row (Lacaml.S.Mat.col m j); j + 1));
+      let ids, dist = search ~semantics:1 t m ~ef:num_neighbours_search ~k:num_neighbours ~fill:1 in
+      for j = 1 to nq do
+        let l = ref [] in
+        for i = num_neighbours downto 1 do
+          let node = Int32.to_int ids.{i, j} in
+          if node >= t.k_base then
+            l := { Hnsw_algo.node; distance_to_target = dist.{i, j} } :: !l
+        done;
+        Batch.Distances.set distances j !l                     (* lib/hnsw.ml:803-804: i counts from 1 *)
+      done
+    end;
+    distances
+end
 
 (* Ohnsw.search_k (lib/ohnsw.ml:543-588) on one layer for ONE target: the start MinQueue as a node
    list, the result MinQueue as an ascending (node, distance) list.  ~semantics:1 is
