@@ -97,17 +97,25 @@ typedef struct hnsw_index_desc {
     const hnsw_layer_desc *upper; /* [max_layer]; upper[l-1] describes layer l               */
 } hnsw_index_desc;
 
-/* Which accept rule W uses on layer 0 (they differ only when a neighbour is exactly as far as
- * max(W)): OHNSW = accept iff |W| < ef or d < max(W).d (Ohnsw.search_k, lib/ohnsw.ml:574);
- * FUNCTOR = Nearest.insert_distance (lib/hnsw.ml:494-506): accept iff the element is not farther
- * than max(W), which under the (distance, node id) order means: a node tied with max(W) but with
- * a smaller id takes its place.  Use FUNCTOR for Hnsw.Ba / Hnsw_algo.Knn.knn. */
+/* Which accept rule W uses (they differ only when a neighbour is exactly as far as max(W)):
+ * OHNSW   = accept iff |W| < ef or d < max(W).d (Ohnsw.search_k, lib/ohnsw.ml:574): a tied neighbour
+ *           is dropped.
+ * FUNCTOR = Nearest.insert_distance (lib/hnsw.ml:494-506) with the in-tree heap's merge
+ *           (lib/hnsw_algo.ml:25-31): d < max(W).d replaces the maximum; d == max(W).d is answered
+ *           Inserted -- the neighbour enters VisitMe and IS expanded later (lib/hnsw_algo.ml:360-364) --
+ *           but W keeps the incumbent; d > max(W).d is Too_far.  Use it for Hnsw.Ba / Hnsw_algo.Knn.knn.
+ * What neither mode takes from the reference is the ORDER a heap yields equal keys in (Core_kernel.Heap
+ * on the imperative path: un-vendored; the in-tree pairing heap on the functor path: shape dependent):
+ * equal distances are popped / evicted in node-id order.  Against the pairing-heap restatement the
+ * functor mode's full ef-sized distance profile (and the ids up to the farthest class) agree on 2699 of
+ * the 2700 query runs of the tie-heavy suites of tests/test_gpu_functor_ties.py; the residual (suite
+ * "levels8", ef 16, query 82) is such an order effect (profiles/r02_functor_tie_agreement.txt). */
 enum { HNSW_SEM_OHNSW = 0, HNSW_SEM_FUNCTOR = 1,
        /* FUNCTOR, and the result is what Hnsw.Nearest.nearest_k (lib/hnsw.ml:522-525) returns: when
         * ef > k that is the k FARTHEST members of W, nearest of those first -- the reference's
         * actual behaviour of Hnsw.Ba.knn / knn_batch with ~num_neighbours_search > ~num_neighbours,
-        * a defect its author's notes acknowledge.  For callers that need the reference's output
-        * bit for bit; knn entry points only. */
+        * a defect its author's notes acknowledge.  For callers that want that output reproduced;
+        * knn entry points only. */
        HNSW_SEM_FUNCTOR_NEAREST_K = 2 };
 
 typedef struct hnsw_search_params {
@@ -159,8 +167,14 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
                           uint32_t *out_ndist, uint32_t *out_nhops);
 
 /* Same, device buffers, asynchronous on `stream` (a hipStream_t; NULL = default stream).
- * d_status (optional, [nq] uint32): bit 0 set if the query's tie-overflow list spilled (the
- * result is then still a valid search result but may differ from the canonical tie order). */
+ * d_status (optional, [nq] uint32): bit 0 set if the query's list of tied, still expandable
+ * candidates outgrew its 64 LDS slots.  THIS ENTRY POINT HAS NO EXACTNESS FALLBACK: entries that did not
+ * fit were not expanded, so a flagged query's result may MISS neighbours the reference would return
+ * (tests/test_gpu_parity.py::test_tie_overflow_beyond_lds_stack builds such a case), not merely order
+ * ties differently.  A caller that needs the reference's result passes d_status and re-runs the flagged
+ * queries through hnsw_search_batch (host buffers; it searches them again with a global slab), as
+ * bench.py counts them (checks.tie_overflow_flagged).  Needs exact ties on a massive scale (e.g. > 64
+ * nodes at exactly max(W).d): 0 of the 10 000 queries of the SIFT-shaped benchmark sets. */
 int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_t nq,
                                  int64_t q_stride, const hnsw_search_params *params,
                                  int32_t *d_ids, float *d_dist, uint32_t *d_ndist,

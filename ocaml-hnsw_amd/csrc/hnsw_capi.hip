@@ -325,8 +325,7 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
             HIP_TRY(hipEventCreate(&e));
             idx->tev.push_back(e);
         }
-        ev = &idx->tev[idx->tev_used];
-        idx->tev_used += 3;
+        ev = &idx->tev[idx->tev_used];      // claimed (tev_used advanced) only once all three are recorded
         HIP_TRY(hipEventRecord(ev[0], (hipStream_t)stream));
     }
     const int mode = idx->order_mode >= 0 ? idx->order_mode : env_int("HNSW_ORDER_QUERIES", -1);
@@ -335,13 +334,14 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
         if (rc) return rc;
         a.q_limit = nq;
     }
-    if (ev) {
-        HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
+    rc = launch_search_args(idx, a, (hipStream_t)stream);
+    if (ev && !rc) {
+        HIP_TRY(hipEventRecord(ev[2], (hipStream_t)stream));
+        idx->tev_used += 3;                 // an early return above leaves the triple unclaimed: nothing half-recorded is ever read
         idx->tev_ordered.resize(idx->tev_used / 3);
         idx->tev_ordered[idx->tev_used / 3 - 1] = block != nullptr;
     }
-    rc = launch_search_args(idx, a, (hipStream_t)stream);
-    if (ev) HIP_TRY(hipEventRecord(ev[2], (hipStream_t)stream));
     return rc;
 }
 

@@ -12,8 +12,9 @@ So against TIES_HEAP the comparison is tie-class aware:
   * the distance arrays of the full ef-sized W must be bit-equal;
   * ids must be equal as SETS inside every class of equal distance strictly below max(W).d;
   * inside the farthest class (the one max(W) cuts) the ids may be a different subset of the same class.
-The test asserts the per-query agreement rate and prints it; bit-exact agreement with TIES_CANONICAL
-(the same rule, (d, id) order) is asserted in full.
+The test asserts the per-query agreement rate (>= 0.99; measured: 2699 of 2700 query runs, see
+profiles/r02_functor_tie_agreement.txt) and prints it; bit-exact agreement with TIES_CANONICAL (the same
+rule, (d, id) order) is asserted in full.
 """
 import numpy as np
 import pytest
@@ -84,8 +85,8 @@ def test_functor_semantics_against_the_pairing_heap_oracle(H, oracle, name, cfg)
         # the rule itself is reproduced; what remains is the heap-shape-dependent order among equal keys.
         # A regression to the old accept rule (ties broken by id, tied neighbours never expanded) drops
         # these rates far below the bounds.
-        assert rate_d >= 0.90, (name, ef, rate_d)
-        assert rate_i >= 0.90, (name, ef, rate_i)
+        assert rate_d >= 0.99, (name, ef, rate_d)
+        assert rate_i >= 0.99, (name, ef, rate_i)
 
 
 def test_tied_neighbour_is_expanded_although_it_never_enters_w(H, oracle):
