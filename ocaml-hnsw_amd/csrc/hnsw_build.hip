@@ -175,13 +175,14 @@ static int32_t build_attempt(const float *vectors, int64_t n, int32_t d, int64_t
     HIP_TRY_B(hipMemcpy(idx->dOff, off.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     HIP_TRY_B(hipMalloc(&idx->dLvl, (size_t)n));
     HIP_TRY_B(hipMemcpy(idx->dLvl, lvl.data(), (size_t)n, hipMemcpyHostToDevice));
+    if ((rc = upload_upper_ref(off.data(), lvl.data(), n, &idx->dRef))) goto done;
     idx->rowsU = rowsU;
     {
         IndexView &iv = idx->iv;
         iv.X = (const float *)idx->dX; iv.stride = stride; iv.n = n; iv.d = d; iv.nchunks = nchunks;
         iv.nbr0 = (const int32_t *)idx->dNbr0; iv.S0 = S0; iv.SU = SU;
         iv.nbrU = (const int32_t *)idx->dNbrU; iv.upper_off = (const int32_t *)idx->dOff;
-        iv.upper_lvl = (const uint8_t *)idx->dLvl;
+        iv.upper_lvl = (const uint8_t *)idx->dLvl; iv.upper_ref = (const int2 *)idx->dRef;
         iv.max_layer = 0; iv.entry_point = 0; iv.id_base = p->id_base;
     }
     bv.iv = idx->iv; bv.nbr0_w = (int32_t *)idx->dNbr0; bv.nbrU_w = (int32_t *)idx->dNbrU;
@@ -290,7 +291,7 @@ static int32_t build_attempt(const float *vectors, int64_t n, int32_t d, int64_t
         hnsw_index_info &inf = idx->info;
         inf.n = n; inf.d = d; inf.metric = p->metric; inf.id_base = p->id_base; inf.max_degree0 = S0;
         inf.max_degree = SU; inf.max_layer = cur_max; inf.entry_point = (int64_t)entry + p->id_base;
-        inf.device_bytes = (int64_t)(xbytes + (size_t)n * S0 * 4 + (size_t)std::max<int64_t>(rowsU, 1) * SU * 4 + (size_t)n * 5);
+        inf.device_bytes = (int64_t)(xbytes + (size_t)n * S0 * 4 + (size_t)std::max<int64_t>(rowsU, 1) * SU * 4 + (size_t)n * 13);
         inf.row_stride_bytes = stride * 4; inf.device = device;
     }
 done:

@@ -47,6 +47,14 @@ int upload_vectors(const float *vectors, int64_t n, int d, int64_t row_stride, v
     return HNSW_OK;
 }
 
+int upload_upper_ref(const int32_t *off, const uint8_t *lvl, int64_t n, void **dRef) {
+    std::vector<int2> ref((size_t)std::max<int64_t>(n, 1));
+    for (int64_t i = 0; i < n; ++i) ref[(size_t)i] = make_int2(off[(size_t)i], (int)lvl[(size_t)i]);
+    if (hipMalloc(dRef, ref.size() * sizeof(int2)) != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_OOM, "hipMalloc for the upper-row table failed"); }
+    if (hipMemcpy(*dRef, ref.data(), ref.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) return fail(HNSW_ERR_HIP, "upper-row table upload failed");
+    return HNSW_OK;
+}
+
 } // namespace hnsw_host
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
@@ -223,7 +231,9 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
         return bail(fail(HNSW_ERR_OOM, "graph upload failed"));
     }
 
+    { int rcr = upload_upper_ref(off.data(), lvl.data(), n, &idx->dRef); if (rcr) return bail(rcr); }
     IndexView &iv = idx->iv;
+    iv.upper_ref = (const int2 *)idx->dRef;
     iv.X = (const float *)idx->dX; iv.stride = stride; iv.n = n; iv.d = d->d; iv.nchunks = nchunks;
     iv.nbr0 = (const int32_t *)idx->dNbr0; iv.S0 = S0; iv.SU = SU;
     iv.nbrU = (const int32_t *)idx->dNbrU; iv.upper_off = (const int32_t *)idx->dOff;
@@ -234,7 +244,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
     hnsw_index_info &inf = idx->info;
     inf.n = n; inf.d = d->d; inf.metric = d->metric; inf.id_base = base; inf.max_degree0 = S0;
     inf.max_degree = d->max_degree; inf.max_layer = d->max_layer; inf.entry_point = ep < 0 ? base - 1 : ep + base;
-    inf.device_bytes = (int64_t)(xbytes + nbr0.size() * 4 + nbrU.size() * 4 + off.size() * 4 + lvl.size());
+    inf.device_bytes = (int64_t)(xbytes + nbr0.size() * 4 + nbrU.size() * 4 + off.size() * 12 + lvl.size());
     inf.row_stride_bytes = stride * 4; inf.device = device;
     *out = idx;
     return HNSW_OK;
@@ -243,7 +253,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
 int32_t hnsw_index_destroy(hnsw_index *idx) {
     if (!idx) return HNSW_OK;
     if (idx->device >= 0) (void)hipSetDevice(idx->device);
-    for (void *p : {idx->dX, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl}) if (p) (void)hipFree(p);
+    for (void *p : {idx->dX, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl, idx->dRef}) if (p) (void)hipFree(p);
     idx->sQ.release(); idx->sIds.release(); idx->sDist.release(); idx->sNd.release(); idx->sNh.release(); idx->sSt.release();
     (void)hipDeviceSynchronize();                      // requests never waited for
     for (hnsw_request *r : idx->all_requests) {

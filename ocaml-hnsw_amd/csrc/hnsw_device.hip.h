@@ -40,6 +40,7 @@ struct IndexView {
     const int32_t *nbrU;     // [rowsU][SU]
     const int32_t *upper_off;// [n] first upper row of the node (layer 1), -1 if none
     const uint8_t *upper_lvl;// [n] number of upper rows of the node
+    const int2 *upper_ref;   // [n] {upper_off, upper_lvl} side by side: ONE dependent load per upper-layer hop instead of two
     int32_t max_layer;
     int32_t entry_point;     // 0-based, -1 = empty
     int32_t id_base;
@@ -491,41 +492,9 @@ __device__ __forceinline__ void visited_add_masked(const WaveCtx &cx, uint32_t i
 // neighbour row of node c on `layer` (Graph.adjacent, lib/ohnsw.ml:171); -1 = hole / padding
 __device__ __forceinline__ int adj_entry(const IndexView &iv, int layer, int c, int lane) {
     if (layer == 0) return lane < iv.S0 ? iv.nbr0[(int64_t)c * iv.S0 + lane] : -1;
-    const int off = iv.upper_off[c];
-    const int lvl = iv.upper_lvl[c];
+    const int2 ref = iv.upper_ref[c];
+    const int off = ref.x, lvl = ref.y;
     return (lane < iv.SU && layer <= lvl) ? iv.nbrU[((int64_t)off + (layer - 1)) * iv.SU + lane] : -1;
-}
-
-// Ohnsw.search_one_simple (lib/ohnsw.ml:492-508) on layers `from` down to `to` (inclusive):
-// scan ALL neighbours of the current best, move to the first-in-row-order strictly closer one,
-// repeat until no change.  No visited set (argument ignored, :493).
-template <int NCH, int RB, int METRIC>
-__device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4 (&qv)[NCH], int from,
-                                               int to, int &cur, uint32_t &cur_key, const WaveCtx &cx,
-                                               uint32_t &n_dist) {
-    for (int layer = from; layer >= to; --layer) {
-        for (;;) {
-            const int nb = adj_entry(iv, layer, cur, cx.lane);
-            const bool valid = nb >= 0;
-            const uint64_t m = ballot(valid);
-            const int cnt = popc(m);
-            if (cnt == 0) break;
-            const int pos = popc(m & ((1ull << cx.lane) - 1ull));
-            __syncthreads();
-            if (valid) cx.cand_id[pos] = nb;
-            __syncthreads();
-            eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, cnt, cx.r, cx.l16);
-            __syncthreads();
-            n_dist += cnt;
-            // the nearest neighbour, the first in row order among equals
-            const uint32_t my = (cx.lane < cnt) ? cx.cand_key[cx.lane] : KEY_INF;
-            const uint32_t bkey = wave_min_u32(my);
-            if (bkey < cur_key) {                                         // strict, :502
-                const int bi = __builtin_ctzll(ballot(cx.lane < cnt && my == bkey));
-                cur = uniform(cx.cand_id[bi]); cur_key = bkey;          // scalar: its row offset comes through the scalar cache
-            } else break;
-        }
-    }
 }
 
 // ---- one round of a hop: up to 4*NB fresh neighbours evaluated ------------------------------------
@@ -606,10 +575,63 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
     out_id = ii;
 }
 
+// one round with as many 4-row batches as the list still needs (at most RB): returns the candidates consumed
+template <int NCH, int RB, int METRIC, bool FULL>
+__device__ __forceinline__ int eval_round(const IndexView &iv, const float4 (&qv)[NCH], const WaveCtx &cx,
+                                          int base, int cnt, uint32_t &ckey, uint32_t &cid) {
+    const int nbb = (cnt - base + 3) >> 2;   // wave-uniform
+    if (RB >= 8 && nbb >= 8) { hop_round<NCH, (RB >= 8 ? 8 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); return 32; }
+    if (RB >= 4 && nbb >= 4) { hop_round<NCH, (RB >= 4 ? 4 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); return 16; }
+    if (RB >= 3 && nbb >= 3) { hop_round<NCH, (RB >= 3 ? 3 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); return 12; }
+    if (RB >= 2 && nbb >= 2) { hop_round<NCH, (RB >= 2 ? 2 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); return 8; }
+    hop_round<NCH, 1, METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid);
+    return 4;
+}
+
+// Ohnsw.search_one_simple (lib/ohnsw.ml:492-508) on layers `from` down to `to` (inclusive):
+// scan ALL neighbours of the current best, move to the first-in-row-order strictly closer one,
+// repeat until no change.  No visited set (argument ignored, :493).  Same row evaluation as the layer
+// search (keys stay in registers: lane order = row order, so the first lane holding the minimum is the
+// first neighbour in row order that attains it); the upper-row lookup is one 8-byte load.
+template <int NCH, int RB, int METRIC, int ROWS = -1>
+__device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4 (&qv)[NCH], int from,
+                                               int to, int &cur, uint32_t &cur_key, const WaveCtx &cx,
+                                               uint32_t &n_dist) {
+    const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
+    for (int layer = from; layer >= to; --layer) {
+        for (;;) {
+            const int nb = adj_entry(iv, layer, cur, cx.lane);
+            const bool valid = nb >= 0;
+            const uint64_t m = ballot(valid);
+            const int cnt = popc(m);
+            if (cnt == 0) break;
+            const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            __syncthreads();
+            if (valid) cx.cand_id[pos] = nb;
+            __syncthreads();
+            n_dist += cnt;
+            uint32_t bkey = KEY_INF;
+            int bid = -1;
+            for (int base = 0; base < cnt;) {
+                uint32_t ckey, cid;
+                if (ROWS == 1 || (ROWS < 0 && full_rows)) base += eval_round<NCH, RB, METRIC, true>(iv, qv, cx, base, cnt, ckey, cid);
+                else base += eval_round<NCH, RB, METRIC, false>(iv, qv, cx, base, cnt, ckey, cid);
+                const uint32_t mk = wave_min_u32(ckey);
+                if (mk < bkey) {                                             // strict: an earlier round keeps a tie
+                    bkey = mk;
+                    bid = (int)rdlane(cid, __builtin_ctzll(ballot(ckey == mk)));
+                }
+            }
+            if (bkey < cur_key) { cur = bid; cur_key = bkey; }                // strict, :502
+            else break;
+        }
+    }
+}
+
 // The rounds of one hop.  Accept test of lib/ohnsw.ml:574 in row order (= ascending lane), each candidate
 // against the CURRENT W.
 #ifdef HNSW_PHASE_TIMING   // measurement build: shader-clock cycles per phase, summed over the query's hops
-struct PhaseClock { uint64_t t[4] = {0, 0, 0, 0}, mark = 0; };
+struct PhaseClock { uint64_t t[6] = {0, 0, 0, 0, 0, 0}, mark = 0; uint32_t n_ins = 0; };
 #define HNSW_PHASE(pc, i) do { const uint64_t tn__ = clock64(); (pc).t[i] += tn__ - (pc).mark; (pc).mark = tn__; } while (0)
 #else
 struct PhaseClock {};
@@ -621,13 +643,8 @@ __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)
                                          const WaveCtx &cx, int cnt, uint32_t &status, PhaseClock &pc) {
     const int lane = cx.lane;
     for (int base = 0; base < cnt;) {
-        const int nbb = (cnt - base + 3) >> 2;   // wave-uniform
         uint32_t ckey, cid;
-        if (RB >= 8 && nbb >= 8) { hop_round<NCH, (RB >= 8 ? 8 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 32; }
-        else if (RB >= 4 && nbb >= 4) { hop_round<NCH, (RB >= 4 ? 4 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 16; }
-        else if (RB >= 3 && nbb >= 3) { hop_round<NCH, (RB >= 3 ? 3 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 12; }
-        else if (RB >= 2 && nbb >= 2) { hop_round<NCH, (RB >= 2 ? 2 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 8; }
-        else { hop_round<NCH, 1, METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); base += 4; }
+        base += eval_round<NCH, RB, METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid);
         uint64_t pass = ballot(SEM ? ckey <= w.wmax : ckey < w.wmax);
 #ifdef HNSW_PHASE_TIMING
         asm volatile("" :: "s"(pass));
@@ -638,6 +655,9 @@ __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)
             pass &= pass - 1;
             const uint32_t kd = rdlane(ckey, i);
             if (kd < w.wmax) {
+#ifdef HNSW_PHASE_TIMING
+                pc.n_ins++;
+#endif
                 wlist_insert<NSLOT, SEM>(w, kd, rdlane(cid, i), lane, cx.ovf, status);     // :575-577
             } else if (SEM && kd == w.wmax && wlist_full(w)) {
                 // Nearest.insert_distance on a tie with max(W): Inserted, W unchanged (lib/hnsw.ml:501-504):
@@ -737,23 +757,31 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         int pidx;
         pref_id = wlist_take_first(w, um, pidx);                         // the next nearest unexpanded
         if (pref_id >= 0) pref_nb = adj_entry(iv, layer, pref_id, lane);
-        if (cnt == 0) { HNSW_PHASE(pc, 0); continue; }
-        const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        __syncthreads();
-        if (fresh) {                                                     // Visited.add, :572
-            cx.vt[(uint32_t)nb & cx.set_mask] = (vword << 16) | ((uint32_t)nb >> cx.set_bits);
-            cx.cand_id[pos] = nb;
+        if (cnt != 0) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            __syncthreads();
+            if (fresh) {                                                 // Visited.add, :572
+                cx.vt[(uint32_t)nb & cx.set_mask] = (vword << 16) | ((uint32_t)nb >> cx.set_bits);
+                cx.cand_id[pos] = nb;
+            }
+            __syncthreads();
+            n_dist += cnt;
+            HNSW_PHASE(pc, 1);                                           // prefetch issue + compaction through LDS
+            if (ROWS == 1 || (ROWS < 0 && full_rows)) hop_eval<NCH, RB, NSLOT, METRIC, SEM, true>(iv, qv, w, cx, cnt, status, pc);   // :573-577
+            else hop_eval<NCH, RB, NSLOT, METRIC, SEM, false>(iv, qv, w, cx, cnt, status, pc);
         }
-        __syncthreads();
-        n_dist += cnt;
-        HNSW_PHASE(pc, 1);                                               // prefetch issue + compaction through LDS
-        if (ROWS == 1 || (ROWS < 0 && full_rows)) hop_eval<NCH, RB, NSLOT, METRIC, SEM, true>(iv, qv, w, cx, cnt, status, pc);   // :573-577
-        else hop_eval<NCH, RB, NSLOT, METRIC, SEM, false>(iv, qv, w, cx, cnt, status, pc);
+#ifdef HNSW_PHASE_TIMING
+        if (!wlist_full(w)) HNSW_PHASE(pc, 4); else                        // insertions while W still holds dummies
+#endif
         HNSW_PHASE(pc, 3);                                               // insertions
     }
 #ifdef HNSW_PHASE_TIMING   // reported through the counters: n_dist = phase 0, n_hops = phase 2, status = phase 3 (20 bits) | phase 1 / 64 (12 bits)
+#if HNSW_PHASE_TIMING == 2   // second set: insert time while W fills / once it is full, and the number of insertions
+    n_dist = (uint32_t)pc.t[4]; n_hops = (uint32_t)pc.t[3]; status = pc.n_ins;
+#else
     n_dist = (uint32_t)pc.t[0]; n_hops = (uint32_t)pc.t[2];
-    { const uint64_t t1 = pc.t[1] >> 6; status = ((uint32_t)pc.t[3] & 0xFFFFFu) | ((uint32_t)(t1 > 4095 ? 4095 : t1) << 20); }
+    { const uint64_t t1 = pc.t[1] >> 6; const uint64_t t3 = pc.t[3] + pc.t[4]; status = ((uint32_t)t3 & 0xFFFFFu) | ((uint32_t)(t1 > 4095 ? 4095 : t1) << 20); }
+#endif
 #endif
 }
 
@@ -811,17 +839,15 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     uint32_t cur_key;
     if (a.pre_entry) {                       // descent already done (hnsw_descent_kernel)
         cur = a.pre_entry[q]; cur_key = a.pre_key[q]; n_dist = a.pre_nd[q];
-        if (a.pre_layer > 1) greedy_descend<NCH, RB, METRIC>(iv, qv, a.pre_layer - 1, 1, cur, cur_key, cx, n_dist);
+        if (a.pre_layer > 1) greedy_descend<NCH, RB, METRIC, FULL ? 1 : 0>(iv, qv, a.pre_layer - 1, 1, cur, cur_key, cx, n_dist);
     } else {
         // entry point
         cur = iv.entry_point;
         if (lane == 0) cx.cand_id[0] = cur;
         __syncthreads();
-        eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, 1, cx.r, cx.l16);
-        __syncthreads();
-        cur_key = cx.cand_key[0];
+        { uint32_t ck, ci; hop_round<NCH, 1, METRIC, FULL>(iv, qv, cx, 0, 1, ck, ci); cur_key = rdlane(ck, 0); }
         n_dist += 1;
-        greedy_descend<NCH, RB, METRIC>(iv, qv, iv.max_layer, 1, cur, cur_key, cx, n_dist);   // :865-867
+        greedy_descend<NCH, RB, METRIC, FULL ? 1 : 0>(iv, qv, iv.max_layer, 1, cur, cur_key, cx, n_dist);   // :865-867
     }
 
     WList<NSLOT> w;

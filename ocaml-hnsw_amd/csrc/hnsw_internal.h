@@ -56,6 +56,9 @@ inline int pick_nslot(int ef) {
 }
 inline int64_t padded_stride(int d) { return ((int64_t)d + 15) / 16 * 16; } // floats: rows are multiples of 64 B
 
+// {upper_off, upper_lvl} of every node side by side (IndexView::upper_ref) from the two host tables
+int upload_upper_ref(const int32_t *off, const uint8_t *lvl, int64_t n, void **dRef);
+
 // copies [n][row_stride] host rows into a fresh zero-padded device table
 int upload_vectors(const float *vectors, int64_t n, int d, int64_t row_stride, void **dX, size_t *bytes);
 
@@ -75,7 +78,7 @@ struct hnsw_index {
     int device = -1;
     hnsw_dev::IndexView iv{};
     hnsw_index_info info{};
-    void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr;
+    void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr, *dRef = nullptr;
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt; // scratch for the host-buffer entry points
     hipStream_t hs[4] = {nullptr, nullptr, nullptr, nullptr}; // streams of the chunked host-buffer search and of requests (lazy)

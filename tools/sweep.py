@@ -186,6 +186,11 @@ if os.environ.get("PHASES"):
             H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(), stream.cuda_stream)
             torch.cuda.synchronize()
         st = c.cpu().numpy().astype(np.uint32)
+        if os.environ["PHASES"] == "2":    # library built with -DHNSW_PHASE_TIMING=2
+            fill = a.cpu().numpy().astype(np.uint32).astype(np.float64); steady = b.cpu().numpy().astype(np.uint32).astype(np.float64)
+            print("nq=%d: insertions per query %.1f; insert cycles while W fills %.0f, once full %.0f (medians); cycles per insertion %.0f" %
+                  (nq, st.mean(), np.median(fill), np.median(steady), (fill.sum() + steady.sum()) / st.sum()), flush=True)
+            continue
         p0 = a.cpu().numpy().astype(np.uint32).astype(np.float64); p2 = b.cpu().numpy().astype(np.uint32).astype(np.float64)
         p3 = (st & 0xFFFFF).astype(np.float64); p1 = ((st >> 20) * 64).astype(np.float64)
         tot = p0 + p1 + p2 + p3
