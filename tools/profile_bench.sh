@@ -6,7 +6,9 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 5 --warmup 1 --no-cpu"
+# the default bench command minus the legs that would add dispatches of the same kernel on OTHER inputs (the
+# secondary data set) or need the CPU oracle: every hnsw_search_kernel dispatch below is the headline workload
+BENCH="python3 $PWD/bench.py --steps 20 --warmup 3 --no-cpu --no-secondary"
 cd /tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1 || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.json 2> $OUT/trace.log || exit 1
@@ -24,6 +26,6 @@ python3 tools/summarize_prof.py $OUT > gpurun_out/prof_${TAG}_summary.txt 2>&1
 # keep only the small stats files: gpurun_out/ is capped at 64 MiB
 mkdir -p gpurun_out/prof_${TAG}_keep
 find $OUT -name "*kernel_stats.csv" -exec cp {} gpurun_out/prof_${TAG}_keep/ \;
-cp $OUT/*.json gpurun_out/prof_${TAG}_keep/ 2>/dev/null
+cp $OUT/*.json $OUT/*.log gpurun_out/prof_${TAG}_keep/ 2>/dev/null
 rm -rf $OUT
 cat gpurun_out/prof_${TAG}_summary.txt
