@@ -53,6 +53,7 @@ struct SearchArgs {
     int32_t ef, k, fill;
     int32_t sem;             // 0 = Ohnsw accept rule, 1 = functor (Nearest.insert_distance) rule, 2 = 1 + nearest_k's output
     int32_t vt_bits;         // log2 of the LDS visited-cache entries
+    int32_t lds_pad;         // bytes of LDS requested beyond wave_lds_words(vt_bits): never touched; the host uses it to choose how many waves a CU holds (balanced_lds_pad)
     int32_t *out_ids;
     float *out_dist;
     uint32_t *out_ndist, *out_nhops, *out_status;

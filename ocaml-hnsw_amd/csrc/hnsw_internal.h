@@ -86,6 +86,8 @@ struct hnsw_index {
     std::vector<hnsw_request *> all_requests;                // every request ever created (released with the index)
     int live_requests = 0, next_stream = 0;
     int64_t resident_queries = 0;        // how many one-wave workgroups of the search kernel the chip holds (0 = not measured yet)
+    int resident_per_cu = 0, cus = 0;    // ... per CU, and the CUs
+    int64_t debug_last_nq = -1;          // HNSW_DEBUG_RESIDENT prints balanced_lds_pad's choice once per batch size
     int resident_nslot = 0; size_t resident_lds = 0;   // ... for this kernel variant / LDS size
     bool time_kernels = false;           // option "time_kernels": event triples around the launches of each device-entry call
     std::vector<hipEvent_t> tev;         // [3 * recorded calls]: before the pre-pass, before the search kernel, after it
@@ -97,6 +99,7 @@ struct hnsw_index {
     std::vector<OrderScratch> order_scratch;
     int order_mode = -1;                 // option "order_queries": -1 automatic (batches larger than resident_queries), 0 never, 1 always
     int vt_bits_override = 0;
+    int lds_pad = -1;                    // option "lds_pad": extra LDS bytes per search wave (-1 = balanced_lds_pad's choice)
 };
 
 namespace hnsw_host {

@@ -21,7 +21,7 @@ constexpr bool F_ = HNSW_V_FULL != 0;
 
 template <int NCH, int RB, int NSLOT>
 hipError_t launch_one(const IndexView &iv, const SearchArgs &a, hipStream_t st) {
-    const size_t lds = hnsw_dev::wave_lds_words(a.vt_bits) * sizeof(uint32_t);
+    const size_t lds = hnsw_dev::wave_lds_words(a.vt_bits) * sizeof(uint32_t) + (size_t)a.lds_pad;
     hipLaunchKernelGGL((hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_>), dim3((unsigned)a.nq),
                        dim3(64), lds, st, iv, a);
     return hipGetLastError();

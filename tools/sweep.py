@@ -49,11 +49,11 @@ stream = torch.cuda.current_stream()
 # infrastructure and is only touched from tests/)
 POST_RUN = globals().get("POST_RUN", [])
 
-def run(nq, ef, k=K, vt=0, reps=5):
+def run(nq, ef, k=K, vt=0, reps=int(os.environ.get("REPS", 5)), pad=-1):
     Qd = make(nq, 2)
     ids = torch.empty((nq, k), dtype=torch.int32, device=dev); dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
     nd = torch.zeros(nq, dtype=torch.int32, device=dev); nh = torch.zeros(nq, dtype=torch.int32, device=dev)
-    hg.set_option("vt_bits", vt)
+    hg.set_option("vt_bits", vt); hg.set_option("lds_pad", pad)
     def go(c=False):
         H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(), nd.data_ptr() if c else 0, nh.data_ptr() if c else 0, 0, stream.cuda_stream)
     go(True); torch.cuda.synchronize()
@@ -67,14 +67,14 @@ def run(nq, ef, k=K, vt=0, reps=5):
     ns = min(200, nq)
     gt = truth(Xd, Qd[:ns], k)
     rec = bench.recall_ids(ids.cpu().numpy()[:ns], gt)
-    print("nq=%7d ef=%4d vt=%2d: %8.3f ms  %10.0f q/s  n_dist(gpu)=%.0f hops=%.0f  gpu-bytes %.2f TB/s  recall %.3f" %
-          (nq, ef, vt, ms, nq / ms * 1e3, ndm, nhm, bq * nq / ms / 1e9, rec), flush=True)
+    print("nq=%7d ef=%4d vt=%2d pad=%5d: %8.3f ms  %10.0f q/s  n_dist(gpu)=%.0f hops=%.0f  gpu-bytes %.2f TB/s  recall %.3f" %
+          (nq, ef, vt, pad, ms, nq / ms * 1e3, ndm, nhm, bq * nq / ms / 1e9, rec), flush=True)
     for hook in POST_RUN:   # e.g. tests/sweep_with_oracle.py compares a sample with the CPU oracle
         hook(dict(nq=nq, ef=ef, k=k, Qd=Qd, ids=ids, dist=dist, nd=nd, nh=nh, go=go, hg=hg, X=X, metric=METRIC, make=make))
 
 for spec in sys.argv[1:]:
-    nq, ef, vt = (int(x) for x in spec.split(","))
-    run(nq, ef, vt=vt)
+    f = [int(x) for x in spec.split(",")]     # nq,ef,vt[,lds_pad]  (lds_pad -1 = the library's choice)
+    run(f[0], f[1], vt=f[2], pad=f[3] if len(f) > 3 else -1)
 
 if os.environ.get("PREF_STATS"):
     nq, ef, k = 10000, 128, 10
