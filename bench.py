@@ -224,6 +224,12 @@ def main():
     if multi:
         all_res = [torch.empty(world * 2 * nres, dtype=torch.int32, device=cdev) for _ in range(2)]
     stream = torch.cuda.current_stream()
+    # row format the knn kernel reads: byte rows (lossless, hnsw_rows8.hip) when every value is an integer in 0..255
+    row_bytes = hg.row_bytes()
+    byte_rows = row_bytes == d
+
+    def kernel_name(bytes_):
+        return "hnsw_search_kernel<2,8,2,0,0,2>" if bytes_ else "hnsw_search_kernel<2,4,2,0,0,1>"
 
     def search(ef_, counters=False, slot=0):
         H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(),
@@ -279,8 +285,23 @@ def main():
     wall, kern_ms = timed(ef, args.steps, args.warmup)
     qps = world * nq * args.steps / wall
     search_ms, prepass_ms = lib_times["search_ms"], lib_times["prepass_ms"]
-    log("ef=%d: %.0f q/s, %.3f ms/step; per step: ordering pre-pass %.3f ms + search kernel %.3f ms (device call %.3f ms)" %
-        (ef, qps, 1e3 * wall / args.steps, prepass_ms, search_ms, kern_ms))
+    log("ef=%d: %.0f q/s, %.3f ms/step; per step: ordering pre-pass %.3f ms + search kernel %.3f ms (device call %.3f ms)%s" %
+        (ef, qps, 1e3 * wall / args.steps, prepass_ms, search_ms, kern_ms, " [byte rows]" if byte_rows else ""))
+    # ---- the same steps through the float32 rows (never `value`): the general-format kernel, the one the HBM
+    #      roofline bounds (a byte row is a quarter of the bytes and leaves that regime) ----
+    fp32_leg = None
+    if byte_rows and world == 1:
+        hg.set_option("byte_rows", 0)
+        lt_keep = dict(lib_times)
+        wall_f, kern_f = timed(ef, args.steps, args.warmup)
+        fp32_leg = {"wall": wall_f, "kern_ms": kern_f, "search_ms": lib_times["search_ms"], "prepass_ms": lib_times["prepass_ms"]}
+        lib_times.clear(); lib_times.update(lt_keep)
+        search(ef, counters=True)
+        torch.cuda.synchronize()
+        fp32_leg["ids"], fp32_leg["dist"] = ids_d.cpu().numpy().copy(), dist_d.cpu().numpy().copy()
+        hg.set_option("byte_rows", 1)
+        log("float32 rows: %.0f q/s, %.3f ms/step; pre-pass %.3f ms + search kernel %.3f ms" %
+            (nq * args.steps / wall_f, 1e3 * wall_f / args.steps, fp32_leg["prepass_ms"], fp32_leg["search_ms"]))
 
     # ---- extra (--pipelined, N = 1, not `value`): the same steps alternated over two HIP streams ----
     # A single 10 k-query launch ends with a drain phase (the last queries to start run on a nearly
@@ -373,6 +394,9 @@ def main():
     # host-buffer entry point searches such queries again with a global slab.  Count them.
     flagged = int((st_d & 1).sum().item())
     checks["tie_overflow_flagged"] = flagged
+    if fp32_leg is not None:
+        checks["byte_rows_equal_float32_rows"] = bool(np.array_equal(fp32_leg["ids"], got) and
+                                                      np.array_equal(fp32_leg["dist"].view(np.uint32), got_dist.view(np.uint32)))
     ef_ok, qps_ok = None, None
 
     # ---- the drop-in call: what Ohnsw.knn_batch_bigarray becomes (host matrices in and out, one
@@ -491,9 +515,10 @@ def main():
             sec_checks["parity_dist_bits_equal"] = bool(np.array_equal(od2.view(np.uint32), got2_d[:s2].view(np.uint32)))
             del sp2, g2
         S2 = 2 * args.M
-        bq2_total = nd2 * (4 * d + 4) + nh2 * 4 * S2 + 4 * d + 8 * k
+        rb2 = hg2.row_bytes()
+        bq2_total = nd2 * (rb2 + 4) + nh2 * 4 * S2 + 4 * d + 8 * k
         if pm2 > 0 and nu2 is not None:     # ordered launch: the descent ran in its own kernel
-            bq2 = (nd2 - nu2) * (4 * d + 4) + nh2 * 4 * S2 + 4 * d + 8 * k + 16
+            bq2 = (nd2 - nu2) * (rb2 + 4) + nh2 * 4 * S2 + 4 * d + 8 * k + 16
             kms2 = sm2
         else:
             bq2, kms2 = bq2_total, sm2 + pm2
@@ -503,8 +528,16 @@ def main():
                      "value": round(nq / w2, 1), "unit": "queries/s", "ms_per_step": round(1e3 * w2, 4), "steps": steps2,
                      "roofline": {"bound": "hbm", "achieved": round(ach2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(ach2 / HBM_PEAK_GBS, 4), "kernel_ms": round(kms2, 4), "bytes_per_query": round(bq2, 1),
+                                  "row_bytes": rb2,
                                   "n_dist_per_query": round(nd2, 1), "n_hops_per_query": round(nh2, 1), "counters": src2},
                      "checks": sec_checks}
+        if rb2 == d:     # the same set through its float32 rows
+            hg2.set_option("byte_rows", 0)
+            wf, smf, pmf = timed2(ef, steps2)
+            hg2.set_option("byte_rows", 1)
+            bqf = (nd2 - (nu2 or 0)) * (4 * d + 4) + nh2 * 4 * S2 + 4 * d + 8 * k + 16
+            secondary["float32_rows"] = {"value": round(nq / wf, 1), "unit": "queries/s", "ms_per_step": round(1e3 * wf, 4),
+                                         "kernel_ms": round(smf, 4), "frac": round(bqf * nq / (smf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if rec2 < 0.95:
             for ef2 in (160, 192, 256, 320, 384, 512, 768, 1024):
                 search2(ef2)
@@ -573,28 +606,34 @@ def main():
         # ordered longest-first the descent ran in its own kernel: the search kernel then does the layer-0
         # part of it (the evaluations after the descent, the hops' adjacency rows, the query, the results,
         # 16 B of hand-over per query), and its own duration is what the library's HIP events measured.
-        bq_total = n_dist_mean * (4 * d + 4) + n_hops_mean * 4 * S + 4 * d + 8 * k
-        ordered = prepass_ms > 0
-        if ordered and n_upper_mean is not None:
-            bq = (n_dist_mean - n_upper_mean) * (4 * d + 4) + n_hops_mean * 4 * S + 4 * d + 8 * k + 16
-            kernel_ms, kernel_name = search_ms, "hnsw_search_kernel<2,4,2,0,0,true>"
-        elif ordered:      # no oracle counters: the pre-pass and the search kernel together
-            bq, kernel_ms, kernel_name = bq_total, search_ms + prepass_ms, "hnsw_descent_kernel + radix sort + hnsw_search_kernel<2,4,2,0>"
-        else:
-            bq, kernel_ms, kernel_name = bq_total, search_ms, "hnsw_search_kernel<2,4,2,0,0,true>"
-        achieved = bq * nq / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        # A row is 4d bytes as float32 and d bytes as a byte row (what this launch read: `row_bytes`).
+        def bq_of(rb, layer0_only):
+            nd_ = n_dist_mean - (n_upper_mean if layer0_only else 0.0)
+            return nd_ * (rb + 4) + n_hops_mean * 4 * S + 4 * d + 8 * k + (16 if layer0_only else 0)
+
+        def traffic_of(name, ordered_):
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
             try:
                 tj = json.load(open(tp))
-                if tj.get("workload") == "C2" and tj.get("nq") == nq and tj.get("ef") == ef and bool(tj.get("ordered")) == ordered:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("workload") == "C2" and tj.get("nq") == nq and tj.get("ef") == ef and bool(tj.get("ordered")) == ordered_:
+                    return tj.get("kernels", {}).get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                pass
+            return None
+
+        bq_total = bq_of(row_bytes, False)
+        ordered = prepass_ms > 0
+        if ordered and n_upper_mean is not None:
+            bq, kernel_ms, kname = bq_of(row_bytes, True), search_ms, kernel_name(byte_rows)
+        elif ordered:      # no oracle counters: the pre-pass and the search kernel together
+            bq, kernel_ms, kname = bq_total, search_ms + prepass_ms, "hnsw_descent_kernel + radix sort + " + kernel_name(byte_rows)
+        else:
+            bq, kernel_ms, kname = bq_total, search_ms, kernel_name(byte_rows)
+        achieved = bq * nq / (kernel_ms * 1e-3) / 1e9
+        traffic = traffic_of(kname, ordered)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4),
+                    "kernel": kname, "kernel_ms": round(kernel_ms, 4), "row_bytes": row_bytes,
                     "bytes_per_query": round(bq, 1), "n_dist_per_query": round(n_dist_mean, 1),
                     "n_hops_per_query": round(n_hops_mean, 1), "counters": src,
                     "step": {"device_call_ms": round(kern_ms, 4), "prepass_ms": round(prepass_ms, 4),
@@ -602,6 +641,22 @@ def main():
                              "bytes_per_query_whole_path": round(bq_total, 1),
                              "n_dist_before_layer0_per_query": None if n_upper_mean is None else round(n_upper_mean, 1),
                              "achieved_whole_path": round(bq_total * nq / (kern_ms * 1e-3) / 1e9, 1)}}
+        if byte_rows:
+            roofline["note"] = ("byte rows: every value of this data set is an integer in 0..255, so the knn kernel gathers d-byte rows "
+                                "(a quarter of the float32 bytes, same arithmetic, bit-identical results); the launch is then bound by "
+                                "the latency of a hop, not by HBM -- the float32-row kernel on the same batch is in `float32_rows`")
+        if fp32_leg is not None:
+            f_ord = fp32_leg["prepass_ms"] > 0
+            f_l0 = f_ord and n_upper_mean is not None
+            f_bq = bq_of(4 * d, f_l0)
+            f_ms = fp32_leg["search_ms"] if (f_l0 or not f_ord) else fp32_leg["search_ms"] + fp32_leg["prepass_ms"]
+            f_ach = f_bq * nq / (f_ms * 1e-3) / 1e9
+            roofline["float32_rows"] = {"value": round(nq * args.steps / fp32_leg["wall"], 1), "unit": "queries/s",
+                                        "ms_per_step": round(1e3 * fp32_leg["wall"] / args.steps, 4),
+                                        "kernel": kernel_name(False), "kernel_ms": round(f_ms, 4), "prepass_ms": round(fp32_leg["prepass_ms"], 4),
+                                        "bytes_per_query": round(f_bq, 1), "achieved": round(f_ach, 1), "peak": HBM_PEAK_GBS, "unit_bw": "GB/s",
+                                        "frac": round(f_ach / HBM_PEAK_GBS, 4), "traffic": traffic_of(kernel_name(False), f_ord),
+                                        "what": "option byte_rows = 0: the same index, batch and steps through the float32 rows"}
 
     if rank == 0:
         out = {
@@ -612,11 +667,12 @@ def main():
             "data": ("file:" + os.path.basename(os.path.normpath(args.dataset))) if args.dataset else "synthetic",
             "config": {"workload": "C2: %s (n=%d d=%d), M=%d efConstruction=%d "
                                    "(graph built on the GPU), ef=%d k=%d, %d queries per GPU per step, replicated index%s"
-                                   % ("vectors from " + args.dataset if args.dataset else "SIFT1M-shaped synthetic, clustered ints 0..218",
+                                   % ("vectors from " + args.dataset if args.dataset else "SIFT1M-shaped synthetic, clustered ints 0..218 stored as float32",
                                       n, d, args.M, args.efc, ef, k, nq,
                                       ", RCCL all-gather of results" if world > 1 else ""),
                        "n": n, "d": d, "M": args.M, "ef_construction": args.efc, "ef": ef, "k": k,
-                       "queries_per_gpu": nq, "global_batch": world * nq, "parallelism": "replica x%d" % world},
+                       "queries_per_gpu": nq, "global_batch": world * nq, "parallelism": "replica x%d" % world,
+                       "rows": "bytes (lossless copy of integer-valued float32 data)" if byte_rows else "float32"},
             "protocol": "hnsw_search_batch_device: queries resident in HBM before the timed region, results left in HBM "
                         "(the host-buffer drop-in call is timed in `drop_in`)",
             "roofline": roofline, "cpu_baseline": cpu_baseline, "drop_in": drop_in, "secondary": secondary,

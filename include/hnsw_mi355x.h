@@ -147,12 +147,23 @@ int32_t hnsw_index_destroy(hnsw_index *idx);
 int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info);
 /* Knobs that never change results:
  *   "vt_bits"       log2 entries of the per-query LDS visited cache (0 = automatic);
- *   "order_queries" a batch larger than the device holds at once is searched longest walk first (a
- *                   descent pre-pass + a sort decide the order; per-query results are unchanged, the
- *                   launch's drain phase gets shorter): -1 = automatic (default), 0 = never, 1 = always;
+ *   "order_queries" a batch of more than half the queries the device holds at once is searched longest
+ *                   walk first (a descent pre-pass + a sort decide the order; per-query results are
+ *                   unchanged, the long walks start first and the launch's drain phase gets shorter):
+ *                   -1 = automatic (default), 0 = never, 1 = always;
  *   "time_kernels"  1 = bracket the launches of every hnsw_search_batch_device call with HIP events
- *                   on the caller's stream (read back with hnsw_index_kernel_times). */
+ *                   on the caller's stream (read back with hnsw_index_kernel_times);
+ *   "lds_pad"       LDS bytes a search workgroup asks for beyond its own (how many queries a CU holds
+ *                   at once in a batch larger than the device holds): -1 = automatic (default);
+ *   "byte_rows"     when every value of the vectors is an integer in 0..255 (SIFT descriptors stored as
+ *                   float32) the index keeps a second, lossless copy of the rows as bytes and the knn
+ *                   searches read that one: each byte is converted back to the float it came from and
+ *                   the arithmetic is unchanged, so distances are bit-identical for a quarter of the
+ *                   bytes gathered.  1 = use the copy where it exists (default), 0 = read the float32
+ *                   rows.  (Environment HNSW_BYTE_ROWS=0 at creation: do not build the copy.) */
 int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value);
+/* Bytes of one vector as the knn searches read it: d for byte rows, 4 * d for float32 rows. */
+int32_t hnsw_index_row_bytes(const hnsw_index *idx, int64_t *row_bytes);
 /* Mean durations (ms) over the device-entry calls recorded since the last call of this function
  * (option "time_kernels"): the search kernel itself, and the ordering pre-pass (descent kernel +
  * sort; 0 when the batch was searched in the given order).  Waits for the recorded calls. */

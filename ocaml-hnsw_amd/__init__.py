@@ -30,7 +30,7 @@ SEM_OHNSW, SEM_FUNCTOR, SEM_FUNCTOR_NEAREST_K = 0, 1, 2
 # every symbol include/hnsw_mi355x.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "hnsw_abi_version", "hnsw_last_error", "hnsw_device_count", "hnsw_index_create",
-    "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_search_batch",
+    "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_index_row_bytes", "hnsw_search_batch",
     "hnsw_search_batch_device", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
     "hnsw_index_layer_stats", "hnsw_index_save", "hnsw_index_load",
@@ -104,6 +104,8 @@ def load():
     L.hnsw_index_destroy.argtypes = [vp]
     L.hnsw_index_get_info.argtypes = [vp, vp]
     L.hnsw_index_set_option.argtypes = [vp, _C.c_char_p, i64]
+    L.hnsw_index_row_bytes.argtypes = [vp, vp]
+    L.hnsw_index_row_bytes.restype = i32
     L.hnsw_search_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp]
     L.hnsw_search_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.hnsw_knn.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -324,6 +326,12 @@ class Hgraph:
 
     def set_option(self, name, value):
         _check(load().hnsw_index_set_option(self.handle, name.encode(), int(value)))
+
+    def row_bytes(self):
+        """Bytes of one vector as the knn searches read it (d: byte rows, 4 d: float32 rows)."""
+        v = _C.c_int64(0)
+        _check(load().hnsw_index_row_bytes(self.handle, _C.byref(v)))
+        return v.value
 
     def kernel_times(self):
         """(search kernel ms, ordering pre-pass ms, calls) averaged over the device-entry calls since the

@@ -303,6 +303,7 @@ done:
         if (ev[k]) (void)hipEventDestroy(ev[k]);
     }
     if (st) (void)hipStreamDestroy(st);
+    if (!rc) rc = make_byte_rows(idx);      // the finished index serves searches from the byte copy where the data allows
     if (rc) { hnsw_index_destroy(idx); return rc; }
     *out = idx;
     return HNSW_OK;

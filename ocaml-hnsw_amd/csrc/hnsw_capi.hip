@@ -64,22 +64,26 @@ int upload_upper_ref(const int32_t *off, const uint8_t *lvl, int64_t n, void **d
     hipError_t search_launch_##m##_##s##_##f(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st); \
     int search_occupancy_##m##_##s##_##f(int nch, int nslot, size_t lds);                                    \
     }
-HNSW_DECL_VARIANT(0, 0, 0) HNSW_DECL_VARIANT(0, 0, 1) HNSW_DECL_VARIANT(0, 1, 0) HNSW_DECL_VARIANT(0, 1, 1)
-HNSW_DECL_VARIANT(1, 0, 0) HNSW_DECL_VARIANT(1, 0, 1) HNSW_DECL_VARIANT(1, 1, 0) HNSW_DECL_VARIANT(1, 1, 1)
+HNSW_DECL_VARIANT(0, 0, 0) HNSW_DECL_VARIANT(0, 0, 1) HNSW_DECL_VARIANT(0, 0, 2) HNSW_DECL_VARIANT(0, 1, 0) HNSW_DECL_VARIANT(0, 1, 1) HNSW_DECL_VARIANT(0, 1, 2)
+HNSW_DECL_VARIANT(1, 0, 0) HNSW_DECL_VARIANT(1, 0, 1) HNSW_DECL_VARIANT(1, 0, 2) HNSW_DECL_VARIANT(1, 1, 0) HNSW_DECL_VARIANT(1, 1, 1) HNSW_DECL_VARIANT(1, 1, 2)
 #undef HNSW_DECL_VARIANT
 
 namespace {
 
 typedef hipError_t (*search_launch_fn)(int, int, const IndexView &, const SearchArgs &, hipStream_t);
 typedef int (*search_occupancy_fn)(int, int, size_t);
-const search_launch_fn k_launch[2][2][2] = {
-    {{search_launch_0_0_0, search_launch_0_0_1}, {search_launch_0_1_0, search_launch_0_1_1}},
-    {{search_launch_1_0_0, search_launch_1_0_1}, {search_launch_1_1_0, search_launch_1_1_1}}};
-const search_occupancy_fn k_occupancy[2][2][2] = {
-    {{search_occupancy_0_0_0, search_occupancy_0_0_1}, {search_occupancy_0_1_0, search_occupancy_0_1_1}},
-    {{search_occupancy_1_0_0, search_occupancy_1_0_1}, {search_occupancy_1_1_0, search_occupancy_1_1_1}}};
+const search_launch_fn k_launch[2][2][3] = {
+    {{search_launch_0_0_0, search_launch_0_0_1, search_launch_0_0_2}, {search_launch_0_1_0, search_launch_0_1_1, search_launch_0_1_2}},
+    {{search_launch_1_0_0, search_launch_1_0_1, search_launch_1_0_2}, {search_launch_1_1_0, search_launch_1_1_1, search_launch_1_1_2}}};
+const search_occupancy_fn k_occupancy[2][2][3] = {
+    {{search_occupancy_0_0_0, search_occupancy_0_0_1, search_occupancy_0_0_2}, {search_occupancy_0_1_0, search_occupancy_0_1_1, search_occupancy_0_1_2}},
+    {{search_occupancy_1_0_0, search_occupancy_1_0_1, search_occupancy_1_0_2}, {search_occupancy_1_1_0, search_occupancy_1_1_1, search_occupancy_1_1_2}}};
 
-inline int variant_full(const hnsw_index *idx) { return idx->iv.nchunks == 16 * pick_nch(idx->iv.nchunks) ? 1 : 0; }
+// the knn kernel's row format: 2 = byte rows (hnsw_rows8.hip), else fp32 rows, 1 = every chunk of the lane grid inside the row
+inline int variant_full(const hnsw_index *idx) {
+    if (idx->iv.X8) return 2;
+    return idx->iv.nchunks == 16 * pick_nch(idx->iv.nchunks) ? 1 : 0;
+}
 
 template <int METRIC>
 hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq,
@@ -101,12 +105,13 @@ int64_t resident_queries(hnsw_index *idx, int ef, int semf) {
     // cached in the handle; the answer depends on the kernel variant's registers and LDS
     const int nslot = pick_nslot(ef), nch = pick_nch(idx->iv.nchunks);
     const size_t lds = hnsw_dev::wave_lds_words(search_vt_bits(idx, ef)) * sizeof(uint32_t);
-    if (idx->resident_queries && idx->resident_nslot == nslot * 2 + semf && idx->resident_lds == lds) return idx->resident_queries;
+    const int vkey = (nslot * 2 + semf) * 4 + variant_full(idx);
+    if (idx->resident_queries && idx->resident_nslot == vkey && idx->resident_lds == lds) return idx->resident_queries;
     const int per_cu = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)](nch, nslot, lds);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, idx->device) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
     const int64_t v = (per_cu > 0 && cus > 0) ? (int64_t)per_cu * cus : (int64_t)1 << 40;   // unknown: never reorder
-    idx->resident_queries = v; idx->resident_nslot = nslot * 2 + semf; idx->resident_lds = lds;
+    idx->resident_queries = v; idx->resident_nslot = vkey; idx->resident_lds = lds;
     idx->resident_per_cu = (per_cu > 0 && cus > 0) ? per_cu : 0; idx->cus = cus;
     return v;
 }
@@ -124,6 +129,9 @@ int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
     if (forced >= 0) return std::min(forced, 32768);
     const int64_t resident = resident_queries(idx, ef, semf);
     if (nq <= resident || idx->resident_per_cu <= 0) return 0;
+    // byte rows: a quarter of the bytes per evaluation, the launch is bound by the latency of a hop, not by the
+    // memory system, and holds as many queries as the registers allow (C2: 0.60 ms per call at 8192 held, 0.65 at 5376)
+    if (idx->iv.X8) return 0;
     constexpr int64_t GRANULE = 1280, GRANULES_PER_CU = 128;
     const int64_t base = (int64_t)(hnsw_dev::wave_lds_words(search_vt_bits(idx, ef)) * sizeof(uint32_t));
     const int64_t passes = (nq + resident - 1) / resident;
@@ -278,6 +286,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
     inf.max_degree = d->max_degree; inf.max_layer = d->max_layer; inf.entry_point = ep < 0 ? base - 1 : ep + base;
     inf.device_bytes = (int64_t)(xbytes + nbr0.size() * 4 + nbrU.size() * 4 + off.size() * 12 + lvl.size());
     inf.row_stride_bytes = stride * 4; inf.device = device;
+    { int rc8 = make_byte_rows(idx); if (rc8) return bail(rc8); }
     *out = idx;
     return HNSW_OK;
 }
@@ -285,7 +294,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
 int32_t hnsw_index_destroy(hnsw_index *idx) {
     if (!idx) return HNSW_OK;
     if (idx->device >= 0) (void)hipSetDevice(idx->device);
-    for (void *p : {idx->dX, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl, idx->dRef}) if (p) (void)hipFree(p);
+    for (void *p : {idx->dX, idx->dX8, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl, idx->dRef}) if (p) (void)hipFree(p);
     idx->sQ.release(); idx->sIds.release(); idx->sDist.release(); idx->sNd.release(); idx->sNh.release(); idx->sSt.release();
     (void)hipDeviceSynchronize();                      // requests never waited for
     for (hnsw_request *r : idx->all_requests) {
@@ -305,10 +314,20 @@ int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info) {
     return HNSW_OK;
 }
 
+int32_t hnsw_index_row_bytes(const hnsw_index *idx, int64_t *row_bytes) {
+    if (!idx || !row_bytes) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    *row_bytes = idx->iv.X8 ? (int64_t)idx->iv.d : (int64_t)idx->iv.d * 4;
+    return HNSW_OK;
+}
+
 int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) {
     if (!idx || !name) return fail(HNSW_ERR_BAD_ARG, "null argument");
     if (!strcmp(name, "vt_bits")) { idx->vt_bits_override = (int)value; return HNSW_OK; }
     if (!strcmp(name, "lds_pad")) { idx->lds_pad = value < 0 ? -1 : (int)std::min<int64_t>(value, 32768); return HNSW_OK; }
+    if (!strcmp(name, "byte_rows")) {     // 0: search the fp32 rows even where a byte copy exists; otherwise: use it where it exists
+        idx->iv.X8 = value != 0 ? (const uint8_t *)idx->dX8 : nullptr;
+        return HNSW_OK;
+    }
     if (!strcmp(name, "time_kernels")) { idx->time_kernels = value != 0; return HNSW_OK; }
     if (!strcmp(name, "order_queries")) { idx->order_mode = value < 0 ? -1 : (value ? 1 : 0); return HNSW_OK; }
     return fail(HNSW_ERR_BAD_ARG, "unknown option %s", name);
@@ -372,7 +391,10 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
         HIP_TRY(hipEventRecord(ev[0], (hipStream_t)stream));
     }
     const int mode = idx->order_mode >= 0 ? idx->order_mode : env_int("HNSW_ORDER_QUERIES", -1);
-    if (mode != 0 && (mode == 1 || nq > resident_queries(idx, params->ef, params->semantics ? 1 : 0))) {
+    // Ordered when more than half of what the chip holds: a batch that fits is faster too with its long walks
+    // dispatched first and spread over the CUs (C2, 7168 queries: 0.59 -> 0.45 ms byte rows, 0.68 -> 0.65 ms fp32);
+    // below that the pre-pass costs more than it returns.
+    if (mode != 0 && (mode == 1 || 2 * nq > resident_queries(idx, params->ef, params->semantics ? 1 : 0))) {
         rc = order_longest_first(idx, d_queries, nq, q_stride, (hipStream_t)stream, &block, &a.qmap, &a.pre_entry, &a.pre_key, &a.pre_nd, &a.pre_layer);
         if (rc) return rc;
         a.q_limit = nq;

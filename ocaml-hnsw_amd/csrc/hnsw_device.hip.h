@@ -44,6 +44,10 @@ struct IndexView {
     int32_t max_layer;
     int32_t entry_point;     // 0-based, -1 = empty
     int32_t id_base;
+    // optional lossless copy of X for data whose every value is an integer in 0..255 (SIFT descriptors): rows of
+    // 64*NCH bytes, zero padded; chunk c of a row (dims 4c..4c+3) is one dword.  nullptr = not available / switched off
+    const uint8_t *X8;
+    int32_t stride8;         // bytes per byte row
 };
 
 struct SearchArgs {
@@ -508,11 +512,16 @@ __device__ __forceinline__ int adj_entry(const IndexView &iv, int layer, int c, 
 // candidates and ASCENDING LANE = ASCENDING ROW ORDER (lane 16*r + b <-> candidate base + NB*r + b).
 // A group whose candidate is past the end of the list re-reads the row of candidate base + b (group 0 of
 // the same batch: same addresses, coalesced, no extra traffic) and its key is forced to +inf.
-template <int NCH, int NB, int METRIC, bool FULL>
+// ROWS: 0 = fp32 rows, ragged (lanes past the row end are masked); 1 = fp32 rows, every chunk of the lane grid inside
+// the row; 2 = byte rows (IndexView::X8): one dword per chunk, converted to the same four floats the fp32 row holds, so
+// the arithmetic and its result are those of the fp32 row bit for bit, for a quarter of the bytes.  (The zero padding
+// of a byte row meets the zero padding of the query: it adds exact zeros.)
+template <int NCH, int NB, int METRIC, int ROWS>
 __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv)[NCH], const WaveCtx &cx,
                                           int base, int cnt, uint32_t &out_key, uint32_t &out_id) {
+    constexpr bool FULL = ROWS != 0;
     const int r = cx.r, l16 = cx.l16;
-    const uint32_t stride_b = (uint32_t)iv.stride * 4u;
+    const uint32_t stride_b = ROWS == 2 ? (uint32_t)iv.stride8 : (uint32_t)iv.stride * 4u;
     const int mine = base + NB * r;
     uint32_t id[NB];
 #pragma unroll
@@ -520,8 +529,17 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
         const int ci = (mine + b < cnt) ? mine + b : base + b;   // base + b < cnt: a round of NB batches has > 4*(NB-1) candidates
         id[b] = (uint32_t)cx.cand_id[ci];
     }
-    float4 v[NB][NCH];
-    if (FULL) {
+    float4 v[ROWS == 2 ? 1 : NB][ROWS == 2 ? 1 : NCH];
+    uint32_t v8[ROWS == 2 ? NB : 1][ROWS == 2 ? NCH : 1];
+    if constexpr (ROWS == 2) {
+        const char *xlane = reinterpret_cast<const char *>(iv.X8) + 4 * l16;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(xlane + (uint64_t)id[b] * stride_b);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) v8[b][i] = row[i * 16];
+        }
+    } else if constexpr (FULL) {
         const char *xlane = reinterpret_cast<const char *>(iv.X) + 16 * l16;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -550,7 +568,13 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
         float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const float4 z = v[b][i];
+            float4 z;
+            if constexpr (ROWS == 2) {
+                const uint32_t u = v8[b][i];
+                z = make_float4((float)(u & 0xFFu), (float)((u >> 8) & 0xFFu), (float)((u >> 16) & 0xFFu), (float)(u >> 24));
+            } else {
+                z = v[b][i];
+            }
             float t = acc;
             if (METRIC == 0) {
                 float dx = z.x - qv[i].x; t = __builtin_fmaf(dx, dx, t);
@@ -577,15 +601,15 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
 }
 
 // one round with as many 4-row batches as the list still needs (at most RB): returns the candidates consumed
-template <int NCH, int RB, int METRIC, bool FULL>
+template <int NCH, int RB, int METRIC, int ROWS>
 __device__ __forceinline__ int eval_round(const IndexView &iv, const float4 (&qv)[NCH], const WaveCtx &cx,
                                           int base, int cnt, uint32_t &ckey, uint32_t &cid) {
     const int nbb = (cnt - base + 3) >> 2;   // wave-uniform
-    if (RB >= 8 && nbb >= 8) { hop_round<NCH, (RB >= 8 ? 8 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); return 32; }
-    if (RB >= 4 && nbb >= 4) { hop_round<NCH, (RB >= 4 ? 4 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); return 16; }
-    if (RB >= 3 && nbb >= 3) { hop_round<NCH, (RB >= 3 ? 3 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); return 12; }
-    if (RB >= 2 && nbb >= 2) { hop_round<NCH, (RB >= 2 ? 2 : 1), METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid); return 8; }
-    hop_round<NCH, 1, METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid);
+    if (RB >= 8 && nbb >= 8) { hop_round<NCH, (RB >= 8 ? 8 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid); return 32; }
+    if (RB >= 4 && nbb >= 4) { hop_round<NCH, (RB >= 4 ? 4 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid); return 16; }
+    if (RB >= 3 && nbb >= 3) { hop_round<NCH, (RB >= 3 ? 3 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid); return 12; }
+    if (RB >= 2 && nbb >= 2) { hop_round<NCH, (RB >= 2 ? 2 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid); return 8; }
+    hop_round<NCH, 1, METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid);
     return 4;
 }
 
@@ -615,8 +639,9 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
             int bid = -1;
             for (int base = 0; base < cnt;) {
                 uint32_t ckey, cid;
-                if (ROWS == 1 || (ROWS < 0 && full_rows)) base += eval_round<NCH, RB, METRIC, true>(iv, qv, cx, base, cnt, ckey, cid);
-                else base += eval_round<NCH, RB, METRIC, false>(iv, qv, cx, base, cnt, ckey, cid);
+                if (ROWS == 2) base += eval_round<NCH, RB, METRIC, 2>(iv, qv, cx, base, cnt, ckey, cid);
+                else if (ROWS == 1 || (ROWS < 0 && full_rows)) base += eval_round<NCH, RB, METRIC, 1>(iv, qv, cx, base, cnt, ckey, cid);
+                else base += eval_round<NCH, RB, METRIC, 0>(iv, qv, cx, base, cnt, ckey, cid);
                 const uint32_t mk = wave_min_u32(ckey);
                 if (mk < bkey) {                                             // strict: an earlier round keeps a tie
                     bkey = mk;
@@ -639,13 +664,13 @@ struct PhaseClock {};
 #define HNSW_PHASE(pc, i) do { } while (0)
 #endif
 
-template <int NCH, int RB, int NSLOT, int METRIC, int SEM, bool FULL>
+template <int NCH, int RB, int NSLOT, int METRIC, int SEM, int ROWS>
 __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)[NCH], WList<NSLOT> &w,
                                          const WaveCtx &cx, int cnt, uint32_t &status, PhaseClock &pc) {
     const int lane = cx.lane;
     for (int base = 0; base < cnt;) {
         uint32_t ckey, cid;
-        base += eval_round<NCH, RB, METRIC, FULL>(iv, qv, cx, base, cnt, ckey, cid);
+        base += eval_round<NCH, RB, METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid);
         uint64_t pass = ballot(SEM ? ckey <= w.wmax : ckey < w.wmax);
 #ifdef HNSW_PHASE_TIMING
         asm volatile("" :: "s"(pass));
@@ -690,8 +715,8 @@ __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)
 // in the oracle's TIES_HEAP mode) is fixed to (d, id) here: VisitMe pops the smallest id first, a
 // replacement evicts the largest id of the farthest class.
 // ROWS: 1 = every float4 chunk of the 16 x NCH lane grid lies inside a row (d in 64*NCH-3 .. 64*NCH: no
-// masking), 0 = ragged rows, -1 = decided at run time (the builder and the layer operators; the knn
-// kernel is instantiated per case so that neither pays for the other's registers).
+// masking), 0 = ragged rows, 2 = byte rows (see hop_round), -1 = fp32 rows, shape decided at run time (the builder and
+// the layer operators; the knn kernel is instantiated per case so that neither pays for the other's registers).
 template <int NCH, int RB, int NSLOT, int METRIC, int SEM = 0, int ROWS = -1>
 __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (&qv)[NCH], int layer,
                                              WList<NSLOT> &w, int ef, const WaveCtx &cx,
@@ -768,8 +793,9 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             __syncthreads();
             n_dist += cnt;
             HNSW_PHASE(pc, 1);                                           // prefetch issue + compaction through LDS
-            if (ROWS == 1 || (ROWS < 0 && full_rows)) hop_eval<NCH, RB, NSLOT, METRIC, SEM, true>(iv, qv, w, cx, cnt, status, pc);   // :573-577
-            else hop_eval<NCH, RB, NSLOT, METRIC, SEM, false>(iv, qv, w, cx, cnt, status, pc);
+            if (ROWS == 2) hop_eval<NCH, RB, NSLOT, METRIC, SEM, 2>(iv, qv, w, cx, cnt, status, pc);                                  // :573-577
+            else if (ROWS == 1 || (ROWS < 0 && full_rows)) hop_eval<NCH, RB, NSLOT, METRIC, SEM, 1>(iv, qv, w, cx, cnt, status, pc);
+            else hop_eval<NCH, RB, NSLOT, METRIC, SEM, 0>(iv, qv, w, cx, cnt, status, pc);
         }
 #ifdef HNSW_PHASE_TIMING
         if (!wlist_full(w)) HNSW_PHASE(pc, 4); else                        // insertions while W still holds dummies
@@ -813,11 +839,11 @@ __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv,
 // registers per lane and unmasked rows fit 72 VGPRs (7 waves/SIMD, 7168 resident queries) without
 // spilling (8 waves would spill; the other variants are left to the allocator)
 #ifndef HNSW_SEARCH_MIN_WAVES
-#define HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, FULL) (((NCH) <= 2 && (NSLOT) <= 2 && (METRIC) == 0 && (FULL)) ? 7 : 1)
+#define HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS) (((NCH) <= 2 && (NSLOT) <= 2 && (METRIC) == 0 && (ROWS) == 1) ? 7 : 1)
 #endif
-// SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); FULL: see search_layer's ROWS
-template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, bool FULL>
-__global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, FULL))
+// SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); ROWS: 0 | 1 | 2, see hop_round
+template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, int ROWS>
+__global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS))
 hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
@@ -840,15 +866,15 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     uint32_t cur_key;
     if (a.pre_entry) {                       // descent already done (hnsw_descent_kernel)
         cur = a.pre_entry[q]; cur_key = a.pre_key[q]; n_dist = a.pre_nd[q];
-        if (a.pre_layer > 1) greedy_descend<NCH, RB, METRIC, FULL ? 1 : 0>(iv, qv, a.pre_layer - 1, 1, cur, cur_key, cx, n_dist);
+        if (a.pre_layer > 1) greedy_descend<NCH, RB, METRIC, ROWS>(iv, qv, a.pre_layer - 1, 1, cur, cur_key, cx, n_dist);
     } else {
         // entry point
         cur = iv.entry_point;
         if (lane == 0) cx.cand_id[0] = cur;
         __syncthreads();
-        { uint32_t ck, ci; hop_round<NCH, 1, METRIC, FULL>(iv, qv, cx, 0, 1, ck, ci); cur_key = rdlane(ck, 0); }
+        { uint32_t ck, ci; hop_round<NCH, 1, METRIC, ROWS>(iv, qv, cx, 0, 1, ck, ci); cur_key = rdlane(ck, 0); }
         n_dist += 1;
-        greedy_descend<NCH, RB, METRIC, FULL ? 1 : 0>(iv, qv, iv.max_layer, 1, cur, cur_key, cx, n_dist);   // :865-867
+        greedy_descend<NCH, RB, METRIC, ROWS>(iv, qv, iv.max_layer, 1, cur, cur_key, cx, n_dist);   // :865-867
     }
 
     WList<NSLOT> w;
@@ -856,7 +882,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     wlist_insert<NSLOT, SEMF>(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);         // :871, seeds W :555-557
     { uint32_t hw; (void)visited_mem(cx, (uint32_t)cur, hw); visited_add_masked(cx, (uint32_t)cur, hw, lane == 0); }
     __syncthreads();
-    search_layer<NCH, RB, NSLOT, METRIC, SEMF, FULL ? 1 : 0>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
+    search_layer<NCH, RB, NSLOT, METRIC, SEMF, ROWS>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
 
     // results: W[0..k) ascending (lib/ohnsw.ml:886-893); sem 2: nearest_k's k farthest of W, lib/hnsw.ml:522-525
     int wbase = NSLOT * 64 - a.ef;
@@ -892,7 +918,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
 // runs this kernel first, sorts the queries by that distance, farthest first, and launches the
 // search kernel in that order (qmap) with the descent result handed over (pre_*): the long walks
 // start first and the drain is made of short ones.  Per-query results do not depend on the order.
-template <int NCH, int RB, int METRIC>
+template <int NCH, int RB, int METRIC, int ROWS = -1>
 __global__ void __launch_bounds__(64)
 hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq, int32_t to_layer,
                     int32_t *out_entry, uint32_t *out_key, uint32_t *out_nd,
@@ -907,11 +933,18 @@ hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_
     int cur = iv.entry_point;
     if (lane == 0) cx.cand_id[0] = cur;
     __syncthreads();
-    eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, 1, cx.r, cx.l16);
-    __syncthreads();
-    uint32_t cur_key = cx.cand_key[0];
+    uint32_t cur_key;
+    if (ROWS == 2) {
+        uint32_t ck, ci;
+        hop_round<NCH, 1, METRIC, ROWS == 2 ? 2 : 1>(iv, qv, cx, 0, 1, ck, ci);
+        cur_key = rdlane(ck, 0);
+    } else {
+        eval_candidates<NCH, RB, METRIC>(iv, qv, cx.cand_id, cx.cand_key, cx.trash, 1, cx.r, cx.l16);
+        __syncthreads();
+        cur_key = cx.cand_key[0];
+    }
     uint32_t n_dist = 1;
-    greedy_descend<NCH, RB, METRIC>(iv, qv, iv.max_layer, to_layer, cur, cur_key, cx, n_dist);
+    greedy_descend<NCH, RB, METRIC, ROWS>(iv, qv, iv.max_layer, to_layer, cur, cur_key, cx, n_dist);
     if (lane == 0) {
         out_entry[q] = cur; out_key[q] = cur_key; out_nd[q] = n_dist;
         out_sortkey[q] = ~cur_key;           // ascending sort of this = farthest entry first

@@ -78,6 +78,7 @@ struct hnsw_index {
     int device = -1;
     hnsw_dev::IndexView iv{};
     hnsw_index_info info{};
+    void *dX8 = nullptr;                 // byte rows (hnsw_rows8.hip), nullptr when the data does not qualify
     void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr, *dRef = nullptr;
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt; // scratch for the host-buffer entry points
@@ -97,12 +98,15 @@ struct hnsw_index {
     // stream is ordered, so the block is free again when the next call on that stream needs it)
     struct OrderScratch { hipStream_t st; void *p; size_t bytes; };
     std::vector<OrderScratch> order_scratch;
-    int order_mode = -1;                 // option "order_queries": -1 automatic (batches larger than resident_queries), 0 never, 1 always
+    int order_mode = -1;                 // option "order_queries": -1 automatic (batches larger than half of resident_queries), 0 never, 1 always
     int vt_bits_override = 0;
     int lds_pad = -1;                    // option "lds_pad": extra LDS bytes per search wave (-1 = balanced_lds_pad's choice)
 };
 
 namespace hnsw_host {
+
+// hnsw_rows8.hip: if every value of idx->dX is an integer in 0..255, build the byte copy (idx->dX8, iv.X8, iv.stride8)
+int make_byte_rows(::hnsw_index *idx);
 
 // Longest-first ordering of a large batch (hnsw_order.hip): runs the descent kernel and a radix sort
 // on `st`; on success *block points to the handle's scratch for that stream (nothing to release)

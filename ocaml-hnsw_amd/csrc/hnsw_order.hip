@@ -77,19 +77,26 @@ order_bucket_kernel(const uint32_t *sortkey, int32_t n, int32_t *order) {
     }
 }
 
+template <int METRIC, int ROWS>
+hipError_t launch_descent_rows(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq, int32_t to_layer, int32_t *entry, uint32_t *key,
+                               uint32_t *nd, uint32_t *sortkey, int32_t *index, hipStream_t st) {
+    const size_t lds = hnsw_dev::wave_lds_words(4) * sizeof(uint32_t);
+    dim3 grid((unsigned)nq), block(64);
+    constexpr bool B = ROWS == 2;            // byte rows: a quarter of the registers per row in flight
+    switch (nch) {
+    case 1: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<1, 8, METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
+    case 2: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<2, (B ? 8 : HNSW_RB_NCH2), METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
+    case 4: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<4, (B ? 4 : 2), METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
+    case 8: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<8, (B ? 2 : 1), METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
+    default: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<16, 1, METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
+    }
+    return hipGetLastError();
+}
 template <int METRIC>
 hipError_t launch_descent(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq, int32_t to_layer, int32_t *entry, uint32_t *key,
                           uint32_t *nd, uint32_t *sortkey, int32_t *index, hipStream_t st) {
-    const size_t lds = hnsw_dev::wave_lds_words(4) * sizeof(uint32_t);
-    dim3 grid((unsigned)nq), block(64);
-    switch (nch) {
-    case 1: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<1, 8, METRIC>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
-    case 2: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<2, HNSW_RB_NCH2, METRIC>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
-    case 4: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<4, 2, METRIC>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
-    case 8: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<8, 1, METRIC>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
-    default: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<16, 1, METRIC>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
-    }
-    return hipGetLastError();
+    return iv.X8 ? launch_descent_rows<METRIC, 2>(nch, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, st)
+                 : launch_descent_rows<METRIC, -1>(nch, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, st);
 }
 } // namespace
 

@@ -1,5 +1,5 @@
 // hnsw_search_variants.hip -- instantiations of hnsw_search_kernel (hnsw_device.hip.h) for ONE
-// (metric, accept rule, row shape) triple; build.py compiles this file once per triple
+// (metric, accept rule, row format) triple; build.py compiles this file once per triple
 // (-DHNSW_V_METRIC= -DHNSW_V_SEMF= -DHNSW_V_FULL=), in parallel.  Each object exports a launcher and an
 // occupancy query over the (NCH, NSLOT) grid; hnsw_capi.hip picks the object by the triple.
 // The triple is a compile-time parameter of the kernel because the register allocation of a kernel is
@@ -8,7 +8,7 @@
 #include "hnsw_internal.h"
 
 #ifndef HNSW_V_METRIC
-#error "compile with -DHNSW_V_METRIC=0|1 -DHNSW_V_SEMF=0|1 -DHNSW_V_FULL=0|1"
+#error "compile with -DHNSW_V_METRIC=0|1 -DHNSW_V_SEMF=0|1 -DHNSW_V_FULL=0|1|2 (rows: ragged fp32, full fp32, bytes)"
 #endif
 
 using hnsw_dev::IndexView;
@@ -17,7 +17,9 @@ using hnsw_dev::SearchArgs;
 namespace {
 
 constexpr int M_ = HNSW_V_METRIC, S_ = HNSW_V_SEMF;
-constexpr bool F_ = HNSW_V_FULL != 0;
+constexpr int F_ = HNSW_V_FULL;
+// 4-row batches in flight per wave: a byte row is a quarter of the registers
+constexpr int RB1 = 8, RB2 = F_ == 2 ? 8 : HNSW_RB_NCH2, RB4 = F_ == 2 ? 4 : 2, RB8 = F_ == 2 ? 2 : 1, RB16 = 1;
 
 template <int NCH, int RB, int NSLOT>
 hipError_t launch_one(const IndexView &iv, const SearchArgs &a, hipStream_t st) {
@@ -63,20 +65,20 @@ namespace hnsw_host {
 
 hipError_t HNSW_V_CAT(search_launch_, HNSW_V_METRIC, HNSW_V_SEMF, HNSW_V_FULL)(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st) {
     switch (nch) {
-    case 1: return launch_slot<1, 8>(nslot, iv, a, st);
-    case 2: return launch_slot<2, HNSW_RB_NCH2>(nslot, iv, a, st);
-    case 4: return launch_slot<4, 2>(nslot, iv, a, st);
-    case 8: return launch_slot<8, 1>(nslot, iv, a, st);
-    default: return launch_slot<16, 1>(nslot, iv, a, st);
+    case 1: return launch_slot<1, RB1>(nslot, iv, a, st);
+    case 2: return launch_slot<2, RB2>(nslot, iv, a, st);
+    case 4: return launch_slot<4, RB4>(nslot, iv, a, st);
+    case 8: return launch_slot<8, RB8>(nslot, iv, a, st);
+    default: return launch_slot<16, RB16>(nslot, iv, a, st);
     }
 }
 int HNSW_V_CAT(search_occupancy_, HNSW_V_METRIC, HNSW_V_SEMF, HNSW_V_FULL)(int nch, int nslot, size_t lds) {
     switch (nch) {
-    case 1: return occupancy_slot<1, 8>(nslot, lds);
-    case 2: return occupancy_slot<2, HNSW_RB_NCH2>(nslot, lds);
-    case 4: return occupancy_slot<4, 2>(nslot, lds);
-    case 8: return occupancy_slot<8, 1>(nslot, lds);
-    default: return occupancy_slot<16, 1>(nslot, lds);
+    case 1: return occupancy_slot<1, RB1>(nslot, lds);
+    case 2: return occupancy_slot<2, RB2>(nslot, lds);
+    case 4: return occupancy_slot<4, RB4>(nslot, lds);
+    case 8: return occupancy_slot<8, RB8>(nslot, lds);
+    default: return occupancy_slot<16, RB16>(nslot, lds);
     }
 }
 
