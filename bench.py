@@ -229,7 +229,7 @@ def main():
     byte_rows = row_bytes == d
 
     def kernel_name(bytes_):
-        return "hnsw_search_kernel<2,8,2,0,0,2>" if bytes_ else "hnsw_search_kernel<2,4,2,0,0,1>"
+        return "hnsw_search_kernel<2,4,2,0,0,2>" if bytes_ else "hnsw_search_kernel<2,4,2,0,0,1>"
 
     def search(ef_, counters=False, slot=0):
         H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(),

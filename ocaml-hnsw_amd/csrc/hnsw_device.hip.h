@@ -104,6 +104,16 @@ __device__ __forceinline__ float reduce16(float v) {
     v = dpp_add<0x121>(v); // row_ror:1
     return v;
 }
+template <int CTRL> __device__ __forceinline__ int32_t dpp_add_i32(int32_t v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true) + v;
+}
+__device__ __forceinline__ int32_t reduce16_i32(int32_t v) {
+    v = dpp_add_i32<0x128>(v);
+    v = dpp_add_i32<0x124>(v);
+    v = dpp_add_i32<0x122>(v);
+    v = dpp_add_i32<0x121>(v);
+    return v;
+}
 // minimum over the wave (wave-uniform result): row_ror mins inside the four 16-lane rows, then the
 // four row results through scalar registers -- no LDS round trips
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
@@ -461,11 +471,16 @@ struct WaveCtx {
     uint32_t *cand_key;  // [64]
     uint32_t *trash;     // [64] write-only sink shared by every masked-off store
     OvfStore ovf;        // lds: [OVF_CAP]
+    // byte rows only (query_bytes): the query itself is byte-valued and short enough for exact integer arithmetic
+    bool qint;
+    uint32_t qb[4];      // this lane's chunks of the query as packed bytes
+    int32_t q2;          // sum of the squares of the whole query
 };
 // 4 KiB of tags at vt_bits = 11 plus 1 KiB: 28 waves per CU fit the 160 KiB LDS
 __host__ __device__ inline size_t wave_lds_words(int vt_bits) { return (((size_t)1 << vt_bits) >> 1) + 192 + OVF_CAP; }
 __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane) {
     WaveCtx cx;
+    cx.qint = false; cx.q2 = 0;
     cx.lane = lane; cx.r = lane >> 4; cx.l16 = lane & 15;
     cx.vt = lds;
     cx.set_bits = vt_bits - 1;
@@ -563,6 +578,33 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
     // trip per round into several (measured on the ragged-row inner-product variant: +50 % per query)
     __builtin_amdgcn_sched_barrier(0);
     uint32_t kk = KEY_INF, ii = 0;
+    if constexpr (ROWS == 2 && NCH <= 4) {
+        // Byte row AND byte-valued query, d <= 256: every product and every partial sum of the float arithmetic below is
+        // an integer below 2^24, so that arithmetic never rounds and its result is the exact integer sum whatever the
+        // order -- computed here with 4-byte dot products (|x - q|^2 = x.x - 2 x.q + q.q): 4 instructions per 8
+        // dimensions where the float path needs 24.
+        if (cx.qint) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                uint32_t sxq = 0, sxx = 0;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    sxq = __builtin_amdgcn_udot4(v8[b][i], cx.qb[i], sxq, false);
+                    if (METRIC == 0) sxx = __builtin_amdgcn_udot4(v8[b][i], v8[b][i], sxx, false);
+                }
+                int32_t t = METRIC == 0 ? (int32_t)sxx - 2 * (int32_t)sxq : (int32_t)sxq;
+                t = reduce16_i32(t);
+                if (METRIC == 0) t += cx.q2;
+                const uint32_t key = dist_to_key<METRIC>((float)t);
+                const bool here = l16 == b;
+                kk = here ? key : kk;
+                ii = here ? id[b] : ii;
+            }
+            out_key = (mine + l16 < cnt) ? kk : KEY_INF;
+            out_id = ii;
+            return;
+        }
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         float acc = 0.0f;
@@ -823,6 +865,29 @@ __device__ __forceinline__ void load_query(float4 (&qv)[NCH], const float *qp, i
         qv[i].w = (e0 + 3 < d) ? qp[e0 + 3] : 0.f;
     }
 }
+// byte rows: is the query byte-valued too (SIFT queries are)?  Then hop_round may use exact integer arithmetic.
+template <int NCH>
+__device__ __forceinline__ void query_bytes(WaveCtx &cx, const float4 (&qv)[NCH], int d) {
+    cx.qint = false; cx.q2 = 0;
+    if constexpr (NCH <= 4) {
+        bool ok = d <= 256;               // 256 * 255^2 < 2^24
+        uint32_t sq = 0;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const float c[4] = {qv[i].x, qv[i].y, qv[i].z, qv[i].w};
+            uint32_t u = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ok = ok && c[j] >= 0.0f && c[j] <= 255.0f && c[j] == truncf(c[j]);
+                u |= ((uint32_t)c[j] & 0xFFu) << (8 * j);
+            }
+            cx.qb[i] = u;
+            sq = __builtin_amdgcn_udot4(u, u, sq, false);
+        }
+        cx.qint = ballot(ok) == ~0ull;
+        cx.q2 = reduce16_i32((int32_t)sq);
+    }
+}
 // a database row as the query (rows are zero padded to the stride)
 template <int NCH>
 __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv, int node, int l16) {
@@ -858,6 +923,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
 
     float4 qv[NCH];
     load_query<NCH>(qv, a.Q + q * a.q_stride, iv.d, cx.l16);
+    if (ROWS == 2) query_bytes<NCH>(cx, qv, iv.d);
     visited_clear(cx);
 
     uint32_t n_dist = 0, n_hops = 0, status = 0;
@@ -930,6 +996,7 @@ hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_
     WaveCtx cx = make_ctx(lds, 4, lane);
     float4 qv[NCH];
     load_query<NCH>(qv, Q + q * q_stride, iv.d, cx.l16);
+    if (ROWS == 2) query_bytes<NCH>(cx, qv, iv.d);
     int cur = iv.entry_point;
     if (lane == 0) cx.cand_id[0] = cur;
     __syncthreads();

@@ -19,7 +19,10 @@ namespace {
 constexpr int M_ = HNSW_V_METRIC, S_ = HNSW_V_SEMF;
 constexpr int F_ = HNSW_V_FULL;
 // 4-row batches in flight per wave: a byte row is a quarter of the registers
-constexpr int RB1 = 8, RB2 = F_ == 2 ? 8 : HNSW_RB_NCH2, RB4 = F_ == 2 ? 4 : 2, RB8 = F_ == 2 ? 2 : 1, RB16 = 1;
+#ifndef HNSW_RB_BYTES_NCH2
+#define HNSW_RB_BYTES_NCH2 4
+#endif
+constexpr int RB1 = 8, RB2 = F_ == 2 ? HNSW_RB_BYTES_NCH2 : HNSW_RB_NCH2, RB4 = F_ == 2 ? 4 : 2, RB8 = F_ == 2 ? 2 : 1, RB16 = 1;
 
 template <int NCH, int RB, int NSLOT>
 hipError_t launch_one(const IndexView &iv, const SearchArgs &a, hipStream_t st) {

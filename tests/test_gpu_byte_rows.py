@@ -41,12 +41,22 @@ def _both_ways(H, hg, fn):
 
 # d: 20 -> 1 chunk column (ragged), 64 -> 1 (full), 100 -> 2 (ragged), 128 -> 2 (full), 130 -> 4 (ragged, d % 4 != 0),
 #    256 -> 4 (full), 300 -> 8, 960 -> 16
+# byte-valued queries (SIFT's are) with d <= 256 take the exact integer dot-product arithmetic of hop_round, any other
+# query the float arithmetic on the converted bytes: both must be the oracle's float32 arithmetic bit for bit.  d = 256 with
+# every value 255 against a query of zeros is the largest sum the integer path may meet (256 * 255^2 < 2^24).
 @pytest.mark.parametrize("d", [20, 64, 100, 128, 130, 256, 300, 960])
 @pytest.mark.parametrize("metric", [0, 1])
-def test_byte_rows_equal_float_rows_and_oracle(H, oracle, d, metric):
+@pytest.mark.parametrize("queries", ["bytes", "floats"])
+def test_byte_rows_equal_float_rows_and_oracle(H, oracle, d, metric, queries):
     n, nq, M, efc = (1500, 96, 8, 40) if d > 256 else (4000, 200, 12, 60)
     X = _bytes_data(n, d, 100 + d)
-    Q = _bytes_data(nq, d, 200 + d).astype(np.float32) + np.float32(0.25)     # queries need not be bytes
+    Q = _bytes_data(nq, d, 200 + d)
+    if queries == "floats":
+        Q = Q + np.float32(0.25)          # queries need not be bytes
+        Q[5] = -Q[5]
+    else:
+        Q[3, :] = 0.0                     # against X[1] = all 255: the extreme sum
+        Q[4, :] = 255.0
     hg = H.Ohnsw.build_batch_bigarray(X, M, efc, seed=3, metric=metric)
     for ef, k in ((16, 5), (100, 10), (300, 64)):
         a, b = _both_ways(H, hg, lambda: H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True))

@@ -40,17 +40,24 @@ for f in find("trace/**/*kernel_trace.csv"):
         out.append("   (trace columns of the first dispatch: arch_vgpr=%s accum_vgpr=%s sgpr=%s lds=%s grid=%s wg=%s)" % (
             col("Arch_VGPR_Count", "VGPR_Count"), col("Accum_VGPR_Count"), col("SGPR_Count"), col("LDS_Block_Size", "LDS_Block_Size_v"),
             col("Grid_Size", "Grid_Size_X"), col("Workgroup_Size", "Workgroup_Size_X")))
+def short(name):
+    """hnsw_search_kernel<2, 8, 2, 0, 0, 2> from the demangled signature"""
+    n = name.split("(")[0]
+    i = n.find("hnsw_search_kernel")
+    return n[i:] if i >= 0 else n
+
+
 for pdir in find("pmc_*/"):
     for f in find(os.path.relpath(pdir, d) + "/**/*counter_collection.csv"):
-        acc = defaultdict(lambda: [0.0, 0])
-        for r in csv.DictReader(open(f)):
+        acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))     # per kernel variant (a bench run launches the
+        for r in csv.DictReader(open(f)):                            # byte-row and the float32-row kernel)
             if "hnsw_search_kernel" not in r.get("Kernel_Name", ""):
                 continue
-            a = acc[r["Counter_Name"]]
+            a = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
-        if acc:
-            out.append("== PMC %s (per hnsw_search_kernel dispatch, mean over %d dispatches)" % (
-                os.path.basename(os.path.dirname(pdir)), max(v[1] for v in acc.values())))
-            for k, (s, c) in sorted(acc.items()):
-                out.append("  %-28s %.6g" % (k, s / c))
+        for kn, cs in sorted(acc.items()):
+            out.append("== PMC %s (per dispatch of %s, mean over %d dispatches)" % (
+                os.path.basename(os.path.dirname(pdir)), kn, max(v[1] for v in cs.values())))
+            for k, (s_, c) in sorted(cs.items()):
+                out.append("  %-28s %.6g" % (k, s_ / c))
 print("\n".join(out))
