@@ -32,9 +32,12 @@ for trial in range(trials):
     id_base = int(rng.integers(0, 2))
     levels = int(rng.choice([2, 3, 4, 50, 1000]))
     X = rng.integers(0, levels, size=(n, d)).astype(np.float32)
-    if metric == 1 or levels == 1000:
+    # byte-valued data (every value an integer 0..255) is searched through the library's byte rows; a third of the
+    # inner-product trials keep such data as it is (no normalisation) so that path meets both metrics
+    ip_bytes = metric == 1 and levels <= 50 and rng.integers(0, 3) == 0
+    if (metric == 1 and not ip_bytes) or levels == 1000:
         X = X + rng.uniform(0, 0.5, size=X.shape).astype(np.float32)
-    if metric == 1:
+    if metric == 1 and not ip_bytes:
         X /= np.maximum(np.linalg.norm(X, axis=1, keepdims=True), 1e-6)
     sp = (o.Space.ip if metric else o.Space.l2)(X, arith=o.TREE16)
     g = o.build_ohnsw(sp, M, int(rng.integers(4, 80)), seed=int(rng.integers(0, 10000)))
@@ -43,8 +46,11 @@ for trial in range(trials):
                   id_base=id_base, max_degree=M, metric=metric)
     hg.set_option("order_queries", int(rng.integers(-1, 2)))
     hg.set_option("vt_bits", int(rng.choice([0, 4, 6, 9, 11, 13])))
+    hg.set_option("byte_rows", int(rng.integers(0, 4) != 0))        # (no effect where the data has no byte copy)
     nq = int(rng.choice([1, 3, 17, 64, 200]))
     Q = (X[rng.integers(0, n, nq)] + (rng.integers(0, 2, size=(nq, d)) if metric == 0 else 0)).astype(np.float32)
+    if rng.integers(0, 3) == 0:
+        Q[rng.integers(0, nq)] += np.float32(0.5)                      # a query that is not byte-valued among byte-valued ones
     ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True)
     oi, od, ond, onh = o.Ohnsw.knn_batch_bigarray(g, sp, Q, k=k, ef=ef, ties=o.TIES_CANONICAL, counters=True)
     oi = np.where(oi >= 0, oi + id_base, -1)
