@@ -125,3 +125,23 @@ def test_save_load_and_flattened_create_rebuild_the_copy(H, tmp_path):
         np.testing.assert_array_equal(x, y)
     for h in (hg, hg2, hg3):
         h.release()
+
+
+def test_launch_options_change_nothing_but_the_launch(H):
+    """lds_pad (how many queries a CU holds at once), order_queries and byte_rows are launch policy: per-query
+    results and counters must not move, whatever they are set to (including LDS requests near the 64 KiB limit)."""
+    n, d = 30000, 128
+    X = _bytes_data(n, d, 31, hi=218)
+    Q = _bytes_data(9000, d, 32, hi=218)
+    hg = H.Ohnsw.build_batch_bigarray(X, 16, 100, seed=1)
+    ref = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=128, counters=True)
+    for rows in (1, 0):
+        hg.set_option("byte_rows", rows)
+        for order in (-1, 0, 1):
+            hg.set_option("order_queries", order)
+            for pad in (-1, 0, 1280, 2560, 7000, 30000, 60000):
+                hg.set_option("lds_pad", pad)
+                got = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=128, counters=True)
+                for x, y in zip(ref, got):
+                    np.testing.assert_array_equal(x, y)
+    hg.release()
