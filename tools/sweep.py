@@ -63,7 +63,7 @@ def run(nq, ef, k=K, vt=0, reps=int(os.environ.get("REPS", 5)), pad=-1):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream); go(); b.record(stream); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     ms = float(np.median(ts))
-    bq = ndm * (4 * d + 4) + nhm * 4 * 2 * M + 4 * d + 8 * k   # uses GPU n_dist (incl. re-evals)
+    bq = ndm * (hg.row_bytes() + 4) + nhm * 4 * 2 * M + 4 * d + 8 * k   # uses GPU n_dist (incl. re-evals); a row is d bytes when the index serves byte rows
     ns = min(200, nq)
     gt = truth(Xd, Qd[:ns], k)
     rec = bench.recall_ids(ids.cpu().numpy()[:ns], gt)
