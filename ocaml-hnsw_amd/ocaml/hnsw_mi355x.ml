@@ -72,6 +72,12 @@ let hnsw_search_one_batch =
      @-> ptr float @-> returning int32_t)
 let hnsw_index_set_option =
   foreign ~from:lib "hnsw_index_set_option" (index @-> string @-> int64_t @-> returning int32_t)
+(* bytes of one vector as the knn searches read it: d when the library serves byte-valued data (SIFT: float32
+   values that are all integers 0..255) from its lossless byte copy of the rows, 4 d otherwise.  Nothing to do on
+   this side: the copy is built by hnsw_index_create itself and is invisible to knn_batch* (same results, bit for
+   bit); `hnsw_index_set_option idx "byte_rows" 0L` reads the float32 rows again. *)
+let hnsw_index_row_bytes =
+  foreign ~from:lib "hnsw_index_row_bytes" (index @-> ptr int64_t @-> returning int32_t)
 let hnsw_index_kernel_times =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_index_kernel_times"
     (index @-> ptr double @-> ptr double @-> ptr int32_t @-> returning int32_t)
