@@ -451,7 +451,10 @@ template <int NSLOT>
 __device__ __forceinline__ void wlist_mark_expanded(WList<NSLOT> &w, int index, int lane) {
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) w.lo[s] |= (uint32_t)((s * 64 + lane) == index);
-    w.wmax_lo |= (uint32_t)(index == NSLOT * 64 - 1);
+    // (index + 1) / (64 NSLOT) is 1 for the last position only (index >= -1): scalar arithmetic, where the compare's
+    // bool went through a vector select and a v_readfirstlane
+    constexpr int LG = NSLOT == 1 ? 6 : NSLOT == 2 ? 7 : NSLOT == 4 ? 8 : NSLOT == 8 ? 9 : 10;
+    w.wmax_lo |= (uint32_t)(index + 1) >> LG;
 }
 
 // ---- per-wave scratch in LDS -------------------------------------------------------------------
