@@ -12,7 +12,7 @@ SOURCES = ["hnsw_capi.hip", "hnsw_build.hip", "hnsw_layer_ops.hip", "hnsw_multi.
 # the knn kernel's variants: one object per (metric, accept rule, row shape), see hnsw_search_variants.hip
 VARIANT_SOURCE = "hnsw_search_variants.hip"
 VARIANTS = [(m, s, f) for m in (0, 1) for s in (0, 1) for f in (0, 1, 2)]   # f: rows ragged fp32 / full fp32 / bytes
-DEPS = SOURCES + [VARIANT_SOURCE, "hnsw_device.hip.h", "hnsw_build_device.hip.h", "hnsw_internal.h",
+DEPS = SOURCES + [VARIANT_SOURCE, "hnsw_device.hip.h", "hnsw_hop_asm.hip.h", "hnsw_build_device.hip.h", "hnsw_internal.h",
         os.path.join(ROOT, "include", "hnsw_mi355x.h")]
 
 
@@ -44,7 +44,7 @@ def build(force=False, verbose=False, resource_log=None):
     if os.environ.get("HNSW_RB_NCH2"):
         base += ["-DHNSW_RB_NCH2=" + os.environ["HNSW_RB_NCH2"]]
     if os.environ.get("HNSW_SEARCH_MIN_WAVES"):
-        base += ["-DHNSW_SEARCH_MIN_WAVES(NCH,NSLOT,METRIC,FULL)=" + os.environ["HNSW_SEARCH_MIN_WAVES"]]
+        base += ["-DHNSW_SEARCH_MIN_WAVES(NCH,NSLOT,METRIC,FULL,SEMF)=" + os.environ["HNSW_SEARCH_MIN_WAVES"]]
     extra = os.environ.get("HNSW_EXTRA_CFLAGS", "").split()   # experiments: variant builds
     base += extra
     lib_out = os.environ.get("HNSW_LIB_OUT") or LIB

@@ -87,7 +87,6 @@ build_search_kernel(const BuildView bv, const BatchView bt) {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s)
             if (w.hi[s] < DUMMY_HI && w.lo[s] != PAD_LO) w.lo[s] &= ~1u;
-        if (wlist_full(w)) w.wmax_lo &= ~1u;
         w.ovf_cnt = 0;
         search_layer<NCH, RB, NSLOT, METRIC>(iv, qv, layer, w, bv.efc, cx, n_dist, n_hops, status); // :811
         const int rec = bt.rec_of[(int64_t)i * bt.lcap + layer];

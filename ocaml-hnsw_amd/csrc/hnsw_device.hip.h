@@ -28,6 +28,17 @@ namespace hnsw_dev {
 
 constexpr uint32_t KEY_INF = 0xFFFFFFFFu;
 
+// experiment switches (tools/mkvariant.sh builds variants with -D...=0)
+#ifndef HNSW_INT_TRANSPOSE
+#define HNSW_INT_TRANSPOSE 1     // byte rows + byte query: the NB integer reductions of a round as one transposing reduction
+#endif
+#ifndef HNSW_ASM_LOOP
+#define HNSW_ASM_LOOP 1          // the headline shape's layer-0 loop instruction by instruction (hnsw_hop_asm.hip.h)
+#endif
+#ifndef HNSW_INSERT_ISLAND
+#define HNSW_INSERT_ISLAND 1     // two-slot Ohnsw lists: the accept-and-insert loop of a round as one hand-scheduled block
+#endif
+
 struct IndexView {
     const float *X;          // [n][stride] zero-padded rows
     int64_t stride;          // floats, multiple of 4
@@ -113,6 +124,55 @@ __device__ __forceinline__ int32_t reduce16_i32(int32_t v) {
     v = dpp_add_i32<0x122>(v);
     v = dpp_add_i32<0x121>(v);
     return v;
+}
+// sums of NBP values per lane over the 16 lanes of a DPP row, transposed: on return lane l16 holds the row's sum of
+// value (l16 * NBP) >> 4 (NBP = 1: every lane the one sum).  Halving steps at lane distance 8, 4, 2: a lane keeps the
+// value its half is for and adds the other half's partial of the same value (row_ror:8 swaps the 8-lane halves,
+// row_half_mirror pairs lanes across bit 2, quad_perm [2,3,0,1] across bit 1); the rest is a plain butterfly.
+template <int CTRL> __device__ __forceinline__ int32_t dpp_i32(int32_t v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int NBP>
+__device__ __forceinline__ int32_t transpose_reduce16_i32(int32_t (&t)[NBP], int l16) {
+    constexpr int ROR8 = 0x128, HALF_MIRROR = 0x141, QP_1032 = 0xB1, QP_2301 = 0x4E;
+    if constexpr (NBP == 1) {
+        return reduce16_i32(t[0]);
+    } else {
+        const bool b3 = (l16 & 8) != 0;
+        int32_t u[NBP / 2];
+#pragma unroll
+        for (int j = 0; j < NBP / 2; ++j) {
+            const int32_t keep = b3 ? t[j + NBP / 2] : t[j], give = b3 ? t[j] : t[j + NBP / 2];
+            u[j] = keep + dpp_i32<ROR8>(give);
+        }
+        if constexpr (NBP == 2) {
+            int32_t v = u[0];
+            v += dpp_i32<HALF_MIRROR>(v);
+            v += dpp_i32<QP_1032>(v);
+            v += dpp_i32<QP_2301>(v);
+            return v;
+        } else {
+            const bool b2 = (l16 & 4) != 0;
+            int32_t w[NBP / 4];
+#pragma unroll
+            for (int j = 0; j < NBP / 4; ++j) {
+                const int32_t keep = b2 ? u[j + NBP / 4] : u[j], give = b2 ? u[j] : u[j + NBP / 4];
+                w[j] = keep + dpp_i32<HALF_MIRROR>(give);
+            }
+            if constexpr (NBP == 4) {
+                int32_t v = w[0];
+                v += dpp_i32<QP_1032>(v);
+                v += dpp_i32<QP_2301>(v);
+                return v;
+            } else {
+                const bool b1 = (l16 & 2) != 0;
+                const int32_t keep = b1 ? w[1] : w[0], give = b1 ? w[0] : w[1];
+                int32_t v = keep + dpp_i32<QP_2301>(give);
+                v += dpp_i32<QP_1032>(v);
+                return v;
+            }
+        }
+    }
 }
 // minimum over the wave (wave-uniform result): row_ror mins inside the four 16-lane rows, then the
 // four row results through scalar registers -- no LDS round trips
@@ -250,7 +310,6 @@ template <int NSLOT> struct WList {
     uint32_t hi[NSLOT], lo[NSLOT];
     uint32_t smax_hi, smax_lo;   // NSLOT > 2 only: lane s holds the key of slot s, lane 63 (the slot's maximum)
     uint32_t wmax;               // distance part of the top entry = max(W): the accept threshold (DUMMY_HI while |W| < ef)
-    uint32_t wmax_lo;            // its low half; flag bit kept in sync
     // entries of C that are not in W (see below).  Invariant: ovf_cnt > 0 only while every listed node is
     // at distance max(W).d (wlist_insert, the only place max(W) changes, empties the list when it drops)
     int ovf_cnt;
@@ -287,7 +346,7 @@ __device__ __forceinline__ void wlist_init(WList<NSLOT> &w, int ef, int lane) {
     const bool sm_pad = lane < NSLOT && (lane + 1) * 64 <= base;
     w.smax_hi = sm_pad ? PAD_HI : (lane < NSLOT ? DUMMY_HI : 0xFFFFFFFFu);
     w.smax_lo = sm_pad ? PAD_LO : 0xFFFFFFFFu;
-    w.wmax = DUMMY_HI; w.wmax_lo = DUMMY_LO; w.ovf_cnt = 0;
+    w.wmax = DUMMY_HI; w.ovf_cnt = 0;
 }
 template <int NSLOT> __device__ __forceinline__ bool wlist_full(const WList<NSLOT> &w) { return w.wmax != DUMMY_HI; }
 // number of real entries
@@ -389,7 +448,7 @@ __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint3
         }
         if (p != q) return;                       // already in W
     }
-    const uint32_t ev_hi = w.wmax, ev_lo = w.wmax_lo;   // the entry that falls off
+    const uint32_t ev_hi = w.wmax, ev_lo = rdlane(w.lo[NSLOT - 1], 63);   // the entry that falls off
 #pragma unroll
     for (int s = NSLOT - 1; s >= 0; --s) {
         if (s * 64 + 63 < p) continue;            // slots wholly below the rank stay (uniform)
@@ -407,9 +466,9 @@ __device__ __forceinline__ void wlist_insert(WList<NSLOT> &w, uint32_t kd, uint3
         }
     }
     w.wmax = rdlane(w.hi[NSLOT - 1], 63);
-    w.wmax_lo = rdlane(w.lo[NSLOT - 1], 63);
     if (ev_hi != w.wmax) {
         w.ovf_cnt = 0;                            // max(W).d dropped: every listed entry is dead
+    } else if (ev_hi == DUMMY_HI) {               // W still holds dummies: nothing real fell off
     } else if (SEM != 0) {                        // evicted while tied with the new max(W): stays in C, and visited
         tie_add(w, ov, key_id(ev_lo) | ((ev_lo & 1u) << 31), lane, status);
     } else if (!(ev_lo & 1u)) {                   // rare: evicted while tied with the new max(W), unexpanded
@@ -451,10 +510,6 @@ template <int NSLOT>
 __device__ __forceinline__ void wlist_mark_expanded(WList<NSLOT> &w, int index, int lane) {
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) w.lo[s] |= (uint32_t)((s * 64 + lane) == index);
-    // (index + 1) / (64 NSLOT) is 1 for the last position only (index >= -1): scalar arithmetic, where the compare's
-    // bool went through a vector select and a v_readfirstlane
-    constexpr int LG = NSLOT == 1 ? 6 : NSLOT == 2 ? 7 : NSLOT == 4 ? 8 : NSLOT == 8 ? 9 : 10;
-    w.wmax_lo |= (uint32_t)(index + 1) >> LG;
 }
 
 // ---- per-wave scratch in LDS -------------------------------------------------------------------
@@ -587,6 +642,7 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
         // order -- computed here with 4-byte dot products (|x - q|^2 = x.x - 2 x.q + q.q): 4 instructions per 8
         // dimensions where the float path needs 24.
         if (cx.qint) {
+#if !HNSW_INT_TRANSPOSE
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 uint32_t sxq = 0, sxx = 0;
@@ -605,6 +661,35 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
             }
             out_key = (mine + l16 < cnt) ? kk : KEY_INF;
             out_id = ii;
+            return;
+#endif
+            constexpr int NBP = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;   // batches padded to a power of two
+            int32_t t[NBP];
+#pragma unroll
+            for (int b = 0; b < NBP; ++b) {
+                uint32_t sxq = 0, sxx = 0;
+                if (b < NB) {
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) {
+                        sxq = __builtin_amdgcn_udot4(v8[b][i], cx.qb[i], sxq, false);
+                        if (METRIC == 0) sxx = __builtin_amdgcn_udot4(v8[b][i], v8[b][i], sxx, false);
+                    }
+                }
+                t[b] = METRIC == 0 ? (int32_t)sxx - 2 * (int32_t)sxq : (int32_t)sxq;
+            }
+            // Integer sums are exact in any order, so the NB reductions over the group's 16 lanes are done as ONE
+            // transposing reduction: lanes l16 of 16/NBP consecutive lanes end with candidate b = l16 * NBP / 16's sum
+            // (NBP = 2: 6 instructions instead of 8, and no per-batch "is this my lane" selects afterwards).
+            int32_t tsum = transpose_reduce16_i32<NBP>(t, l16);
+            if (METRIC == 0) tsum += cx.q2;
+            constexpr int SH = NBP == 1 ? 4 : NBP == 2 ? 3 : NBP == 4 ? 2 : 1;   // lanes per candidate = 1 << SH
+            const int b = l16 >> SH;
+            uint32_t myid = id[0];
+#pragma unroll
+            for (int j = 1; j < NB; ++j) myid = (b == j) ? id[j] : myid;
+            const bool rep = (l16 & ((1 << SH) - 1)) == 0 && b < NB && mine + b < cnt;
+            out_key = rep ? dist_to_key<METRIC>((float)tsum) : KEY_INF;
+            out_id = myid;
             return;
         }
     }
@@ -699,6 +784,103 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
     }
 }
 
+// ---- the accept-and-insert loop of one round for a two-slot Ohnsw list, hand-scheduled -------------------------------
+// What hop_eval's loop does per accepted candidate (lib/ohnsw.ml:574-577), as ONE block of gfx950 instructions: next
+// candidate of `pass` -> its key and id to scalar registers -> accept test against the CURRENT max(W) -> rank (two compare
+// + count pairs) -> new maximum -> shift (EXEC narrowed to the lanes from the rank up around two in-place v_mov_b32_dpp
+// wave_shr:1 per slot; the lane at the rank keeps its value -- its source lane is switched off -- until the v_writelane
+// pair puts the new key there) -> next.  About 38 instructions and 3 branches per insertion where hipcc's code for the
+// C++ loop above needs 55 to 67 and 8; both the scalar unit (shared by the CU's four SIMDs) and the vector unit are
+// close to saturated in a loaded launch, and a lone wave pays for every taken branch.
+// The block handles the COMMON insertion only and leaves the loop, with the candidate still in `pass`, when
+//   * some member of W is at exactly the candidate's distance (ids decide the rank, and the node itself may be in W), or
+//   * the entry that falls off is a real one at the new maximum's distance (it stays in C: the tie list);
+// the caller then runs the general wlist_insert for that candidate and comes back.  Returns whether anything was
+// inserted (every insertion here lowers max(W).d or replaces a dummy: the tie list is dead or empty).
+__device__ __forceinline__ bool insert_island2(WList<2> &w, uint32_t ckey, uint32_t cid, uint64_t &pass) {
+    // wave-uniform by construction; the readfirstlanes only matter where the compiler cannot see it (a caller whose
+    // loop bounds come from memory) and fold away elsewhere
+    uint32_t any = 0, wmax = (uint32_t)uniform((int)w.wmax);
+    pass = ((uint64_t)(uint32_t)uniform((int)(pass >> 32)) << 32) | (uint32_t)uniform((int)(uint32_t)pass);
+    uint32_t i, kd, klo, p, t, nw, ca, cb, sm0;
+    uint64_t e0, e1, m, sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 %[sm0], m0\n"                                  // m0 (lane select of v_writelane) is handed back as it was
+        "1:\n\t"
+        "s_cmp_eq_u64 %[pass], 0\n\t"
+        "s_cbranch_scc1 9f\n\t"
+        "s_ff1_i32_b64 %[i], %[pass]\n\t"
+        "v_readlane_b32 %[kd], %[ck], %[i]\n\t"
+        "v_readlane_b32 %[klo], %[ci], %[i]\n\t"
+        "s_cmp_ge_u32 %[kd], %[wmax]\n\t"
+        "s_cbranch_scc1 8f\n\t"                                  // no longer below max(W): rejected (:574)
+        "v_cmp_eq_u32_e64 %[e0], %[kd], %[h0]\n\t"
+        "v_cmp_eq_u32_e64 %[e1], %[kd], %[h1]\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"
+        "s_bcnt1_i32_b64 %[p], vcc\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[kd], %[h1]\n\t"
+        "s_bcnt1_i32_b64 %[t], vcc\n\t"
+        "s_or_b64 %[e0], %[e0], %[e1]\n\t"
+        "s_cbranch_scc1 9f\n\t"                                  // a member of W at this very distance: general path
+        "s_add_u32 %[p], %[p], %[t]\n\t"                         // rank = keys below
+        "v_readlane_b32 %[nw], %[h1], 62\n\t"
+        "s_cmp_eq_u32 %[p], 127\n\t"
+        "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                  // the new max(W).d
+        "s_cmp_eq_u32 %[nw], %[wmax]\n\t"
+        "s_cbranch_scc1 4f\n"                                     // the entry falling off ties with it: dummy or general path
+        "3:\n\t"
+        "s_lshl_b32 %[klo], %[klo], 1\n\t"
+        "s_add_u32 %[klo], %[klo], 2\n\t"                        // low half: (id + 1) << 1, unexpanded
+        "s_cmp_lt_u32 %[p], 64\n\t"
+        "s_cbranch_scc1 5f\n\t"
+        "s_sub_u32 %[p], %[p], 64\n\t"                           // rank in the upper slot
+        "s_lshl_b64 %[m], -1, %[p]\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "v_mov_b32_dpp %[h1], %[h1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[l1], %[l1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_mov_b32 m0, %[p]\n\t"
+        "v_writelane_b32 %[h1], %[kd], m0\n\t"
+        "v_writelane_b32 %[l1], %[klo], m0\n\t"
+        "s_branch 7f\n"
+        "4:\n\t"
+        "s_cmp_eq_u32 %[wmax], -2\n\t"                           // DUMMY_HI: W still holds dummies, nothing real falls off
+        "s_cbranch_scc1 3b\n\t"
+        "s_branch 9f\n"
+        "5:\n\t"                                                 // rank in the lower slot: the upper slot moves as a whole
+        "v_readlane_b32 %[ca], %[h0], 63\n\t"
+        "v_readlane_b32 %[cb], %[l0], 63\n\t"
+        "v_mov_b32_dpp %[h1], %[h1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[l1], %[l1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_lshl_b64 %[m], -1, %[p]\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "v_mov_b32_dpp %[h0], %[h0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[l0], %[l0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_writelane_b32 %[h1], %[ca], 0\n\t"
+        "v_writelane_b32 %[l1], %[cb], 0\n\t"
+        "s_mov_b32 m0, %[p]\n\t"
+        "v_writelane_b32 %[h0], %[kd], m0\n\t"
+        "v_writelane_b32 %[l0], %[klo], m0\n"
+        "7:\n\t"
+        "s_mov_b32 %[wmax], %[nw]\n\t"
+        "s_mov_b32 %[any], 1\n"
+        "8:\n\t"
+        "s_bitset0_b64 %[pass], %[i]\n\t"
+        "s_branch 1b\n"
+        "9:\n\t"
+        "s_mov_b32 m0, %[sm0]"
+        : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]),
+          [pass] "+&s"(pass), [wmax] "+&s"(wmax), [any] "+&s"(any),
+          [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t), [nw] "=&s"(nw),
+          [ca] "=&s"(ca), [cb] "=&s"(cb), [e0] "=&s"(e0), [e1] "=&s"(e1), [m] "=&s"(m), [sv] "=&s"(sv), [sm0] "=&s"(sm0)
+        : [ck] "v"(ckey), [ci] "v"(cid)
+        : "vcc", "scc");
+    w.wmax = wmax;
+    return any != 0;
+}
+
 // The rounds of one hop.  Accept test of lib/ohnsw.ml:574 in row order (= ascending lane), each candidate
 // against the CURRENT W.
 #ifdef HNSW_PHASE_TIMING   // measurement build: shader-clock cycles per phase, summed over the query's hops
@@ -721,6 +903,22 @@ __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)
         asm volatile("" :: "s"(pass));
 #endif
         HNSW_PHASE(pc, 2);                                               // ids from LDS, row loads, arithmetic, keys, accept ballot
+#if HNSW_INSERT_ISLAND && !defined(HNSW_PHASE_TIMING)
+        // (not in the kernel that has the hand-written loop: this is then its seldom-taken path, and the block's scalar
+        // temporaries would push that kernel past the 96 SGPRs that eight waves per SIMD allow)
+        if constexpr (NSLOT == 2 && SEM == 0 && !(HNSW_ASM_LOOP && NCH == 2 && METRIC == 0 && ROWS == 2)) {
+            while (pass) {
+                if (insert_island2(w, ckey, cid, pass)) w.ovf_cnt = 0;
+                if (pass == 0ull) break;
+                // the lowest remaining candidate needs the general insertion (see insert_island2)
+                const int i = __builtin_ctzll(pass);
+                pass &= pass - 1;
+                const uint32_t kd = rdlane(ckey, i);
+                if (kd < w.wmax) wlist_insert<NSLOT, SEM>(w, kd, rdlane(cid, i), lane, cx.ovf, status);
+            }
+            continue;
+        }
+#endif
         while (pass) {
             const int i = __builtin_ctzll(pass);
             pass &= pass - 1;
@@ -745,6 +943,10 @@ __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)
     }
 }
 
+} // namespace hnsw_dev
+#include "hnsw_hop_asm.hip.h"
+namespace hnsw_dev {
+
 // Ohnsw.search_k (lib/ohnsw.ml:543-588) on one layer.  On entry W holds the start nodes
 // (all unexpanded = the start queue, :555-559); on exit W is the ef nearest found.
 // While the rows of a hop are in flight, the adjacency row of the then-nearest unexpanded
@@ -768,6 +970,23 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
                                              uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
     const int lane = cx.lane;
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
+#if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING) && !defined(HNSW_TIMING)
+    if constexpr (NCH == 2 && NSLOT == 2 && METRIC == 0 && SEM == 0 && ROWS == 2) {
+        // the headline shape (d <= 128 byte rows, byte query, L2, Ohnsw rule, ef 65..128): hand-scheduled loop, same results
+        if (layer == 0 && cx.qint && cx.ovf.g == nullptr && (uint64_t)iv.n * (uint64_t)iv.S0 < (1ull << 30)) {
+#ifdef HNSW_ASM_DEBUG
+#ifdef HNSW_ASM_DEBUG_HOPS
+            search_layer0_bytes_l2_asm(iv, w, cx, n_dist, n_hops, status, HNSW_ASM_DEBUG_HOPS);
+#else
+            search_layer0_bytes_l2_asm(iv, w, cx, n_dist, n_hops, status, (uint32_t)ef >> 16);   // debugging: hops to run here (high half of ef)
+#endif
+#else
+            search_layer0_bytes_l2_asm(iv, w, cx, n_dist, n_hops, status);
+            return;
+#endif
+        }
+    }
+#endif
     int pref_id = -1, pref_nb = -1;
     PhaseClock pc;
 #ifdef HNSW_PHASE_TIMING
@@ -905,13 +1124,18 @@ __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv,
 // ---- the search kernel: Ohnsw.knn (lib/ohnsw.ml:859-875) per query -------------------------------
 // waves per SIMD the register allocator must leave room for: the L2 variants for d <= 128 with W in at most two key
 // registers per lane and unmasked rows fit 72 VGPRs (7 waves/SIMD, 7168 resident queries) without
-// spilling (8 waves would spill; the other variants are left to the allocator)
+// spilling (8 waves would spill); the kernel with the hand-written loop (hnsw_hop_asm.hip.h) is held to 8 waves/SIMD: the
+// loop itself needs 57 VGPRs and ~45 SGPRs, but left alone the allocator spreads the C++ paths around it over all 102
+// SGPRs, which costs the eighth wave (it now parks ~20 scalars of the prologue / epilogue in VGPR lanes instead); the
+// other variants are left to the allocator
 #ifndef HNSW_SEARCH_MIN_WAVES
-#define HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS) (((NCH) <= 2 && (NSLOT) <= 2 && (METRIC) == 0 && (ROWS) == 1) ? 7 : 1)
+#define HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS, SEMF) \
+    (((NCH) <= 2 && (NSLOT) <= 2 && (METRIC) == 0 && (ROWS) == 1) ? 7 : \
+     (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) == 2 && (METRIC) == 0 && (ROWS) == 2 && (SEMF) == 0) ? 8 : 1)
 #endif
 // SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); ROWS: 0 | 1 | 2, see hop_round
 template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, int ROWS>
-__global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS))
+__global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS, SEMF))
 hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
@@ -951,7 +1175,11 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     wlist_insert<NSLOT, SEMF>(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);         // :871, seeds W :555-557
     { uint32_t hw; (void)visited_mem(cx, (uint32_t)cur, hw); visited_add_masked(cx, (uint32_t)cur, hw, lane == 0); }
     __syncthreads();
+#ifdef HNSW_ASM_DEBUG
+    search_layer<NCH, RB, NSLOT, METRIC, SEMF, ROWS>(iv, qv, 0, w, a.ef | (a.lds_pad << 16), cx, n_dist, n_hops, status);
+#else
     search_layer<NCH, RB, NSLOT, METRIC, SEMF, ROWS>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
+#endif
 
     // results: W[0..k) ascending (lib/ohnsw.ml:886-893); sem 2: nearest_k's k farthest of W, lib/hnsw.ml:522-525
     int wbase = NSLOT * 64 - a.ef;

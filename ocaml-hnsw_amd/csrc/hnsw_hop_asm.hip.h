@@ -1,0 +1,490 @@
+// hnsw_hop_asm.hip.h -- the layer-0 loop of Ohnsw.search_k (lib/ohnsw.ml:543-588) for the headline shape, written
+// instruction by instruction for gfx950.
+//
+// Shape: byte rows of at most 128 bytes (d <= 128: NCH = 2), a byte-valued query (exact integer arithmetic, see
+// hop_round), L2, the Ohnsw accept rule, ef in 65..128 (W in two key registers per lane).  Everything else takes
+// search_layer's C++ loop; this block computes exactly what that loop computes (same pops, same evaluations, same
+// insertions, same counters), so the two are interchangeable and tests/ compare both against the oracle.
+//
+// Why by hand: in a loaded launch a CU issues at most one vector and one scalar instruction per cycle for its 32 waves
+// (the scalar unit is shared by the four SIMDs), and hipcc's hop is ~125 vector + ~115 scalar instructions, a third of
+// them glue (loop-carried register copies, boolean flags materialised in mask registers and re-tested, skip branches
+// around single instructions); a lone wave at the end of a launch additionally pays for every taken branch.  Here a
+// hop is one basic-block chain: pop (s_ff1 + v_readlane + v_writelane for the flag), adjacency row (or the row
+// fetched speculatively during the previous hop), visited filter, compaction through LDS, one round of 4 / 8 / 16 rows
+// with every load issued before the first is consumed, integer dot products, ONE transposing reduction for the
+// round's sums, accept ballot, and the insertion loop of insert_island2.
+#pragma once
+
+namespace hnsw_dev {
+
+#ifndef HNSW_ASM_LOOP
+#define HNSW_ASM_LOOP 1
+#endif
+#ifndef HNSW_ASM_MAXNB
+#define HNSW_ASM_MAXNB 4         // debugging: 1 / 2 restrict a round to one / two 4-row batches
+#endif
+#ifndef HNSW_ASM_PREFETCH
+#define HNSW_ASM_PREFETCH 1
+#endif
+
+__device__ __forceinline__ uint32_t lds_offset(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+#define HNSW_DPP_ALL " row_mask:0xf bank_mask:0xf"
+#define HNSW_DPP_BC " row_mask:0xf bank_mask:0xf bound_ctrl:1"
+
+// ids of batch B of a round -> LDS read.  Group r reads candidate base + NB r + B, clamped to the last candidate of the
+// list (a group past the end re-reads a row that is in flight anyway; its key is masked out below).
+//   sx = cand + 4 base; lastad = cand + 4 (cnt - 1); r4 = 4 r per lane; SH = log2 NB
+#define HNSW_ID_READ(B, ID, SH)                                                          \
+    "s_add_u32 %[tmp], %[sx], 4*" #B "\n\t"                                              \
+    "v_lshl_add_u32 " ID ", %[r4], " #SH ", %[tmp]\n\t"                                  \
+    "v_min_u32 " ID ", %[lastad], " ID "\n\t"                                            \
+    "ds_read_b32 " ID ", " ID "\n\t"
+// row address (one 64-bit multiply-add) and the row's two dwords per lane
+#define HNSW_ROW_LOAD(ID, AD, DA, DB)                                                    \
+    "v_mad_u64_u32 " AD ", vcc, " ID ", %[st8], %[xl]\n\t"                               \
+    "global_load_dword " DA ", " AD ", off\n\t"                                          \
+    "global_load_dword " DB ", " AD ", off offset:64\n\t"
+// x.q -> TA and x.x -> DA for this lane's 8 dimensions; HNSW_COMBINE: |x - q|^2 - q.q = x.x - 2 x.q -> DA.
+// gfx950 hazard (not interlocked, and nothing inserts wait states into inline assembly): the result of a v_dot4 may be
+// read or overwritten by a DIFFERENT vector instruction only 3 / 4 wait states later (a following v_dot4 that takes it
+// as its accumulator is fine), so the combines come after other batches' dot products or after an s_nop.
+#define HNSW_DOTS(DA, DB, TA)                                                            \
+    "v_dot4_u32_u8 " TA ", " DA ", %[qb0], 0\n\t"                                        \
+    "v_dot4_u32_u8 " DA ", " DA ", " DA ", 0\n\t"                                        \
+    "v_dot4_u32_u8 " TA ", " DB ", %[qb1], " TA "\n\t"                                   \
+    "v_dot4_u32_u8 " DA ", " DB ", " DB ", " DA "\n\t"
+#define HNSW_COMBINE(DA, TA) "v_mad_i32_i24 " DA ", " TA ", -2, " DA "\n\t"
+
+// the insertion loop of one round: insert_island2's code plus the two rare cases it left to C++
+//   labels: 10 loop, 19 done
+#define HNSW_INSERT_LOOP                                                                                                 \
+    "10:\n\t"                                                                                                            \
+    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                        \
+    "s_cbranch_scc1 19f\n\t"                                                                                             \
+    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                    \
+    "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
+    "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
+    "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
+    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
+    "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                           \
+    "v_cmp_eq_u32_e64 %[um1], %[kd], %[h1]\n\t"                                                                           \
+    "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                             \
+    "s_bcnt1_i32_b64 %[p], vcc\n\t"                                                                                      \
+    "v_cmp_gt_u32_e32 vcc, %[kd], %[h1]\n\t"                                                                             \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                      \
+    "s_lshl_b32 %[klo], %[klo], 1\n\t"                                                                                   \
+    "s_add_u32 %[klo], %[klo], 2\n\t"                                     /* low half: (id + 1) << 1, unexpanded */      \
+    "s_add_u32 %[p], %[p], %[t]\n\t"                                      /* rank = keys at a smaller distance */       \
+    "s_or_b64 vcc, %[um0], %[um1]\n\t"                                                                                     \
+    "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
+    "11:\n\t"                                                                                                            \
+    "v_readlane_b32 %[nw], %[h1], 62\n\t"                                                                                \
+    "s_cmp_eq_u32 %[p], 127\n\t"                                                                                         \
+    "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                               /* the new max(W).d */                         \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
+    "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */      \
+    "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
+    "12:\n\t"                                                                                                            \
+    "s_cmp_lt_u32 %[p], 64\n\t"                                                                                          \
+    "s_cbranch_scc1 13f\n\t"                                                                                             \
+    "s_sub_u32 %[p], %[p], 64\n\t"                                        /* rank in the upper slot */                   \
+    "s_lshl_b64 exec, -1, %[p]\n\t"                                                                                      \
+    "v_mov_b32_dpp %[h1], %[h1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
+    "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
+    "s_mov_b64 exec, -1\n\t"                                                                                             \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                             \
+    "v_writelane_b32 %[h1], %[kd], m0\n\t"                                                                               \
+    "v_writelane_b32 %[l1], %[klo], m0\n\t"                                                                              \
+    "s_branch 17f\n"                                                                                                     \
+    "13:\n\t"                                                             /* rank in the lower slot */                   \
+    "v_readlane_b32 %[sx], %[h0], 63\n\t"                                                                                \
+    "v_readlane_b32 %[tmp], %[l0], 63\n\t"                                                                                \
+    "v_mov_b32_dpp %[h1], %[h1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
+    "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
+    "s_lshl_b64 exec, -1, %[p]\n\t"                                                                                      \
+    "v_mov_b32_dpp %[h0], %[h0] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
+    "v_mov_b32_dpp %[l0], %[l0] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
+    "s_mov_b64 exec, -1\n\t"                                                                                             \
+    "v_writelane_b32 %[h1], %[sx], 0\n\t"                                                                                \
+    "v_writelane_b32 %[l1], %[tmp], 0\n\t"                                                                                \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                             \
+    "v_writelane_b32 %[h0], %[kd], m0\n\t"                                                                               \
+    "v_writelane_b32 %[l0], %[klo], m0\n"                                                                                \
+    "17:\n\t"                                                                                                            \
+    "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
+    "18:\n\t"                                                                                                            \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                    \
+    "s_branch 10b\n"                                                                                                     \
+    /* rare: distance tie inside W.  rank += members at this distance with a smaller id; a member with this id (flag */ \
+    /* bit either way) means the node is already in W (a re-evaluation the visited cache forgot): ignored */            \
+    "14:\n\t"                                                                                                            \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[l0]\n\t"                                                                            \
+    "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                     \
+    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                     \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[l1]\n\t"                                                                            \
+    "s_and_b64 vcc, vcc, %[um1]\n\t"                                                                                     \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                     \
+    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                     \
+    "s_or_b32 %[t], %[klo], 1\n\t"                                                                                       \
+    "v_or_b32_e32 %[t0], 1, %[l0]\n\t"                                                                                   \
+    "v_or_b32_e32 %[t1], 1, %[l1]\n\t"                                                                                   \
+    "v_cmp_eq_u32_e32 vcc, %[t], %[t0]\n\t"                                                                              \
+    "s_and_b64 %[um0], vcc, %[um0]\n\t"                                                                                    \
+    "v_cmp_eq_u32_e32 vcc, %[t], %[t1]\n\t"                                                                              \
+    "s_and_b64 %[um1], vcc, %[um1]\n\t"                                                                                    \
+    "s_or_b64 %[um0], %[um0], %[um1]\n\t"                                                                                   \
+    "s_cbranch_scc1 18b\n\t"                                              /* already in W */                             \
+    "s_branch 11b\n"                                                                                                     \
+    /* rare: the entry that falls off is at the new maximum's distance.  A dummy: nothing happens.  A real, unexpanded */ \
+    /* one stays in the candidate queue (lib/ohnsw.ml:568 is false for it): pushed on the tie list */                    \
+    "15:\n\t"                                                                                                            \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                       \
+    "s_cbranch_scc1 12b\n\t"                                                                                             \
+    "v_readlane_b32 %[t], %[l1], 63\n\t"                                                                                 \
+    "s_bitcmp1_b32 %[t], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
+    "s_cbranch_scc1 16f\n\t"                                                                                             \
+    "s_lshr_b32 %[t], %[t], 1\n\t"                                                                                       \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
+    "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                                                                    \
+    "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                                                              \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                    \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                      \
+    "s_mov_b64 exec, 1\n\t"                                                                                              \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                           \
+    "s_mov_b64 exec, -1\n\t"                                                                                             \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                      \
+    "s_branch 12b\n"                                                                                                     \
+    "16:\n\t"                                                                                                            \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 12b\n"                                                                                                     \
+    "19:\n\t"
+
+// accept ballot of a round: candidate index of this lane = base + CO (per-lane constant; a lane that holds no
+// candidate's sum has 0x1000 there), valid below cnt, and below the current max(W) (lib/ohnsw.ml:574)
+#define HNSW_ACCEPT(CO)                                                                  \
+    "v_add_u32_e32 %[t0], %[base], " CO "\n\t"                                           \
+    "v_cmp_gt_u32_e32 vcc, %[cnt], %[t0]\n\t"                                            \
+    "v_cmp_gt_u32_e64 %[fresh], %[wmax], %[ckey]\n\t"                                     \
+    "s_and_b64 %[fresh], %[fresh], vcc\n\t"
+
+// Runs the layer-0 search to completion.  On entry W holds the start node (unexpanded) and the visited cache knows it.
+__device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, WList<2> &w, const WaveCtx &cx,
+                                                           uint32_t &n_dist, uint32_t &n_hops, uint32_t &status, uint32_t maxhops = 0xFFFFFFFFu) {
+    const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
+    const uint64_t nbr = (uint64_t)(uintptr_t)iv.nbr0;
+    const uint64_t rowm = iv.S0 >= 64 ? ~0ull : ((1ull << iv.S0) - 1ull);
+    const uint32_t rowb = (uint32_t)iv.S0 * 4u, st8 = (uint32_t)iv.stride8;
+    const uint32_t vtb = lds_offset(cx.vt), cand = lds_offset(cx.cand_id);
+    const uint32_t setm = cx.set_mask, setb = (uint32_t)cx.set_bits;
+    const uint32_t q2 = (uint32_t)uniform(cx.q2);
+    uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
+    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt);
+    // temporaries
+    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint64_t ad0, ad1, ad2, ad3;
+    uint64_t um0, um1, fresh, b3m, b2m;   // um0 / um1 double as the insertion's equality masks, fresh as the round's accept mask
+    uint32_t pref, cnt, base, sx, lastad, i, kd, klo, p, t, nw, tmp;   // klo doubles as the hop's node, sx / tmp as the shift's carries
+    asm volatile(
+        // ---- per-lane constants
+        "v_lshlrev_b32_e32 %[lane4], 2, %[lane]\n\t"
+        "v_lshrrev_b32_e32 %[r4], 4, %[lane]\n\t"                         // r
+        "v_bfe_u32 %[t0], %[lane], 3, 1\n\t"
+        "v_lshl_add_u32 %[co2], %[r4], 1, %[t0]\n\t"                      // NB 2: 2 r + bit 3 of the lane
+        "v_bfe_u32 %[t0], %[lane], 2, 2\n\t"
+        "v_lshl_add_u32 %[co4], %[r4], 2, %[t0]\n\t"                      // NB 4: 4 r + bits 3:2
+        "v_mov_b32_e32 %[co1], %[r4]\n\t"                                 // NB 1: candidate r
+        "v_mov_b32_e32 %[t1], 0x1000\n\t"                                 // lanes that hold no candidate's sum: never below cnt
+        "v_and_b32_e32 %[t0], 15, %[lane]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
+        "s_nop 1\n\t"                                                     // gfx950: a vector write of vcc, then 2 wait states before a vector read
+        "v_cndmask_b32_e32 %[co1], %[t1], %[co1], vcc\n\t"
+        "v_and_b32_e32 %[t0], 7, %[lane]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[co2], %[t1], %[co2], vcc\n\t"
+        "v_and_b32_e32 %[t0], 3, %[lane]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[co4], %[t1], %[co4], vcc\n\t"
+        "v_lshlrev_b32_e32 %[r4], 2, %[r4]\n\t"                           // 4 r: byte offset of candidate r in the id list
+        "v_and_b32_e32 %[t0], 8, %[lane]\n\t"
+        "v_cmp_ne_u32_e64 %[b3m], 0, %[t0]\n\t"
+        "v_and_b32_e32 %[t0], 4, %[lane]\n\t"
+        "v_cmp_ne_u32_e64 %[b2m], 0, %[t0]\n\t"
+        "s_mov_b32 %[pref], -1\n"
+        // ================================ one hop ================================
+        "1:\n\t"
+#ifdef HNSW_ASM_PAD1
+        "s_nop 0\n\t"
+        "s_nop 0\n\t"
+#endif
+#ifdef HNSW_ASM_DEBUG
+        "s_cmp_ge_u32 %[nh], %[maxh]\n\t"                                 // debugging: leave after maxh hops, the C++ loop goes on from here
+        "s_cbranch_scc1 99f\n\t"
+#endif
+        // pop: the first unexpanded member of W (pop_min, :565) and its flag
+        "v_and_b32_e32 %[t0], 1, %[l0]\n\t"
+        "v_and_b32_e32 %[t1], 1, %[l1]\n\t"
+        "v_cmp_eq_u32_e64 %[um0], 0, %[t0]\n\t"
+        "v_cmp_eq_u32_e64 %[um1], 0, %[t1]\n\t"
+        "s_cmp_eq_u64 %[um0], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_ff1_i32_b64 %[i], %[um0]\n\t"
+        "v_readlane_b32 %[kd], %[l0], %[i]\n\t"
+        "s_bitset0_b64 %[um0], %[i]\n\t"
+        "s_mov_b32 m0, %[i]\n\t"
+        "s_or_b32 %[t], %[kd], 1\n\t"
+        "v_writelane_b32 %[l0], %[t], m0\n\t"
+        "s_branch 3f\n"
+        "2:\n\t"
+        "s_cmp_eq_u64 %[um1], 0\n\t"
+        "s_cbranch_scc1 90f\n\t"
+        "s_ff1_i32_b64 %[i], %[um1]\n\t"
+        "v_readlane_b32 %[kd], %[l1], %[i]\n\t"
+        "s_bitset0_b64 %[um1], %[i]\n\t"
+        "s_mov_b32 m0, %[i]\n\t"
+        "s_or_b32 %[t], %[kd], 1\n\t"
+        "v_writelane_b32 %[l1], %[t], m0\n"
+        "3:\n\t"
+        "s_lshr_b32 %[klo], %[kd], 1\n\t"
+        "s_sub_u32 %[klo], %[klo], 1\n"                                       // node id
+        "4:\n\t"
+        "s_add_u32 %[nh], %[nh], 1\n\t"
+        // adjacency row (Graph.adjacent, :570): fetched during the previous hop if the guess was right
+        "s_cmp_eq_u32 %[klo], %[pref]\n\t"
+        "s_cbranch_scc1 5f\n\t"
+        "s_mul_i32 %[tmp], %[klo], %[rowb]\n\t"                             // byte offset of the row (the caller checked that the table is < 4 GiB)
+        "v_add_u32_e32 %[t0], %[tmp], %[lane4]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"                                          // a wrong guess still in flight is drained first (its target is pnb)
+        "v_mov_b32_e32 %[nb], -1\n\t"
+        "s_mov_b64 exec, %[rowm]\n\t"
+        "global_load_dword %[nb], %[t0], %[nbr]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_branch 6f\n"
+        "5:\n\t"
+        "s_add_u32 %[st], %[st], 0x100\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_mov_b32_e32 %[nb], %[pnb]\n"
+        "6:\n\t"
+        // visited filter (Visited.mem, :571): 2-way set of 16-bit tags per word
+        "v_and_b32_e32 %[va], %[setm], %[nb]\n\t"
+        "v_lshl_add_u32 %[va], %[va], 2, %[vtb]\n\t"
+        "ds_read_b32 %[vw], %[va]\n\t"
+        "v_lshrrev_b32_e32 %[tag], %[setb], %[nb]\n\t"
+        "v_cmp_lt_i32_e32 vcc, -1, %[nb]\n\t"
+#if HNSW_ASM_PREFETCH
+        // the next nearest unexpanded member of W: its row is fetched now, beside this hop's vectors
+        "s_mov_b32 %[pref], -1\n\t"
+        "s_cmp_eq_u64 %[um0], 0\n\t"
+        "s_cbranch_scc1 7f\n\t"
+        "s_ff1_i32_b64 %[i], %[um0]\n\t"
+        "v_readlane_b32 %[pref], %[l0], %[i]\n\t"
+        "s_branch 8f\n"
+        "7:\n\t"
+        "s_cmp_eq_u64 %[um1], 0\n\t"
+        "s_cbranch_scc1 9f\n\t"
+        "s_ff1_i32_b64 %[i], %[um1]\n\t"
+        "v_readlane_b32 %[pref], %[l1], %[i]\n"
+        "8:\n\t"
+        "s_lshr_b32 %[pref], %[pref], 1\n\t"
+        "s_sub_u32 %[pref], %[pref], 1\n\t"
+        "s_mul_i32 %[tmp], %[pref], %[rowb]\n\t"
+        "v_add_u32_e32 %[t1], %[tmp], %[lane4]\n\t"
+        "v_mov_b32_e32 %[pnb], -1\n\t"
+        "s_mov_b64 exec, %[rowm]\n\t"
+        "global_load_dword %[pnb], %[t1], %[nbr]\n\t"
+        "s_mov_b64 exec, -1\n"
+        "9:\n\t"
+#endif
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_ne_u32_sdwa %[um0], %[vw], %[tag] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+        "v_cmp_ne_u32_sdwa %[um1], %[vw], %[tag] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "s_and_b64 %[fresh], %[um0], %[um1]\n\t"
+        "s_and_b64 %[fresh], %[fresh], vcc\n\t"
+        "s_cbranch_scc0 1b\n\t"                                           // nothing fresh: next hop
+        // Visited.add (:572) and the list of fresh neighbours, in row order
+        "s_bcnt1_i32_b64 %[cnt], %[fresh]\n\t"
+        "s_mov_b64 exec, %[fresh]\n\t"
+        "v_mbcnt_lo_u32_b32 %[t0], exec_lo, 0\n\t"                        // exec is the fresh mask here
+        "v_mbcnt_hi_u32_b32 %[t0], exec_hi, %[t0]\n\t"
+        "v_lshl_or_b32 %[vw], %[vw], 16, %[tag]\n\t"
+        "ds_write_b32 %[va], %[vw]\n\t"
+        "v_lshl_add_u32 %[t0], %[t0], 2, %[cand]\n\t"
+        "ds_write_b32 %[t0], %[nb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_add_u32 %[nd], %[nd], %[cnt]\n\t"
+        "s_mov_b32 %[base], 0\n\t"
+        "s_lshl_b32 %[lastad], %[cnt], 2\n\t"
+        "s_add_u32 %[lastad], %[lastad], %[cand]\n\t"
+        "s_sub_u32 %[lastad], %[lastad], 4\n"
+        // ================================ one round ================================
+        "20:\n\t"
+        "s_sub_u32 %[tmp], %[cnt], %[base]\n\t"
+        "s_lshl_b32 %[sx], %[base], 2\n\t"
+        "s_add_u32 %[sx], %[sx], %[cand]\n\t"
+#if HNSW_ASM_MAXNB >= 4
+        "s_cmp_gt_u32 %[tmp], 8\n\t"
+        "s_cbranch_scc1 40f\n\t"
+#endif
+#if HNSW_ASM_MAXNB >= 2
+        "s_cmp_gt_u32 %[tmp], 4\n\t"
+        "s_cbranch_scc1 30f\n\t"
+#endif
+        // ---- 4 rows: one batch
+        HNSW_ID_READ(0, "%[id0]", 0)
+        "s_waitcnt lgkmcnt(0)\n\t"
+        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")
+        "s_waitcnt vmcnt(0)\n\t"
+        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")
+        "v_mov_b32_e32 %[cid], %[id0]\n\t"
+        "s_nop 2\n\t"
+        HNSW_COMBINE("%[d0]", "%[ta]")
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:8" HNSW_DPP_BC "\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:4" HNSW_DPP_BC "\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:2" HNSW_DPP_BC "\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:1" HNSW_DPP_BC "\n\t"
+        "v_add_u32_e32 %[d0], %[q2], %[d0]\n\t"
+        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"
+        HNSW_ACCEPT("%[co1]")
+        "s_add_u32 %[base], %[base], 4\n\t"
+        "s_branch 50f\n"
+        // ---- 8 rows: two batches
+        "30:\n\t"
+        HNSW_ID_READ(0, "%[id0]", 1)
+        HNSW_ID_READ(1, "%[id1]", 1)
+        "s_waitcnt lgkmcnt(1)\n\t"
+        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")
+        "s_waitcnt vmcnt(0)\n\t"
+        HNSW_DOTS("%[d2]", "%[d3]", "%[tb]")
+        HNSW_COMBINE("%[d0]", "%[ta]")
+        "s_nop 2\n\t"
+        HNSW_COMBINE("%[d2]", "%[tb]")
+        "v_cndmask_b32_e64 %[ta], %[d0], %[d2], %[b3m]\n\t"               // keep: the sum this half of the group is for
+        "v_cndmask_b32_e64 %[tb], %[d2], %[d0], %[b3m]\n\t"               // give: the other half's
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[ta], %[tb], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[ta], %[ta], %[ta] row_half_mirror" HNSW_DPP_BC "\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"
+        "v_add_u32_e32 %[ta], %[q2], %[ta]\n\t"
+        "v_cvt_f32_i32_e32 %[ckey], %[ta]\n\t"
+        HNSW_ACCEPT("%[co2]")
+        "s_add_u32 %[base], %[base], 8\n\t"
+        "s_branch 50f\n"
+        // ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end)
+        "40:\n\t"
+        HNSW_ID_READ(0, "%[id0]", 2)
+        HNSW_ID_READ(1, "%[id1]", 2)
+        HNSW_ID_READ(2, "%[id2]", 2)
+        HNSW_ID_READ(3, "%[id3]", 2)
+        "s_waitcnt lgkmcnt(3)\n\t"
+        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")
+        "s_waitcnt lgkmcnt(2)\n\t"
+        HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")
+        "s_waitcnt lgkmcnt(1)\n\t"
+        HNSW_ROW_LOAD("%[id2]", "%[ad2]", "%[d4]", "%[d5]")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        HNSW_ROW_LOAD("%[id3]", "%[ad3]", "%[d6]", "%[d7]")
+        "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"
+        "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"
+        "s_waitcnt vmcnt(6)\n\t"
+        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")
+        "s_waitcnt vmcnt(4)\n\t"
+        HNSW_DOTS("%[d2]", "%[d3]", "%[tb]")
+        "s_waitcnt vmcnt(2)\n\t"
+        HNSW_COMBINE("%[d0]", "%[ta]")
+        HNSW_DOTS("%[d4]", "%[d5]", "%[ta]")
+        "s_waitcnt vmcnt(0)\n\t"
+        HNSW_COMBINE("%[d2]", "%[tb]")
+        HNSW_DOTS("%[d6]", "%[d7]", "%[tb]")
+        HNSW_COMBINE("%[d4]", "%[ta]")
+        "s_nop 2\n\t"
+        HNSW_COMBINE("%[d6]", "%[tb]")
+        // sums of candidates 0..3 of the group in d0, d2, d4, d6 -> quads of the group's 16 lanes
+        "v_cndmask_b32_e64 %[ta], %[d0], %[d4], %[b3m]\n\t"
+        "v_cndmask_b32_e64 %[d1], %[d4], %[d0], %[b3m]\n\t"
+        "v_cndmask_b32_e64 %[tb], %[d2], %[d6], %[b3m]\n\t"
+        "v_cndmask_b32_e64 %[d3], %[d6], %[d2], %[b3m]\n\t"
+        "v_add_u32_dpp %[ta], %[d1], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"  // candidates 0 | 2 (d1 written three instructions ago)
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %[tb], %[d3], %[tb] row_ror:8" HNSW_DPP_BC "\n\t"  // candidates 1 | 3
+        "v_cndmask_b32_e64 %[d0], %[ta], %[tb], %[b2m]\n\t"
+        "v_cndmask_b32_e64 %[d1], %[tb], %[ta], %[b2m]\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[d0], %[d1], %[d0] row_half_mirror" HNSW_DPP_BC "\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"
+        "v_add_u32_e32 %[d0], %[q2], %[d0]\n\t"
+        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"
+        HNSW_ACCEPT("%[co4]")
+        "s_add_u32 %[base], %[base], 16\n"
+        // ---- the round's accepted candidates, in row order, each against the current W (:574-577)
+        "50:\n\t"
+        HNSW_INSERT_LOOP
+        "s_cmp_lt_u32 %[base], %[cnt]\n\t"
+        "s_cbranch_scc1 20b\n\t"
+        "s_branch 1b\n"
+        // ---- no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568)
+        "90:\n\t"
+        "s_cmp_eq_u32 %[oc], 0\n\t"
+        "s_cbranch_scc1 99f\n\t"
+        "s_sub_u32 %[oc], %[oc], 1\n\t"
+        "s_lshl_b32 %[tmp], %[oc], 2\n\t"
+        "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"
+        "v_mov_b32_e32 %[t0], %[tmp]\n\t"
+        "ds_read_b32 %[t0], %[t0] offset:768\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[klo], %[t0]\n\t"
+        "s_mov_b64 %[um0], 0\n\t"
+        "s_mov_b64 %[um1], 0\n\t"
+        "s_branch 4b\n"
+        "99:\n\t"
+        "s_waitcnt vmcnt(0)"                                              // a speculative row fetch may still be in flight
+        : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]),
+          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
+          [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
+          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4),
+          [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
+          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
+          [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
+          [um0] "=&s"(um0), [um1] "=&s"(um1), [fresh] "=&s"(fresh),
+          [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
+          [pref] "=&s"(pref), [cnt] "=&s"(cnt), [base] "=&s"(base),
+          [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t),
+          [nw] "=&s"(nw), [tmp] "=&s"(tmp)
+        : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
+          [nbr] "s"(nbr), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
+          [cand] "s"(cand), [q2] "s"(q2)
+#ifdef HNSW_ASM_DEBUG
+          , [maxh] "s"(maxhops)
+#endif
+        : "vcc", "scc", "m0", "memory");
+    w.wmax = wmax; w.ovf_cnt = (int)oc;
+    n_dist = nd; n_hops = nh; status = st;
+}
+
+} // namespace hnsw_dev
