@@ -404,34 +404,56 @@ def main():
     drop_in = None
     if world == 1 and rank == 0:
         Qh = Qd.cpu().numpy()
-        reps = max(3, min(args.steps, 10))
+        reps = max(5, min(args.steps, 10))
         hi_, hd_ = H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef)       # warm-up, and the exact result of every query
         checks["device_call_equals_drop_in"] = bool(np.array_equal(hi_, got) and np.array_equal(hd_.view(np.uint32), got_dist.view(np.uint32)))
-        t = time.perf_counter()
-        for _ in range(reps):
-            H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef)
-        sync_s = (time.perf_counter() - t) / reps
-        # the same call in two halves (hnsw_search_submit / hnsw_search_wait), two requests in flight
+
+        def timed_calls(fn):
+            ts = []
+            for _ in range(reps):
+                t = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t)
+            ts.sort()
+            return ts[len(ts) // 2], ts[0], ts[-1]
+
+        def leg(med, lo, hi, what):
+            return {"value": round(nq / med, 1), "unit": "queries/s", "ms_per_batch": round(1e3 * med, 4),
+                    "ms_min": round(1e3 * lo, 4), "ms_max": round(1e3 * hi, 4), "what": what}
+
+        # (a) as the reference's benchmark calls it: fresh pageable matrices (the runtime stages the copies)
+        sync_p = timed_calls(lambda: H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef))
+        # (b) the caller registered its query and result matrices once (hnsw_host_register; an OCaml benchmark loop
+        #     passes the same Bigarrays again and again) and the results land in them
+        oi_ = np.empty((nq, k), np.int32)
+        od_ = np.empty((nq, k), np.float32)
+        for a_ in (Qh, oi_, od_):
+            H.pin(a_)
+        H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef, out=(oi_, od_))
+        checks["registered_arrays_equal_device_call"] = bool(np.array_equal(oi_, got) and np.array_equal(od_.view(np.uint32), got_dist.view(np.uint32)))
+        sync_r = timed_calls(lambda: H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef, out=(oi_, od_)))
+        # (c) the same call in two halves (hnsw_search_submit / hnsw_search_wait), two requests in flight
         inflight = []
         for _ in range(6):      # warm-up: every pooled request has its device buffers before the clock starts
             inflight.append(H.submit(hg, Qh, ef, k))
             if len(inflight) > 2:
-                inflight.pop(0).wait()
-        t = time.perf_counter()
-        for _ in range(reps):
+                inflight.pop(0).wait(out=(oi_, od_))
+
+        def one_submit_wait():
             inflight.append(H.submit(hg, Qh, ef, k))
-            inflight.pop(0).wait()
-        sub_s = (time.perf_counter() - t) / reps
+            inflight.pop(0).wait(out=(oi_, od_))
+        sub = timed_calls(one_submit_wait)
         while inflight:
-            inflight.pop(0).wait()
-        drop_in = {"synchronous": {"value": round(nq / sync_s, 1), "unit": "queries/s", "ms_per_batch": round(1e3 * sync_s, 4),
-                                   "what": "hnsw_search_batch: pageable host queries -> H2D -> ordering pre-pass + search kernel -> D2H "
-                                           "-> host ids/distances, one blocking call per %d-query batch (the body of Ohnsw.knn_batch_bigarray)" % nq},
-                   "submit_wait_2_in_flight": {"value": round(nq / sub_s, 1), "unit": "queries/s", "ms_per_batch": round(1e3 * sub_s, 4),
-                                               "what": "hnsw_search_submit / hnsw_search_wait, two requests in flight, same host buffers"},
-                   "batches_timed": reps}
-        log("drop-in (host buffers): synchronous %.0f q/s (%.3f ms/batch), submit/wait x2 %.0f q/s (%.3f ms/batch)" %
-            (nq / sync_s, 1e3 * sync_s, nq / sub_s, 1e3 * sub_s))
+            inflight.pop(0).wait(out=(oi_, od_))
+        for a_ in (Qh, oi_, od_):
+            H.unpin(a_)
+        drop_in = {"synchronous": leg(*sync_r, "hnsw_search_batch, the caller's query / result matrices registered once (hnsw_host_register): H2D -> ordering "
+                                               "pre-pass + search kernel -> D2H, one blocking call per %d-query batch = the body of Ohnsw.knn_batch_bigarray" % nq),
+                   "synchronous_pageable": leg(*sync_p, "the same call on fresh pageable matrices (copies staged by the runtime)"),
+                   "submit_wait_2_in_flight": leg(*sub, "hnsw_search_submit / hnsw_search_wait, two requests in flight, registered matrices"),
+                   "batches_timed": reps, "statistic": "median of the per-call wall times (min / max beside it)"}
+        log("drop-in (host buffers): synchronous %.0f q/s (%.3f ms/batch; pageable %.3f ms), submit/wait x2 %.0f q/s (%.3f ms/batch)" %
+            (nq / sync_r[0], 1e3 * sync_r[0], 1e3 * sync_p[0], nq / sub[0], 1e3 * sub[0]))
     if rank == 0:
         ns = min(1000, nq)
         gt = brute_force_topk(Xd, Qd[:ns], k)

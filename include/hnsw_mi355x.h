@@ -177,6 +177,15 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
                           const hnsw_search_params *params, int32_t *out_ids, float *out_dist,
                           uint32_t *out_ndist, uint32_t *out_nhops);
 
+/* Optional: page-lock a host array of the caller (hipHostRegister) so that the copies of the host-buffer entry points
+ * (hnsw_search_batch, hnsw_search_submit / hnsw_search_wait, hnsw_multi_search_batch) run asynchronously at PCIe speed
+ * instead of being staged by the runtime.  The CALLER owns the lifetime: the array must stay allocated (an OCaml
+ * Bigarray: reachable) until hnsw_host_unregister; the library never registers anything behind the caller's back.
+ * Registering an array twice is not an error.  OCaml side: Hnsw_mi355x.pin / unpin on the query and result Bigarrays of
+ * a benchmark loop (benchmark/benchmark.ml:86-98 passes the same matrices again and again). */
+int32_t hnsw_host_register(void *p, int64_t bytes);
+int32_t hnsw_host_unregister(void *p);
+
 /* Same, device buffers, asynchronous on `stream` (a hipStream_t; NULL = default stream).
  * d_status (optional, [nq] uint32): bit 0 set if the query's list of tied, still expandable
  * candidates outgrew its 64 LDS slots.  THIS ENTRY POINT HAS NO EXACTNESS FALLBACK: entries that did not

@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "hnsw_search_submit", "hnsw_search_wait", "hnsw_index_kernel_times",
     "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
     "hnsw_multi_search_batch_device", "hnsw_multi_copy_result",
+    "hnsw_host_register", "hnsw_host_unregister",
 ]
 
 
@@ -143,6 +144,9 @@ def load():
     L.hnsw_multi_search_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp]
     L.hnsw_multi_search_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp]
     L.hnsw_multi_copy_result.argtypes = [vp, i32, vp, vp]
+    L.hnsw_host_register.argtypes = [vp, i64]
+    L.hnsw_host_unregister.argtypes = [vp]
+    L.hnsw_host_register.restype = L.hnsw_host_unregister.restype = i32
     for f in ("hnsw_search_layer_batch", "hnsw_search_one_batch", "hnsw_multi_create", "hnsw_multi_destroy",
               "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
               "hnsw_multi_search_batch_device", "hnsw_multi_copy_result"):
@@ -352,13 +356,34 @@ class Hgraph:
             pass
 
 
-def _search(hgraph, batch, ef, k, fill, counters=False, sem=0):
+def pin(array):
+    """hnsw_host_register: page-lock a host array the caller keeps alive (its query or result matrix of a benchmark
+    loop), so that the host-buffer entry points copy it at PCIe speed.  Undo with unpin() BEFORE the array is freed."""
+    a = _np.asarray(array)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise InvalidArgument("pin: array must be C-contiguous")
+    _check(load().hnsw_host_register(_ptr(a), a.nbytes))
+    return array
+
+
+def unpin(array):
+    """hnsw_host_unregister"""
+    _check(load().hnsw_host_unregister(_ptr(_np.asarray(array))))
+
+
+def _search(hgraph, batch, ef, k, fill, counters=False, sem=0, out=None):
     Q, qs = _rows(batch)
     if Q.ndim != 2 or (Q.shape[0] and Q.shape[1] != hgraph.d):
         raise InvalidArgument("batch must be [nq][d]")
     nq = Q.shape[0]
-    ids = _np.empty((nq, k), _np.int32)
-    dist = _np.empty((nq, k), _np.float32)
+    if out is not None:      # result matrices of the caller (e.g. pinned ones it reuses batch after batch)
+        ids, dist = out
+        if ids.shape != (nq, k) or dist.shape != (nq, k) or ids.dtype != _np.int32 or dist.dtype != _np.float32 \
+                or not ids.flags["C_CONTIGUOUS"] or not dist.flags["C_CONTIGUOUS"]:
+            raise InvalidArgument("out must be (int32 [nq][k], float32 [nq][k]), C-contiguous")
+    else:
+        ids = _np.empty((nq, k), _np.int32)
+        dist = _np.empty((nq, k), _np.float32)
     nd = _np.zeros(nq, _np.uint32) if counters else None
     nh = _np.zeros(nq, _np.uint32) if counters else None
     p = _SearchParams(ef, k, fill, sem)
@@ -375,11 +400,16 @@ class Request:
     def __init__(self, hgraph, handle, nq, k, keep):
         self._hg, self._h, self.nq, self.k, self._keep = hgraph, handle, nq, k, keep
 
-    def wait(self, counters=False):
+    def wait(self, counters=False, out=None):
         if self._h is None:
             raise InvalidArgument("request already waited for")
-        ids = _np.empty((self.nq, self.k), _np.int32)
-        dist = _np.empty((self.nq, self.k), _np.float32)
+        if out is not None:
+            ids, dist = out
+            if ids.shape != (self.nq, self.k) or dist.shape != (self.nq, self.k) or ids.dtype != _np.int32 or dist.dtype != _np.float32:
+                raise InvalidArgument("out must be (int32 [nq][k], float32 [nq][k])")
+        else:
+            ids = _np.empty((self.nq, self.k), _np.int32)
+            dist = _np.empty((self.nq, self.k), _np.float32)
         nd = _np.zeros(self.nq, _np.uint32) if counters else None
         nh = _np.zeros(self.nq, _np.uint32) if counters else None
         h, self._h, self._keep = self._h, None, None
@@ -418,10 +448,11 @@ class Ohnsw:
         return [(int(i), float(d)) for i, d in zip(ids[0], dist[0]) if i >= hgraph.id_base]
 
     @staticmethod
-    def knn_batch_bigarray(hgraph, k, batch, ef=None, counters=False):
+    def knn_batch_bigarray(hgraph, k, batch, ef=None, counters=False, out=None):
         """Ohnsw.knn_batch_bigarray hgraph ~k batch (lib/ohnsw.ml:877-897) -> (ids, distances):
-        ids [nq][k] (-1 where fewer than k were found), distances [nq][k] fp32 (NaN there)."""
-        return _search(hgraph, batch, k if ef is None else ef, k, FILL_OHNSW, counters)
+        ids [nq][k] (-1 where fewer than k were found), distances [nq][k] fp32 (NaN there).
+        out = (ids, distances): write into the caller's matrices instead of fresh ones."""
+        return _search(hgraph, batch, k if ef is None else ef, k, FILL_OHNSW, counters, out=out)
 
     @staticmethod
     def search_k(hgraph, layer, start_nodes, targets, k, ef=None, sem=SEM_OHNSW, counters=False):

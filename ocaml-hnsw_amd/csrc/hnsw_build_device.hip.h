@@ -406,13 +406,19 @@ build_link_sequential_kernel(const BuildView bv, const LinkArgs la) {
             if (in) continue;                                       // uniform
             int xv;
             const int nx = read_list(x, xv);
-            // survivors, in list order, then reversed
+            // survivors, in list order, then reversed.  The list holds up to 65 entries (the virtual cons of q in
+            // front of a full 64-entry row): entry 64 is taken separately, it is the last in list order
             const int e = lane < nx ? u_id[lane] : -1;
-            const uint64_t sm = ballot(lane < nx && e != nb);
+            const bool keep = lane < nx && e != nb;
+            const uint64_t sm = ballot(keep);
             const int spos = popc(sm & ((1ull << lane) - 1ull));
-            const int ns = popc(sm);
+            int ns = popc(sm);
+            const int e64 = nx > 64 ? u_id[64] : -1;                // wave-uniform
+            const bool keep64 = nx > 64 && e64 != nb;
             __syncthreads();
-            if (lane < nx && e != nb) s_key[spos] = (uint32_t)e;    // s_key is free here: reuse it as the survivor list
+            if (keep) s_key[spos] = (uint32_t)e;                    // s_key is free here: reuse it as the survivor list
+            if (keep64 && lane == 0) s_key[ns] = (uint32_t)e64;
+            ns += keep64 ? 1 : 0;
             __syncthreads();
             int w;
             int32_t *xrow = row_ptr_w(bv, la.layer, x, w);

@@ -295,10 +295,10 @@ int32_t hnsw_index_destroy(hnsw_index *idx) {
     if (!idx) return HNSW_OK;
     if (idx->device >= 0) (void)hipSetDevice(idx->device);
     for (void *p : {idx->dX, idx->dX8, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl, idx->dRef}) if (p) (void)hipFree(p);
-    idx->sQ.release(); idx->sIds.release(); idx->sDist.release(); idx->sNd.release(); idx->sNh.release(); idx->sSt.release();
+    idx->sQ.release(); idx->sIds.release(); idx->sDist.release(); idx->sNd.release(); idx->sNh.release(); idx->sSt.release(); idx->sFlag.release();
     (void)hipDeviceSynchronize();                      // requests never waited for
     for (hnsw_request *r : idx->all_requests) {
-        r->q.release(); r->ids.release(); r->dist.release(); r->nd.release(); r->nh.release(); r->st.release();
+        r->q.release(); r->ids.release(); r->dist.release(); r->nd.release(); r->nh.release(); r->st.release(); r->flag.release();
         delete r;
     }
     for (hipStream_t st : idx->hs) if (st) (void)hipStreamDestroy(st);
@@ -363,9 +363,21 @@ int launch_search_args(hnsw_index *idx, SearchArgs &a, hipStream_t st) {
 }
 } // namespace
 
+extern "C++" {
+namespace hnsw_host {
+int search_batch_device_flag(hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
+                             const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
+                             uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, uint32_t *d_any_flag, void *stream);
+}
+}
 int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
                                  const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
                                  uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, void *stream) {
+    return search_batch_device_flag(idx, d_queries, nq, q_stride, params, d_ids, d_dist, d_ndist, d_nhops, d_status, nullptr, stream);
+}
+extern "C++" int hnsw_host::search_batch_device_flag(hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
+                                 const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
+                                 uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, uint32_t *d_any_flag, void *stream) {
     int rc = check_params(idx, params);
     if (rc) return rc;
     if (nq < 0 || nq > 0x7FFFFFFFLL) return fail(HNSW_ERR_BAD_ARG, "nq out of range");
@@ -377,6 +389,7 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
     a.Q = d_queries; a.q_stride = q_stride; a.nq = nq; a.ef = params->ef; a.k = params->k; a.fill = params->fill; a.sem = params->semantics;
     a.vt_bits = search_vt_bits(idx, params->ef);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_ndist; a.out_nhops = d_nhops; a.out_status = d_status;
+    a.any_flag = d_any_flag;
     // A batch larger than the chip holds at once is searched longest walk first (hnsw_order.hip):
     // per-query results are unchanged, the launch's drain phase is made of short walks.
     void *block = nullptr;
@@ -444,27 +457,34 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
     const size_t qbytes = ((size_t)(nq - 1) * q_stride + idx->iv.d) * sizeof(float);
     if ((rc = idx->sQ.ensure(qbytes)) || (rc = idx->sIds.ensure((size_t)nq * k * 4)) ||
         (rc = idx->sDist.ensure((size_t)nq * k * 4)) || (rc = idx->sNd.ensure((size_t)nq * 4)) ||
-        (rc = idx->sNh.ensure((size_t)nq * 4)) || (rc = idx->sSt.ensure((size_t)nq * 4)))
+        (rc = idx->sNh.ensure((size_t)nq * 4)) || (rc = idx->sSt.ensure((size_t)nq * 4)) || (rc = idx->sFlag.ensure(16)))
         return rc;
-    // Upload, search (ordered longest walk first when the batch is larger than the chip holds) and
-    // download on one of the handle's streams.  (Splitting the batch into chunks on two streams to
-    // overlap the copies with the search was measured too: 1.08 ms against 1.06 ms for this.)
+    // Upload, search (ordered longest walk first when the batch is larger than the chip holds) and download on one
+    // of the handle's streams, ONE stream synchronisation at the end.  The copies run at PCIe speed when the caller
+    // registered its arrays (hnsw_host_register); from pageable memory the runtime stages them.  Whether any query
+    // needs the exactness fallback comes back as one word beside the results (the kernel sets it), not as a scan of
+    // nq status words.  (Splitting the batch into chunks on two streams to overlap the copies with the search was
+    // measured too: 1.08 ms against 1.06 ms for this.)
     if (!idx->hs[0]) HIP_TRY(hipStreamCreateWithFlags(&idx->hs[0], hipStreamNonBlocking));
     hipStream_t st = idx->hs[0];
     const float *dQ = (const float *)idx->sQ.p;
+    uint32_t flag = 0;
+    HIP_TRY(hipMemsetAsync(idx->sFlag.p, 0, 4, st));
     HIP_TRY(hipMemcpyAsync(idx->sQ.p, queries, qbytes, hipMemcpyHostToDevice, st));
-    rc = hnsw_search_batch_device(idx, dQ, nq, q_stride, params, (int32_t *)idx->sIds.p, (float *)idx->sDist.p,
-                                  (uint32_t *)idx->sNd.p, (uint32_t *)idx->sNh.p, (uint32_t *)idx->sSt.p, st);
-    if (rc) { (void)hipDeviceSynchronize(); return rc; }
-    auto copy_out = [&](int64_t lo, int64_t cnt, hipStream_t s_) -> int {
-        HIP_TRY(hipMemcpyAsync(out_ids + lo * k, (int32_t *)idx->sIds.p + lo * k, (size_t)cnt * k * 4, hipMemcpyDeviceToHost, s_));
-        HIP_TRY(hipMemcpyAsync(out_dist + lo * k, (float *)idx->sDist.p + lo * k, (size_t)cnt * k * 4, hipMemcpyDeviceToHost, s_));
-        if (out_ndist) HIP_TRY(hipMemcpyAsync(out_ndist + lo, (uint32_t *)idx->sNd.p + lo, (size_t)cnt * 4, hipMemcpyDeviceToHost, s_));
-        if (out_nhops) HIP_TRY(hipMemcpyAsync(out_nhops + lo, (uint32_t *)idx->sNh.p + lo, (size_t)cnt * 4, hipMemcpyDeviceToHost, s_));
+    rc = search_batch_device_flag(idx, dQ, nq, q_stride, params, (int32_t *)idx->sIds.p, (float *)idx->sDist.p,
+                                  (uint32_t *)idx->sNd.p, (uint32_t *)idx->sNh.p, (uint32_t *)idx->sSt.p, (uint32_t *)idx->sFlag.p, st);
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    auto copy_out = [&](hipStream_t s_) -> int {
+        HIP_TRY(hipMemcpyAsync(out_ids, idx->sIds.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s_));
+        HIP_TRY(hipMemcpyAsync(out_dist, idx->sDist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s_));
+        if (out_ndist) HIP_TRY(hipMemcpyAsync(out_ndist, idx->sNd.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s_));
+        if (out_nhops) HIP_TRY(hipMemcpyAsync(out_nhops, idx->sNh.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s_));
         return HNSW_OK;
     };
-    if ((rc = copy_out(0, nq, st))) { (void)hipDeviceSynchronize(); return rc; }
-    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = copy_out(st))) { (void)hipStreamSynchronize(st); return rc; }
+    HIP_TRY(hipMemcpyAsync(&flag, idx->sFlag.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!(flag & 1u)) return HNSW_OK;
     // Exactness fallback for queries whose tie-overflow stack outgrew its LDS slots (rare: the rows
     // of the whole batch are then copied out again)
     int64_t n_rerun = 0;
@@ -476,7 +496,7 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
                           }, &n_rerun);
     if (rc) return rc;
     if (n_rerun > 0) {
-        if ((rc = copy_out(0, nq, nullptr))) return rc;
+        if ((rc = copy_out(nullptr))) return rc;
         HIP_TRY(hipDeviceSynchronize());
     }
     return HNSW_OK;
@@ -502,14 +522,18 @@ int32_t hnsw_search_submit(hnsw_index *idx, const float *queries, int64_t nq, in
     const int k = params->k;
     const size_t qbytes = ((size_t)(nq - 1) * q_stride + idx->iv.d) * sizeof(float);
     if ((rc = r->q.ensure(qbytes)) || (rc = r->ids.ensure((size_t)nq * k * 4)) || (rc = r->dist.ensure((size_t)nq * k * 4)) ||
-        (rc = r->nd.ensure((size_t)nq * 4)) || (rc = r->nh.ensure((size_t)nq * 4)) || (rc = r->st.ensure((size_t)nq * 4)))
+        (rc = r->nd.ensure((size_t)nq * 4)) || (rc = r->nh.ensure((size_t)nq * 4)) || (rc = r->st.ensure((size_t)nq * 4)) ||
+        (rc = r->flag.ensure(16)))
         return give_back(rc);
     hipStream_t st = idx->hs[r->stream];
     if (hipMemcpyAsync(r->q.p, queries, qbytes, hipMemcpyHostToDevice, st) != hipSuccess)
         return give_back(fail(HNSW_ERR_HIP, "query upload failed"));
-    rc = hnsw_search_batch_device(idx, (const float *)r->q.p, nq, q_stride, params, (int32_t *)r->ids.p, (float *)r->dist.p,
-                                  (uint32_t *)r->nd.p, (uint32_t *)r->nh.p, (uint32_t *)r->st.p, st);
+    if (hipMemsetAsync(r->flag.p, 0, 4, st) != hipSuccess) return give_back(fail(HNSW_ERR_HIP, "hipMemsetAsync failed"));
+    rc = search_batch_device_flag(idx, (const float *)r->q.p, nq, q_stride, params, (int32_t *)r->ids.p, (float *)r->dist.p,
+                                  (uint32_t *)r->nd.p, (uint32_t *)r->nh.p, (uint32_t *)r->st.p, (uint32_t *)r->flag.p, st);
     if (rc) return give_back(rc);
+    // the results follow the search on the request's stream: hnsw_search_wait only has to wait for them
+    r->host_flag = 0;
     idx->live_requests++;
     *out = r;
     return HNSW_OK;
@@ -522,10 +546,20 @@ int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uin
     if (!out_ids || !out_dist) return done(fail(HNSW_ERR_BAD_ARG, "null result buffers"));
     if (hipSetDevice(idx->device) != hipSuccess) return done(fail(HNSW_ERR_HIP, "hipSetDevice failed"));
     hipStream_t st = idx->hs[r->stream];
-    if (hipStreamSynchronize(st) != hipSuccess) return done(fail(HNSW_ERR_HIP, "search failed: %s", hipGetErrorString(hipGetLastError())));
     const int k = r->params.k;
     const int64_t nq = r->nq;
-    // exactness fallback for queries whose tie-overflow stack outgrew its LDS slots (as in hnsw_search_batch)
+    // results and the "any query flagged" word in one go; the exactness fallback (as in hnsw_search_batch) only if set
+    uint32_t flag = 0;
+    {
+        hipError_t e0 = hipMemcpyAsync(out_ids, r->ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st);
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(out_dist, r->dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st);
+        if (e0 == hipSuccess && out_ndist) e0 = hipMemcpyAsync(out_ndist, r->nd.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
+        if (e0 == hipSuccess && out_nhops) e0 = hipMemcpyAsync(out_nhops, r->nh.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(&flag, r->flag.p, 4, hipMemcpyDeviceToHost, st);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);
+        if (e0 != hipSuccess) return done(fail(HNSW_ERR_HIP, "search failed: %s", hipGetErrorString(e0)));
+    }
+    if (!(flag & 1u)) return done(HNSW_OK);
     int rc = rerun_overflowed(idx, nq, (const uint32_t *)r->st.p,
                               [&](const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap) {
                                   return search_rerun_device(idx, (const float *)r->q.p, nq, r->q_stride, &r->params, (int32_t *)r->ids.p,
@@ -540,6 +574,21 @@ int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uin
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return done(fail(HNSW_ERR_HIP, "result download failed: %s", hipGetErrorString(e)));
     return done(HNSW_OK);
+}
+
+int32_t hnsw_host_register(void *p, int64_t bytes) {
+    if (!p || bytes <= 0) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_register: null buffer or bytes <= 0");
+    hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return HNSW_OK; }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostRegister(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); }
+    return HNSW_OK;
+}
+
+int32_t hnsw_host_unregister(void *p) {
+    if (!p) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_unregister: null buffer");
+    hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e)); }
+    return HNSW_OK;
 }
 
 int32_t hnsw_knn(hnsw_index *idx, const float *query, const hnsw_search_params *params,

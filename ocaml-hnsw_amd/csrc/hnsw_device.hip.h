@@ -82,6 +82,8 @@ struct SearchArgs {
     const uint32_t *pre_key;
     const uint32_t *pre_nd;
     int32_t pre_layer;       // the pre-pass descended through layers max_layer..pre_layer; this kernel continues below
+    uint32_t *any_flag;      // optional: one word, bit 0 set when ANY query of the launch carries status bit 0 (the host-buffer
+                             // entry points read this word back with the results instead of scanning nq status words)
 };
 
 // ---- distance keys -------------------------------------------------------------------------
@@ -212,20 +214,18 @@ __device__ __forceinline__ uint32_t wrlane(uint32_t v, uint32_t val, int lane) {
 // NB batches of 4 rows, straight-line: all ids are read from LDS first, then all NB*NCH
 // global_load_dwordx4 are issued, then consumed.  A group whose candidate index is past cnt
 // re-reads the row of group 0 of its batch (same addresses: coalesced, no extra traffic) and its
-// result is dropped, so no load sits behind an exec-mask branch.  Row offsets are 32-bit in
-// float4 units (tables up to 64 GiB).
+// result is dropped, so no load sits behind an exec-mask branch.
 template <int NCH, int NB, int METRIC, bool FULL>
 __device__ __forceinline__ void eval_nb(const IndexView &iv, const float4 (&qv)[NCH],
                                         const int32_t *cand_id, uint32_t *cand_key,
                                         uint32_t *trash, int base, int cnt, int r, int l16) {
-    const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
-    const uint32_t stride4 = (uint32_t)(iv.stride >> 2);
-    uint32_t row4[NB];
+    const uint32_t stride_b = (uint32_t)iv.stride * 4u;
+    const char *row[NB];     // 64-bit row addresses (base + id * stride, one v_mad_u64_u32): no table-size limit
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int ci = base + 4 * b + r;
         const int ce = ci < cnt ? ci : base + 4 * b;
-        row4[b] = (uint32_t)cand_id[ce] * stride4;
+        row[b] = reinterpret_cast<const char *>(iv.X) + (uint64_t)(uint32_t)cand_id[ce] * stride_b;
     }
     float4 v[NB][NCH];
 #pragma unroll
@@ -233,8 +233,7 @@ __device__ __forceinline__ void eval_nb(const IndexView &iv, const float4 (&qv)[
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = i * 16 + l16;
-            if (FULL) v[b][i] = X4[row4[b] + (uint32_t)c];
-            else v[b][i] = X4[row4[b] + (uint32_t)(c < iv.nchunks ? c : 0)];
+            v[b][i] = *reinterpret_cast<const float4 *>(row[b] + 16u * (uint32_t)((FULL || c < iv.nchunks) ? c : 0));
         }
     }
 #pragma unroll
@@ -1205,6 +1204,9 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
         if (a.out_nhops) a.out_nhops[q] = n_hops;
 #endif
         if (a.out_status) a.out_status[q] = status;
+#ifndef HNSW_PHASE_TIMING
+        if ((status & 1u) && a.any_flag) atomicOr(a.any_flag, 1u);
+#endif
     }
 }
 
@@ -1264,19 +1266,18 @@ hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64
     if (q >= nq) return;
     float4 qv[NCH];
     load_query<NCH>(qv, Q + q * q_stride, iv.d, l16);
-    const float4 *X4 = reinterpret_cast<const float4 *>(iv.X);
-    const uint32_t stride4 = (uint32_t)(iv.stride >> 2);
+    const uint32_t stride_b = (uint32_t)iv.stride * 4u;
     for (int base = blockIdx.y * 4 * UB; base < m; base += 4 * UB * gridDim.y) {
         float4 v[UB][NCH];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int j = base + 4 * u + r;
             const int je = j < m ? j : base;            // past the end: re-read a row already in flight
-            const uint32_t row4 = (uint32_t)(ids[q * m + je] - iv.id_base) * stride4;
+            const char *row = reinterpret_cast<const char *>(iv.X) + (uint64_t)(uint32_t)(ids[q * m + je] - iv.id_base) * stride_b;   // 64-bit: no table-size limit
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int c = i * 16 + l16;
-                v[u][i] = X4[row4 + (uint32_t)(c < iv.nchunks ? c : 0)];
+                v[u][i] = *reinterpret_cast<const float4 *>(row + 16u * (uint32_t)(c < iv.nchunks ? c : 0));
             }
         }
 #pragma unroll

@@ -70,8 +70,9 @@ struct hnsw_request {
     hnsw_index *idx = nullptr;
     int64_t nq = 0, q_stride = 0;
     hnsw_search_params params{};
-    hnsw_host::DevBuf q, ids, dist, nd, nh, st;
+    hnsw_host::DevBuf q, ids, dist, nd, nh, st, flag;
     int stream = 0;
+    uint32_t host_flag = 0;
 };
 
 struct hnsw_index {
@@ -81,7 +82,7 @@ struct hnsw_index {
     void *dX8 = nullptr;                 // byte rows (hnsw_rows8.hip), nullptr when the data does not qualify
     void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr, *dRef = nullptr;
     int64_t rowsU = 0;
-    hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt; // scratch for the host-buffer entry points
+    hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt, sFlag; // scratch for the host-buffer entry points (sFlag: the launch's "any query flagged" word)
     hipStream_t hs[4] = {nullptr, nullptr, nullptr, nullptr}; // streams of the chunked host-buffer search and of requests (lazy)
     std::vector<hnsw_request *> free_requests;               // finished requests keep their buffers for the next submit
     std::vector<hnsw_request *> all_requests;                // every request ever created (released with the index)
@@ -115,6 +116,10 @@ int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, i
                         void **block, const int32_t **qmap, const int32_t **pre_entry, const uint32_t **pre_key,
                         const uint32_t **pre_nd, int32_t *pre_layer);
 
+// hnsw_search_batch_device plus the optional device word that collects status bit 0 of the whole launch
+int search_batch_device_flag(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
+                             const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
+                             uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, uint32_t *d_any_flag, void *stream);
 // parameter / handle checks shared by every search entry point (HNSW_ERR_BAD_ARG, HNSW_ERR_EMPTY_INDEX, ...)
 int search_check(const ::hnsw_index *idx, const hnsw_search_params *p);
 // launch of the exactness fallback (see rerun_overflowed): `c` flagged queries, listed in qmap, searched again

@@ -64,12 +64,11 @@ struct hnsw_multi {
     RcclApi rccl;
     std::vector<ncclComm_t> comms;        // [G], created at the first device-resident search
     std::vector<hipStream_t> streams;     // [G]
+    std::vector<hipEvent_t> done;         // [G] "this device's search is enqueued up to here" (the same-device copy arrangement)
     std::vector<DevBuf> dQ, dIds, dDist, dNd, dNh, dSt;   // per device: its query shard; the FULL [nq][k] result; per-shard counters
     int64_t last_nq = 0; int last_k = 0;
-    // host buffers of the caller pinned with hipHostRegister (kept between calls: a benchmark loop passes
-    // the same arrays again and again); unregistered with the handle
-    struct Pin { const void *p; size_t bytes; };
-    std::vector<Pin> pins;
+    std::vector<DevBuf> dFlag;            // per device: the launch's "any query flagged" word (see hnsw_search_batch)
+    uint32_t *hFlags = nullptr;           // [G] pinned host words the flags are copied into
 };
 
 namespace {
@@ -84,10 +83,14 @@ int ensure_streams(hnsw_multi *m) {
     const size_t G = m->replicas.size();
     if (m->streams.size() == G) return HNSW_OK;
     m->streams.assign(G, nullptr);
-    m->dQ.resize(G); m->dIds.resize(G); m->dDist.resize(G); m->dNd.resize(G); m->dNh.resize(G); m->dSt.resize(G);
+    m->dQ.resize(G); m->dIds.resize(G); m->dDist.resize(G); m->dNd.resize(G); m->dNh.resize(G); m->dSt.resize(G); m->dFlag.resize(G);
+    if (!m->hFlags) HIP_TRY(hipHostMalloc((void **)&m->hFlags, G * sizeof(uint32_t), hipHostMallocPortable));
     for (size_t g = 0; g < G; ++g) {
         HIP_TRY(hipSetDevice(m->devices[g]));
         HIP_TRY(hipStreamCreateWithFlags(&m->streams[g], hipStreamNonBlocking));
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->done.push_back(e);
     }
     return HNSW_OK;
 }
@@ -105,17 +108,7 @@ int ensure_comms(hnsw_multi *m) {
     return HNSW_OK;
 }
 
-// pin a caller's host buffer once (no-op when already pinned, silently unpinned when the runtime refuses:
-// the copies then run from pageable memory as before)
-void pin_host(hnsw_multi *m, const void *p, size_t bytes) {
-    if (!p || bytes < (64u << 10)) return;
-    for (const auto &q : m->pins) if (q.p == p && q.bytes >= bytes) return;
-    for (size_t i = 0; i < m->pins.size(); ++i)
-        if (m->pins[i].p == p) { (void)hipHostUnregister(const_cast<void *>(p)); m->pins.erase(m->pins.begin() + (long)i); break; }
-    if (m->pins.size() >= 16) { (void)hipHostUnregister(const_cast<void *>(m->pins.front().p)); m->pins.erase(m->pins.begin()); }
-    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) == hipSuccess) m->pins.push_back({p, bytes});
-    else (void)hipGetLastError();
-}
+int sync_all(hnsw_multi *m);
 
 // Sharded search + gather: on return every device's dIds / dDist hold the full [nq][k] result.
 int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q_stride, const hnsw_search_params *params,
@@ -126,12 +119,17 @@ int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q
     if ((rc = ensure_streams(m)) || (rc = ensure_comms(m))) return rc;
     const int d = m->replicas[0]->iv.d;
     const size_t full = (size_t)nq * k;
-    // ---- per device: upload the shard, search it (results straight into the shard's slice of the full table) ----
+    // ---- per device: upload the shard, search it (results straight into the shard's slice of the full table).  Nothing
+    //      below waits on the host until every device has its search AND the exchange enqueued: whether a shard needs
+    //      the exactness fallback comes back as one word per device, read after the exchange ----
     for (int g = 0; g < G; ++g) {
         const int64_t lo = shard_lo(nq, g, G), hi = shard_lo(nq, g + 1, G);
         hnsw_index *idx = m->replicas[(size_t)g];
         HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
-        if ((rc = m->dIds[(size_t)g].ensure(std::max<size_t>(full, 1) * 4)) || (rc = m->dDist[(size_t)g].ensure(std::max<size_t>(full, 1) * 4))) return rc;
+        if ((rc = m->dIds[(size_t)g].ensure(std::max<size_t>(full, 1) * 4)) || (rc = m->dDist[(size_t)g].ensure(std::max<size_t>(full, 1) * 4)) ||
+            (rc = m->dFlag[(size_t)g].ensure(16)))
+            return rc;
+        m->hFlags[g] = 0;
         if (hi <= lo) continue;
         const int64_t ns = hi - lo;
         const size_t qbytes = ((size_t)(ns - 1) * q_stride + d) * sizeof(float);
@@ -139,62 +137,62 @@ int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q
             (rc = m->dNh[(size_t)g].ensure((size_t)ns * 4)) || (rc = m->dSt[(size_t)g].ensure((size_t)ns * 4)))
             return rc;
         hipStream_t st = m->streams[(size_t)g];
+        HIP_TRY(hipMemsetAsync(m->dFlag[(size_t)g].p, 0, 4, st));
         HIP_TRY(hipMemcpyAsync(m->dQ[(size_t)g].p, queries + lo * q_stride, qbytes, hipMemcpyHostToDevice, st));
-        rc = hnsw_search_batch_device(idx, (const float *)m->dQ[(size_t)g].p, ns, q_stride, params,
+        rc = search_batch_device_flag(idx, (const float *)m->dQ[(size_t)g].p, ns, q_stride, params,
                                       (int32_t *)m->dIds[(size_t)g].p + lo * k, (float *)m->dDist[(size_t)g].p + lo * k,
-                                      (uint32_t *)m->dNd[(size_t)g].p, (uint32_t *)m->dNh[(size_t)g].p, (uint32_t *)m->dSt[(size_t)g].p, st);
+                                      (uint32_t *)m->dNd[(size_t)g].p, (uint32_t *)m->dNh[(size_t)g].p, (uint32_t *)m->dSt[(size_t)g].p,
+                                      (uint32_t *)m->dFlag[(size_t)g].p, st);
         if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(&m->hFlags[g], m->dFlag[(size_t)g].p, 4, hipMemcpyDeviceToHost, st));
     }
-    // ---- exactness fallback per shard (queries whose tie list outgrew its LDS slots), before the exchange ----
-    for (int g = 0; g < G; ++g) {
-        const int64_t lo = shard_lo(nq, g, G), hi = shard_lo(nq, g + 1, G);
-        if (hi <= lo) continue;
-        hnsw_index *idx = m->replicas[(size_t)g];
-        HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
-        HIP_TRY(hipStreamSynchronize(m->streams[(size_t)g]));
-        rc = rerun_overflowed(idx, hi - lo, (const uint32_t *)m->dSt[(size_t)g].p,
-                              [&](const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap) {
-                                  return search_rerun_device(idx, (const float *)m->dQ[(size_t)g].p, hi - lo, q_stride, params,
-                                                             (int32_t *)m->dIds[(size_t)g].p + lo * k, (float *)m->dDist[(size_t)g].p + lo * k,
-                                                             (uint32_t *)m->dNd[(size_t)g].p, (uint32_t *)m->dNh[(size_t)g].p,
-                                                             (uint32_t *)m->dSt[(size_t)g].p, qmap, c, slab, cap, nullptr);
-                              });
-        if (rc) return rc;
-        if (out_ndist) HIP_TRY(hipMemcpyAsync(out_ndist + lo, m->dNd[(size_t)g].p, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, m->streams[(size_t)g]));
-        if (out_nhops) HIP_TRY(hipMemcpyAsync(out_nhops + lo, m->dNh[(size_t)g].p, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, m->streams[(size_t)g]));
-    }
-    // ---- the exchange: every device receives every shard ----
-    if (G > 1 || m->distinct) {
+    // ---- the exchange: every device receives every shard (shards [r_lo, r_hi) only: the whole table, or, after the
+    //      fallback, the repaired shards again) ----
+    auto exchange = [&](int only_shard) -> int {
+        if (!(G > 1 || m->distinct)) return HNSW_OK;
         if (m->distinct) {
-            const bool equal = nq % G == 0;
+            const bool equal = nq % G == 0 && only_shard < 0;
             RCCL_TRY(m, m->rccl.GroupStart());
-            for (int g = 0; g < G; ++g) {
-                HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
+            int err = HNSW_OK;
+            for (int g = 0; g < G && !err; ++g) {
+                if (hipSetDevice(m->devices[(size_t)g]) != hipSuccess) { err = fail(HNSW_ERR_HIP, "hipSetDevice failed"); break; }
                 int32_t *ids = (int32_t *)m->dIds[(size_t)g].p;
                 float *dd = (float *)m->dDist[(size_t)g].p;
+                ncclResult_t r1 = ncclSuccess;
                 if (equal) {       // in place: the send buffer is this rank's slice of the receive buffer
                     const size_t cnt = (size_t)(nq / G) * k;
-                    RCCL_TRY(m, m->rccl.AllGather(ids + (size_t)g * cnt, ids, cnt, ncclInt32, m->comms[(size_t)g], m->streams[(size_t)g]));
-                    RCCL_TRY(m, m->rccl.AllGather(dd + (size_t)g * cnt, dd, cnt, ncclFloat32, m->comms[(size_t)g], m->streams[(size_t)g]));
+                    r1 = m->rccl.AllGather(ids + (size_t)g * cnt, ids, cnt, ncclInt32, m->comms[(size_t)g], m->streams[(size_t)g]);
+                    if (r1 == ncclSuccess) r1 = m->rccl.AllGather(dd + (size_t)g * cnt, dd, cnt, ncclFloat32, m->comms[(size_t)g], m->streams[(size_t)g]);
                 } else {           // unequal shards: one in-place broadcast per shard (all-gather-v)
-                    for (int r = 0; r < G; ++r) {
+                    for (int r = 0; r < G && r1 == ncclSuccess; ++r) {
+                        if (only_shard >= 0 && r != only_shard) continue;
                         const int64_t lo = shard_lo(nq, r, G), hi = shard_lo(nq, r + 1, G);
                         if (hi <= lo) continue;
-                        RCCL_TRY(m, m->rccl.Broadcast(ids + lo * k, ids + lo * k, (size_t)(hi - lo) * k, ncclInt32, r, m->comms[(size_t)g], m->streams[(size_t)g]));
-                        RCCL_TRY(m, m->rccl.Broadcast(dd + lo * k, dd + lo * k, (size_t)(hi - lo) * k, ncclFloat32, r, m->comms[(size_t)g], m->streams[(size_t)g]));
+                        r1 = m->rccl.Broadcast(ids + lo * k, ids + lo * k, (size_t)(hi - lo) * k, ncclInt32, r, m->comms[(size_t)g], m->streams[(size_t)g]);
+                        if (r1 == ncclSuccess) r1 = m->rccl.Broadcast(dd + lo * k, dd + lo * k, (size_t)(hi - lo) * k, ncclFloat32, r, m->comms[(size_t)g], m->streams[(size_t)g]);
                     }
                 }
+                if (r1 != ncclSuccess) err = fail(HNSW_ERR_HIP, "RCCL exchange failed: %s", m->rccl.GetErrorString(r1));
             }
-            RCCL_TRY(m, m->rccl.GroupEnd());
+            // the group is ALWAYS closed: an early return between GroupStart and GroupEnd would leave this thread
+            // inside an open group and every later call on these communicators would misbehave
+            ncclResult_t re = m->rccl.GroupEnd();
+            if (err) return err;
+            if (re != ncclSuccess) return fail(HNSW_ERR_HIP, "ncclGroupEnd failed: %s", m->rccl.GetErrorString(re));
         } else {
             // several replicas on one device (a test arrangement): RCCL refuses duplicate devices, and the
             // "exchange" between buffers of the same device is a device-to-device copy
             for (int g = 0; g < G; ++g) {
                 HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
                 for (int r = 0; r < G; ++r) {
-                    if (r == g) continue;
+                    if (r == g || (only_shard >= 0 && r != only_shard)) continue;
                     const int64_t lo = shard_lo(nq, r, G), hi = shard_lo(nq, r + 1, G);
                     if (hi <= lo) continue;
+                    // the copy runs on the RECEIVER's stream: it must not start before the sender's search is done
+                    if (only_shard < 0) {
+                        hipEvent_t ev = m->done[(size_t)r];
+                        HIP_TRY(hipStreamWaitEvent(m->streams[(size_t)g], ev, 0));
+                    }
                     HIP_TRY(hipMemcpyPeerAsync((int32_t *)m->dIds[(size_t)g].p + lo * k, m->devices[(size_t)g], (int32_t *)m->dIds[(size_t)r].p + lo * k,
                                                m->devices[(size_t)r], (size_t)(hi - lo) * k * 4, m->streams[(size_t)g]));
                     HIP_TRY(hipMemcpyPeerAsync((float *)m->dDist[(size_t)g].p + lo * k, m->devices[(size_t)g], (float *)m->dDist[(size_t)r].p + lo * k,
@@ -202,6 +200,36 @@ int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q
                 }
             }
         }
+        return HNSW_OK;
+    };
+    if (!m->distinct) {   // the copy arrangement orders receiver streams behind sender streams with one event per device
+        for (int g = 0; g < G; ++g) {
+            HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
+            HIP_TRY(hipEventRecord(m->done[(size_t)g], m->streams[(size_t)g]));
+        }
+    }
+    if ((rc = exchange(-1))) return rc;
+    // ---- now the one host round trip: wait, read the flag words; a flagged shard (rare) is searched again with the
+    //      global slab and its slice of the table is sent round once more ----
+    if ((rc = sync_all(m))) return rc;
+    for (int g = 0; g < G; ++g) {
+        const int64_t lo = shard_lo(nq, g, G), hi = shard_lo(nq, g + 1, G);
+        if (hi <= lo) continue;
+        hnsw_index *idx = m->replicas[(size_t)g];
+        HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
+        if (m->hFlags[g] & 1u) {
+            rc = rerun_overflowed(idx, hi - lo, (const uint32_t *)m->dSt[(size_t)g].p,
+                                  [&](const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap) {
+                                      return search_rerun_device(idx, (const float *)m->dQ[(size_t)g].p, hi - lo, q_stride, params,
+                                                                 (int32_t *)m->dIds[(size_t)g].p + lo * k, (float *)m->dDist[(size_t)g].p + lo * k,
+                                                                 (uint32_t *)m->dNd[(size_t)g].p, (uint32_t *)m->dNh[(size_t)g].p,
+                                                                 (uint32_t *)m->dSt[(size_t)g].p, qmap, c, slab, cap, nullptr);
+                                  });
+            if (rc) return rc;
+            if ((rc = exchange(g))) return rc;
+        }
+        if (out_ndist) HIP_TRY(hipMemcpyAsync(out_ndist + lo, m->dNd[(size_t)g].p, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, m->streams[(size_t)g]));
+        if (out_nhops) HIP_TRY(hipMemcpyAsync(out_nhops + lo, m->dNh[(size_t)g].p, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, m->streams[(size_t)g]));
     }
     m->last_nq = nq; m->last_k = k;
     return HNSW_OK;
@@ -245,10 +273,11 @@ int32_t hnsw_multi_destroy(hnsw_multi *m) {
     for (ncclComm_t c : m->comms) if (c) (void)m->rccl.CommDestroy(c);
     for (size_t g = 0; g < m->streams.size(); ++g) {
         (void)hipSetDevice(m->devices[g]);
-        m->dQ[g].release(); m->dIds[g].release(); m->dDist[g].release(); m->dNd[g].release(); m->dNh[g].release(); m->dSt[g].release();
+        m->dQ[g].release(); m->dIds[g].release(); m->dDist[g].release(); m->dNd[g].release(); m->dNh[g].release(); m->dSt[g].release(); m->dFlag[g].release();
         if (m->streams[g]) (void)hipStreamDestroy(m->streams[g]);
+        if (g < m->done.size()) (void)hipEventDestroy(m->done[g]);
     }
-    for (const auto &p : m->pins) (void)hipHostUnregister(const_cast<void *>(p.p));
+    if (m->hFlags) (void)hipHostFree(m->hFlags);
     for (hnsw_index *idx : m->replicas) (void)hnsw_index_destroy(idx);
     delete m;
     return HNSW_OK;
@@ -273,7 +302,10 @@ int32_t hnsw_multi_search_batch_device(hnsw_multi *m, const float *queries, int6
     if (!params) return fail(HNSW_ERR_BAD_ARG, "null params");
     if (nq < 1 || !queries) return fail(HNSW_ERR_BAD_ARG, "bad buffers (nq=%lld)", (long long)nq);
     if (q_stride < m->replicas[0]->iv.d) return fail(HNSW_ERR_BAD_ARG, "q_stride < d");
-    pin_host(m, queries, ((size_t)(nq - 1) * q_stride + m->replicas[0]->iv.d) * sizeof(float));
+    {   // parameter errors are reported before any allocation sized by them
+        int rcp = search_check(m->replicas[0], params);
+        if (rcp) return rcp;
+    }
     int rc = search_and_gather(m, queries, nq, q_stride, params, nullptr, nullptr);
     if (rc) { (void)sync_all(m); return rc; }
     if ((rc = sync_all(m))) return rc;
@@ -312,9 +344,6 @@ int32_t hnsw_multi_search_batch(hnsw_multi *m, const float *queries, int64_t nq,
     }
     const int k = params->k;
     const size_t full = (size_t)nq * k * 4;
-    pin_host(m, queries, ((size_t)(nq - 1) * q_stride + m->replicas[0]->iv.d) * sizeof(float));
-    pin_host(m, out_ids, full);
-    pin_host(m, out_dist, full);
     int rc = search_and_gather(m, queries, nq, q_stride, params, out_ndist, out_nhops);
     if (rc) { (void)sync_all(m); return rc; }
     // the host gets the table from ONE device (it is complete everywhere after the exchange)

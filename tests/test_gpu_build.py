@@ -215,6 +215,8 @@ def test_randomized_builds(H, oracle):
     ("levels", 0, 2500, 6, 8, 60),          # few distinct coordinates: exact distance ties everywhere
     ("unit", 1, 3000, 24, 8, 50),           # inner product (distance 1 - <a,b>, negative values possible)
     ("sift", 0, 2000, 128, 16, 100),        # the C2 shape: integer-valued, d = 128, M = 16
+    ("sift", 0, 2500, 32, 32, 80),          # M = 32: layer-0 rows of 64 entries, a dropped node's list is [q] + a full row = 65
+    ("levels", 0, 2500, 6, 32, 80),         # the same with exact ties everywhere
 ])
 def test_sequential_build_equals_the_reference_insert_link_for_link(H, oracle, kind, metric, n, d, M, efc):
     """max_batch = 1: every node is inserted on its own, and the link step runs neighbour by neighbour as
@@ -246,6 +248,30 @@ def test_sequential_build_equals_the_reference_insert_link_for_link(H, oracle, k
         np.testing.assert_array_equal(nodes, wn)
         np.testing.assert_array_equal(deg, wd)
         np.testing.assert_array_equal(nbr, wb)
+
+
+def test_default_build_with_64_entry_rows_is_symmetric(H, oracle):
+    """M = 32 (C3 / C5's graph shape: layer-0 rows are 64 entries wide, the widest the tables allow), default batching:
+    single-node batches (a node that raises max_layer, a one-node tail) go through the sequential link kernel, whose
+    survivor lists can hold 65 entries.  Graph.Test.invariant (lib/ohnsw.ml:217-225): every link has its back-link."""
+    rng = np.random.default_rng(17)
+    n, d, M = 5001, 24, 32
+    centres = rng.integers(20, 200, size=(16, d))
+    X = np.clip(np.rint(centres[rng.integers(0, 16, n)] + rng.normal(0, 20, size=(n, d))), 0, 218).astype(np.float32)
+    hg = H.Ohnsw.build_batch_bigarray(X, M, 80, seed=2).export()
+    links = set()
+    for i in range(n):
+        for v in hg.nbr0[i, :hg.deg0[i]]:
+            links.add((i, int(v)))
+    missing = [(a, b) for (a, b) in links if (b, a) not in links]
+    assert not missing, "asymmetric layer-0 links: %s" % missing[:5]
+    assert hg.deg0.max() <= 2 * M
+    for nodes, deg, nbr in hg.upper:
+        pos = {int(v): j for j, v in enumerate(nodes)}
+        for j, v in enumerate(nodes):
+            for u in nbr[j, :deg[j]]:
+                ju = pos[int(u)]
+                assert int(v) in nbr[ju, :deg[ju]].tolist(), "asymmetric upper-layer link %d -> %d" % (v, u)
 
 
 def test_hub_with_more_than_64_new_links_in_one_batch_stays_symmetric(H, oracle):

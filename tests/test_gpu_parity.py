@@ -128,7 +128,18 @@ def test_within_tolerance_of_reference_arithmetic(H, oracle, case):
     ok = np.isfinite(odist)
     assert np.array_equal(ok, np.isfinite(dist))
     scale = np.maximum(np.abs(odist), 1e-3 if c["metric"] else 1e-30)
-    close = ~ok | (np.abs(dist - odist) <= 4 * REL_TOL * scale)
+    rel = np.where(ok, np.abs(dist - odist) / scale, 0.0)
+    # the contract itself (north star: "L2 distances within 1e-5 relative"): wherever both sides report the SAME node
+    # at a rank, its two distances differ by at most 1e-5 relative -- every such entry, no slack
+    same = ok & (ids == oids)
+    worst_same = float(rel[same].max()) if same.any() else 0.0
+    print("\n[tolerance] %s: max relative distance difference on %d same-node entries: %.3g (bound %.0e); "
+          "rank-wise over all %d entries: max %.3g, share above the bound %.2g"
+          % (c.get("name", "?"), int(same.sum()), worst_same, REL_TOL, int(ok.sum()), float(rel.max()),
+             float((rel[ok] > REL_TOL).mean()) if ok.any() else 0.0))
+    assert worst_same <= REL_TOL
+    # rank-wise (different nodes may sit at a rank after a near-tie swap or a diverged walk): the same bound on 99.9 %
+    close = ~ok | (rel <= REL_TOL)
     assert close[ok].mean() > 0.999
     # ids: a differing position is legitimate only as a swap inside the tolerance band
     differs = ids != oids
@@ -505,3 +516,35 @@ def test_nearest_k_compat_reproduces_the_reference_output(H, oracle):
             assert (plain[:, 0] <= got[:, 0]).all() and (plain[:, 0] < got[:, 0]).any()
         else:
             np.testing.assert_array_equal(plain.view(np.uint32), got.view(np.uint32))
+
+
+def test_registered_host_arrays_and_caller_owned_results(H, oracle):
+    """hnsw_host_register / hnsw_host_unregister (the caller owns the lifetime) and results written into the caller's
+    matrices: same bits as the plain call, for the synchronous call and for submit / wait; registering twice is fine."""
+    X = _dataset("sift", 5000, 128, 3)
+    Q = _dataset("sift", 3000, 128, 4)          # > 64 KiB so that the copies are worth pinning
+    hg = H.Ohnsw.build_batch_bigarray(X, 16, 80, seed=2)
+    k, ef = 10, 128
+    want_i, want_d = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef)
+    ids = np.full((Q.shape[0], k), -7, np.int32)
+    dist = np.zeros((Q.shape[0], k), np.float32)
+    for a in (Q, ids, dist):
+        H.pin(a)
+    H.pin(Q)                                     # twice: not an error
+    try:
+        got = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, out=(ids, dist))
+        assert got[0] is ids and got[1] is dist
+        np.testing.assert_array_equal(ids, want_i)
+        np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
+        ids[:] = -7
+        r = H.submit(hg, Q, ef, k)
+        r.wait(out=(ids, dist))
+        np.testing.assert_array_equal(ids, want_i)
+        np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
+    finally:
+        for a in (Q, ids, dist):
+            H.unpin(a)
+    with pytest.raises(H.Failure):
+        H.unpin(ids)                             # not registered any more
+    with pytest.raises(H.InvalidArgument):
+        H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, out=(ids[:, :5], dist))
