@@ -109,6 +109,84 @@ let hnsw_multi_copy_result =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_multi_copy_result"
     (multi @-> int32_t @-> ptr int32_t @-> ptr float @-> returning int32_t)
 
+(* the rest of include/hnsw_mi355x.h: single query, gathered distances, select_neighbours, the device builder,
+   save / load, per-layer statistics, host-array registration *)
+let hnsw_knn =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_knn"
+    (index @-> ptr float @-> ptr search_params @-> ptr int32_t @-> ptr float @-> ptr int32_t @-> returning int32_t)
+let hnsw_distance_batch =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_distance_batch"
+    (index @-> ptr float @-> int64_t @-> int64_t @-> ptr int32_t @-> int32_t @-> ptr float @-> returning int32_t)
+let hnsw_select_neighbours_batch =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_select_neighbours_batch"
+    (index @-> ptr float @-> int64_t @-> int64_t @-> ptr int32_t @-> ptr int32_t @-> int32_t @-> int32_t @-> int32_t
+     @-> ptr int32_t @-> ptr int32_t @-> ptr int32_t @-> returning int32_t)
+type build_params
+let build_params : build_params structure typ = structure "hnsw_build_params"
+let b_num_connections = field build_params "num_connections" int32_t
+let b_efc = field build_params "num_nodes_search_construction" int32_t
+let b_metric = field build_params "metric" int32_t
+let b_id_base = field build_params "id_base" int32_t
+let b_seed = field build_params "seed" uint64_t
+let b_max_batch = field build_params "max_batch" int32_t
+let b_batch_div = field build_params "batch_div" int32_t
+let () = seal build_params
+let hnsw_build =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_build"
+    (ptr float @-> int64_t @-> int32_t @-> int64_t @-> ptr build_params @-> int32_t @-> ptr index @-> returning int32_t)
+let hnsw_index_save = foreign ~from:lib ~release_runtime_lock:true "hnsw_index_save" (index @-> string @-> returning int32_t)
+let hnsw_index_load =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_index_load" (string @-> int32_t @-> ptr index @-> returning int32_t)
+type layer_stats
+let layer_stats : layer_stats structure typ = structure "hnsw_layer_stats"
+let ls_num_nodes = field layer_stats "num_nodes" int64_t
+let ls_min_degree = field layer_stats "min_degree" int32_t
+let ls_max_degree = field layer_stats "max_degree" int32_t
+let ls_mean_degree = field layer_stats "mean_degree" double
+let ls_num_isolated = field layer_stats "num_isolated" int64_t
+let () = seal layer_stats
+let hnsw_index_layer_stats =
+  foreign ~from:lib "hnsw_index_layer_stats" (index @-> int32_t @-> ptr layer_stats @-> returning int32_t)
+let hnsw_abi_version = foreign ~from:lib "hnsw_abi_version" (void @-> returning int32_t)
+let hnsw_device_count = foreign ~from:lib "hnsw_device_count" (ptr int32_t @-> returning int32_t)
+type index_info
+let index_info : index_info structure typ = structure "hnsw_index_info"
+let ii_n = field index_info "n" int64_t
+let ii_d = field index_info "d" int32_t
+let ii_metric = field index_info "metric" int32_t
+let ii_id_base = field index_info "id_base" int32_t
+let ii_max_degree0 = field index_info "max_degree0" int32_t
+let ii_max_degree = field index_info "max_degree" int32_t
+let ii_max_layer = field index_info "max_layer" int32_t
+let ii_entry_point = field index_info "entry_point" int64_t
+let ii_device_bytes = field index_info "device_bytes" int64_t
+let ii_row_stride_bytes = field index_info "row_stride_bytes" int64_t
+let ii_device = field index_info "device" int32_t
+let ii_reserved = field index_info "reserved" int32_t
+let () = seal index_info
+let hnsw_index_get_info = foreign ~from:lib "hnsw_index_get_info" (index @-> ptr index_info @-> returning int32_t)
+(* the flattened graph of a device index (built there by hnsw_build, or loaded from a file) back to the host *)
+let hnsw_index_export_layer0 =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_index_export_layer0" (index @-> ptr int32_t @-> ptr int32_t @-> returning int32_t)
+let hnsw_index_export_upper_count =
+  foreign ~from:lib "hnsw_index_export_upper_count" (index @-> int32_t @-> ptr int64_t @-> returning int32_t)
+let hnsw_index_export_upper =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_index_export_upper"
+    (index @-> int32_t @-> ptr int64_t @-> ptr int32_t @-> ptr int32_t @-> returning int32_t)
+let hnsw_multi_num_replicas = foreign ~from:lib "hnsw_multi_num_replicas" (multi @-> ptr int32_t @-> returning int32_t)
+let hnsw_multi_replica = foreign ~from:lib "hnsw_multi_replica" (multi @-> int32_t @-> ptr index @-> returning int32_t)
+(* device-pointer entry points (hnsw_search_batch_device, hnsw_distance_batch_device): for callers that already hold
+   HIP device pointers and a stream; an OCaml program has neither, so they are bound as raw pointers only *)
+let hnsw_search_batch_device =
+  foreign ~from:lib "hnsw_search_batch_device"
+    (index @-> ptr float @-> int64_t @-> int64_t @-> ptr search_params @-> ptr int32_t @-> ptr float @-> ptr uint32_t
+     @-> ptr uint32_t @-> ptr uint32_t @-> ptr void @-> returning int32_t)
+let hnsw_distance_batch_device =
+  foreign ~from:lib "hnsw_distance_batch_device"
+    (index @-> ptr float @-> int64_t @-> int64_t @-> ptr int32_t @-> int32_t @-> ptr float @-> ptr void @-> returning int32_t)
+let hnsw_host_register = foreign ~from:lib "hnsw_host_register" (ptr void @-> int64_t @-> returning int32_t)
+let hnsw_host_unregister = foreign ~from:lib "hnsw_host_unregister" (ptr void @-> returning int32_t)
+
 (* Error convention -> the reference's exceptions (lib/ohnsw.ml:25,343,862) *)
 let check rc =
   match Int32.to_int rc with
@@ -490,8 +568,8 @@ let search_one (t : t) ~layer ~start_node (target : Lacaml.S.vec) =
 (* Batches in flight: [submit] copies the batch in and starts the search, [wait] returns what
    [search] would have.  A caller with more than one batch overlaps them
    (let r1 = submit t b1 ... in let r2 = submit t b2 ... in wait r1; wait r2): the next batch fills
-   the drain of the previous one (12.9 M q/s against 9.4 M q/s for back-to-back synchronous calls on
-   the SIFT1M-shaped workload, host buffers included). *)
+   the drain of the previous one (round 3, SIFT1M-shaped workload, registered matrices, PCIe copies included:
+   36 M q/s with two requests in flight against 16.7 M q/s for back-to-back synchronous calls). *)
 type pending = { req : request; p_k : int; p_nq : int; keep : Lacaml.S.mat }
 
 let submit ?(semantics = 0) t (batch : Lacaml.S.mat) ~ef ~k ~fill : pending =
@@ -510,3 +588,129 @@ let wait (r : pending) =
   check (hnsw_search_wait r.req (bigarray_start array2 ids) (bigarray_start array2 distances)
            (from_voidp uint32_t null) (from_voidp uint32_t null));
   ids, distances
+
+(* ---- single query ------------------------------------------------------------------------------ *)
+
+(* one query through hnsw_knn: the (node, distance) pairs found, nearest first *)
+let knn_on ?(semantics = 0) (t : t) (target : Lacaml.S.vec) ~ef ~k ~fill : (int * float) list =
+  let ids = CArray.make int32_t k and dist = CArray.make float k in
+  let cnt = allocate int32_t 0l in
+  let p = make search_params in
+  setf p p_ef (Int32.of_int ef); setf p p_k (Int32.of_int k); setf p p_fill (Int32.of_int fill);
+  setf p p_semantics (Int32.of_int semantics);
+  check (hnsw_knn t.handle (bigarray_start array1 target) (addr p) (CArray.start ids) (CArray.start dist) cnt);
+  List.init (Int32.to_int !@cnt) (fun i -> Int32.to_int (CArray.get ids i), CArray.get dist i)
+
+(* Ohnsw.knn (lib/ohnsw.ml:859-875).  The reference's signature is
+     'a Hgraph.t -> Visited.t -> k:int -> 'a -> 'a MinQueue.t
+   whose result type is abstract outside lib/ohnsw.ml (:404-416; test/test.ml:122-125 no longer type-checks against
+   it): what a caller can do with it is pop it nearest first (:886-893), so that list is what is returned, and the
+   scratch Visited.t (device-side state here) is not taken.  An empty hgraph raises Invalid_argument
+   "knn: empty hgraph" (:861-862). *)
+let knn (hgraph : Lacaml.S.vec Ohnsw.Hgraph.t) ~k (target : Lacaml.S.vec) : (int * float) list =
+  knn_on (index_of_ohnsw hgraph) target ~ef:k ~k ~fill:0
+
+(* Hnsw.Ba.knn (lib/hnsw.ml:763-767):
+     t -> Lacaml.S.vec -> num_neighbours_search:int -> num_neighbours:int -> int Hnsw_algo.value_distance list
+   1-based node ids, the functor path's accept rule (semantics 1); ~nearest_k_compat:true reproduces
+   Nearest.nearest_k's output (lib/hnsw.ml:522-525) as in [knn_batch]. *)
+let ba_knn ?(nearest_k_compat = false) (hgraph : Hnsw.Ba.Hgraph.t) (target : Lacaml.S.vec) ~num_neighbours_search ~num_neighbours :
+  int Hnsw_algo.value_distance list =
+  knn_on ~semantics:(if nearest_k_compat then 2 else 1) (index_of_ba hgraph) target
+    ~ef:num_neighbours_search ~k:num_neighbours ~fill:1
+  |> List.map (fun (node, distance_to_target) -> { Hnsw_algo.node; distance_to_target })
+
+(* ---- the other operators of the header ----------------------------------------------------------- *)
+
+(* distances.(q).(j) = distance (query q) (value ids.(q).(j)): EuclideanBa.distance / Ohnsw.distance_l2 gathered on the
+   device (lib/hnsw.ml:809-815, lib/ohnsw.ml:899; bench_dist/bench_dist.ml:22-33 times exactly this, one pair per call) *)
+let distance_batch (t : t) (queries : Lacaml.S.mat) (ids : int array array) : float array array =
+  let nq = A2.dim2 queries in
+  if Array.length ids <> nq then invalid_arg "distance_batch: one id list per query";
+  let m = if nq = 0 then 0 else Array.length ids.(0) in
+  let flat_ids = CArray.make int32_t (max 1 (nq * m)) and out = CArray.make float (max 1 (nq * m)) in
+  Array.iteri (fun q row ->
+      if Array.length row <> m then invalid_arg "distance_batch: ragged id lists";
+      Array.iteri (fun j v -> CArray.set flat_ids (q * m + j) (Int32.of_int v)) row) ids;
+  check (hnsw_distance_batch t.handle (bigarray_start array2 queries) (Int64.of_int nq) (Int64.of_int t.dim)
+           (CArray.start flat_ids) (Int32.of_int m) (CArray.start out));
+  Array.init nq (fun q -> Array.init m (fun j -> CArray.get out (q * m + j)))
+
+(* Ohnsw.select_neighbours (lib/ohnsw.ml:647-663) for ONE base value: candidates as node ids (their distances to the
+   target are recomputed on the device), at most ~num_neighbours kept, in selection order (nearest first).
+   ~keep_all_if_few:true adds Hnsw_algo.SelectNeighbours' shortcut (lib/hnsw_algo.ml:596-599); ~degrees gives
+   ~do_not_isolate:true (candidates of degree <= 1 are kept unconditionally, :591-592). *)
+let select_neighbours ?(keep_all_if_few = false) ?degrees (t : t) (target : Lacaml.S.vec) ~(candidates : int list) ~num_neighbours : int list =
+  let nc = List.length candidates in
+  let cand = CArray.of_list int32_t (List.map Int32.of_int candidates) in
+  let cnt = allocate int32_t (Int32.of_int nc) in
+  let deg = match degrees with
+    | Some l -> CArray.start (CArray.of_list int32_t (List.map Int32.of_int l))
+    | None -> from_voidp int32_t null in
+  let out = CArray.make int32_t (max 1 num_neighbours) and out_cnt = allocate int32_t 0l in
+  check (hnsw_select_neighbours_batch t.handle (bigarray_start array1 target) 1L (Int64.of_int t.dim)
+           (CArray.start cand) cnt (Int32.of_int (max 1 nc)) (Int32.of_int num_neighbours)
+           (if keep_all_if_few then 1l else 0l) deg (CArray.start out) out_cnt);
+  List.init (Int32.to_int !@out_cnt) (fun i -> Int32.to_int (CArray.get out i))
+
+(* the device builder: the body of Ohnsw.build_batch_bigarray (lib/ohnsw.ml:840-857) in batches on the GPU
+   (~max_batch:1 = Ohnsw.insert link for link); the OCaml builder stays the reference path, this is the fast one *)
+let build ?(device = 0) ?(metric = 0) ?(seed = 0) ?(max_batch = 0) ?(batch_div = 0) ~id_base ~num_connections
+    ~num_nodes_search_construction (vectors : Lacaml.S.mat) : t =
+  let dim = A2.dim1 vectors and n = A2.dim2 vectors in
+  let b = make build_params in
+  setf b b_num_connections (Int32.of_int num_connections); setf b b_efc (Int32.of_int num_nodes_search_construction);
+  setf b b_metric (Int32.of_int metric); setf b b_id_base (Int32.of_int id_base);
+  setf b b_seed (Unsigned.UInt64.of_int seed); setf b b_max_batch (Int32.of_int max_batch);
+  setf b b_batch_div (Int32.of_int batch_div);
+  let out = allocate index null in
+  check (hnsw_build (bigarray_start array2 vectors) (Int64.of_int n) (Int32.of_int dim) (Int64.of_int dim) (addr b)
+           (Int32.of_int device) out);
+  let t = { handle = !@out; k_base = id_base; dim } in
+  Gc.finalise (fun t -> ignore (hnsw_index_destroy t.handle)) t;
+  t
+
+(* flattened-index file (the reference has no persistence: lib/hnsw.ml:348, lib/ohnsw.ml:312 derive sexp with opaque values) *)
+let save (t : t) (path : string) = check (hnsw_index_save t.handle path)
+let load ?(device = 0) ~id_base ~dim (path : string) : t =
+  let out = allocate index null in
+  check (hnsw_index_load path (Int32.of_int device) out);
+  let t = { handle = !@out; k_base = id_base; dim } in
+  Gc.finalise (fun t -> ignore (hnsw_index_destroy t.handle)) t;
+  t
+
+(* Hgraph.Stats (lib/hnsw.ml:353-375) of one layer: (layer size, min, max, mean degree, number of isolated nodes) *)
+let stats (t : t) ~layer : int * int * int * float * int =
+  let s = make layer_stats in
+  check (hnsw_index_layer_stats t.handle (Int32.of_int layer) (addr s));
+  (Int64.to_int (getf s ls_num_nodes), Int32.to_int (getf s ls_min_degree), Int32.to_int (getf s ls_max_degree),
+   getf s ls_mean_degree, Int64.to_int (getf s ls_num_isolated))
+
+(* Page-lock a query or result matrix a benchmark loop passes again and again (benchmark/benchmark.ml:86-98): the
+   copies of knn_batch* then run at PCIe speed.  The CALLER keeps the Bigarray reachable until [unpin] -- the library
+   never registers memory on its own. *)
+let pin (m : (_, _, _) A2.t) = check (hnsw_host_register (to_voidp (bigarray_start array2 m)) (Int64.of_int (A2.size_in_bytes m)))
+let unpin (m : (_, _, _) A2.t) = check (hnsw_host_unregister (to_voidp (bigarray_start array2 m)))
+
+(* the graph of a device index as a [flat] (the input of unflatten_ohnsw / unflatten_ba): e.g. an index built on the
+   device with [build], handed back to the OCaml builder so that Ohnsw.insert can go on from there *)
+let export (t : t) : flat =
+  let inf = make index_info in
+  check (hnsw_index_get_info t.handle (addr inf));
+  let n = Int64.to_int (getf inf ii_n) and max_layer = Int32.to_int (getf inf ii_max_layer) in
+  let width0 = Int32.to_int (getf inf ii_max_degree0) and width_upper = max 1 (Int32.to_int (getf inf ii_max_degree)) in
+  let deg0 = A1.create Bigarray.int32 Bigarray.c_layout n in
+  let nbr0 = A2.create Bigarray.int32 Bigarray.c_layout n width0 in
+  check (hnsw_index_export_layer0 t.handle (bigarray_start array1 deg0) (bigarray_start array2 nbr0));
+  let upper = Array.init max_layer (fun l ->
+      let cnt = allocate int64_t 0L in
+      check (hnsw_index_export_upper_count t.handle (Int32.of_int (l + 1)) cnt);
+      let c = Int64.to_int !@cnt in
+      let nodes = A1.create Bigarray.int64 Bigarray.c_layout c in
+      let deg = A1.create Bigarray.int32 Bigarray.c_layout c in
+      let nbr = A2.create Bigarray.int32 Bigarray.c_layout c width_upper in
+      if c > 0 then
+        check (hnsw_index_export_upper t.handle (Int32.of_int (l + 1)) (bigarray_start array1 nodes)
+                 (bigarray_start array1 deg) (bigarray_start array2 nbr));
+      (nodes, deg, nbr)) in
+  { deg0; nbr0; upper; max_layer; width0; width_upper; entry_point = Int64.to_int (getf inf ii_entry_point) }

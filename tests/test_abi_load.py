@@ -73,3 +73,24 @@ def test_argument_validation_is_host_side(H):
     # shapes are checked before anything touches a device
     with pytest.raises(H.InvalidArgument):
         H.Hgraph(np.zeros((4, 8), np.float32), np.zeros(3, np.int32), np.zeros((4, 4), np.int32))
+
+
+def test_ocaml_binding_binds_every_declared_symbol():
+    """ocaml/hnsw_mi355x.ml (source only: the image has no OCaml toolchain) must at least NAME every entry point the
+    header declares in a `foreign` binding, and wrap the single-query forms the reference exposes (Ohnsw.knn,
+    lib/ohnsw.ml:859-875; Hnsw.Ba.knn, lib/hnsw.ml:763-767)."""
+    ml = open(os.path.join(ROOT, "ocaml-hnsw_amd", "ocaml", "hnsw_mi355x.ml")).read()
+    missing = [s for s in _declared_symbols() if not re.search(r'foreign[^"]*"%s"' % s, ml)]
+    assert not missing, missing
+    for wrapper in ("let knn ", "let ba_knn ", "let knn_batch_bigarray ", "let knn_batch ", "let distance_batch ",
+                    "let select_neighbours ", "let build ", "let save ", "let load ", "let stats ", "let pin ", "let unpin ", "let export "):
+        assert wrapper in ml, wrapper
+    # struct field orders match the header (ctypes structures are positional)
+    hdr = open(os.path.join(ROOT, "include", "hnsw_mi355x.h")).read()
+    for struct, prefix in (("hnsw_search_params", "p_"), ("hnsw_layer_stats", "ls_"), ("hnsw_build_params", "b_")):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        c_fields = [f.strip().lstrip("*") for decl in body.split(";") if decl.strip()
+                    for f in decl.strip().split(None, 1)[1].split(",")]
+        ml_fields = re.findall(r'field %s "([a-z_0-9]+)"' % struct.replace("hnsw_", ""), ml)
+        assert ml_fields == c_fields, (struct, ml_fields, c_fields)
