@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the harder SIFT-like data point (object `secondary`)")
     ap.add_argument("--no-builder-check", action="store_true", help="skip the batched-vs-sequential builder comparison inside `secondary` (about 75 s)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic / roofline.issue are then null)")
+    ap.add_argument("--pmc-child", default=None, help="(internal) load this index file and run a few steps: the process rocprofv3 wraps")
+    ap.add_argument("--no-bench-dist", action="store_true", help="skip the bench_dist counterpart (object `bench_dist`; about 8 s)")
     ap.add_argument("--no-others", action="store_true", help="skip the C3 / C5 configurations (object `others`; about 100 s)")
     ap.add_argument("--pipelined", action="store_true",
                     help="also time the same steps alternated over two HIP streams (extra object `pipelined`, never `value`); "
@@ -150,6 +153,23 @@ def main():
     H.load()
     if H.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the search path has no CPU fallback")
+    if args.pmc_child:
+        # the process a rocprofv3 --pmc pass wraps: the index file the parent saved, the parent's query batch (same
+        # seed), a few steps of the headline call and (byte_rows = 0) of the float32-row call
+        torch.cuda.set_device(0)
+        dev_ = torch.device("cuda", 0)
+        hgc = H.Hgraph.load(args.pmc_child)
+        Qc = make_sift_like(args.nq, args.d, seed=2, device=dev_)
+        ic = torch.empty((args.nq, args.k), dtype=torch.int32, device=dev_)
+        dc = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev_)
+        stc = torch.cuda.current_stream()
+        for rows_ in (1, 0):
+            hgc.set_option("byte_rows", rows_)
+            for _ in range(5):
+                H.search_batch_device(hgc, Qc.data_ptr(), args.nq, args.d, args.ef, args.k, ic.data_ptr(), dc.data_ptr(), 0, 0, 0, stc.cuda_stream)
+            torch.cuda.synchronize()
+        _restore_stdout(saved_stdout)
+        return
     gpu = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
@@ -707,6 +727,119 @@ def main():
             except Exception as e:
                 others["C5"] = {"skipped": "failed: %r" % (e,)}
 
+    # ---- bench_dist counterpart (bench_dist/bench_dist.ml:8-33: 1 M calls of distance_l2 at d = 784, checksum, s/call,
+    #      calls/s): 1 M gathered distances over random rows of a 1 M x 784 table, one launch ----
+    bench_dist = None
+    if world == 1 and rank == 0 and not args.no_bench_dist:
+        t0 = time.time()
+        dd, nn, nqd, md = 784, 1_000_000, 1024, 1024
+        gd_ = torch.Generator(device=dev)
+        gd_.manual_seed(dd)
+        Xdist = torch.rand((nn, dd), generator=gd_, device=dev).cpu().numpy()
+        hgd = H.Hgraph(Xdist, np.zeros(nn, np.int32), np.full((nn, 2), -1, np.int32), entry_point=0).to_device(gpu)
+        Qdist = torch.rand((nqd, dd), generator=gd_, device=dev)
+        idd = torch.randint(0, nn, (nqd, md), generator=gd_, device=dev, dtype=torch.int32)
+        outd = torch.empty((nqd, md), dtype=torch.float32, device=dev)
+        Ld = H.load()
+
+        def go_d():
+            rc_ = Ld.hnsw_distance_batch_device(hgd.handle, Qdist.data_ptr(), nqd, dd, idd.data_ptr(), md, outd.data_ptr(), stream.cuda_stream)
+            assert rc_ == 0, Ld.hnsw_last_error()
+        go_d()
+        torch.cuda.synchronize()
+        tsd = []
+        for _ in range(7):
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record(stream); go_d(); b_.record(stream); torch.cuda.synchronize()
+            tsd.append(a_.elapsed_time(b_))
+        tsd.sort()
+        msd = tsd[len(tsd) // 2]
+        pairs = nqd * md
+        # spot check against fp64 on the host: the north star's 1e-5 relative
+        jq, jm = np.arange(0, nqd, 97), np.arange(0, md, 89)
+        got_d = outd.cpu().numpy()[np.ix_(jq, jm)]
+        ids_h = idd.cpu().numpy()[np.ix_(jq, jm)]
+        qh = Qdist.cpu().numpy()[jq].astype(np.float64)
+        want_d = np.sqrt(((Xdist[ids_h].astype(np.float64) - qh[:, None, :]) ** 2).sum(-1))
+        bench_dist = {"d": dd, "n": nn, "pairs": pairs, "ms": round(msd, 4), "ms_min": round(tsd[0], 4), "ms_max": round(tsd[-1], 4),
+                      "s_per_call": msd * 1e-3 / pairs, "calls_per_s": round(pairs / (msd * 1e-3), 1),
+                      "gathered_TBps": round(pairs * 4 * dd / (msd * 1e-3) / 1e12, 3), "frac_of_hbm_peak": round(pairs * 4 * dd / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "checksum": float(outd.double().sum()), "max_rel_err_vs_fp64_sample": float(np.max(np.abs(got_d - want_d) / want_d)),
+                      "what": "hnsw_distance_batch_device: 1024 queries x 1024 random ids = 1 M (query, row) pairs per launch, 3136-byte rows "
+                              "(bench_dist/bench_dist.ml:22-33 times 1 M single calls of Ohnsw.distance_l2 at this d)"}
+        log("bench_dist d=%d: %.3g calls/s, %.2f TB/s gathered, max rel err %.2g (%.0fs)" %
+            (dd, bench_dist["calls_per_s"], bench_dist["gathered_TBps"], bench_dist["max_rel_err_vs_fp64_sample"], time.time() - t0))
+        hgd.release()
+        del Xdist, Qdist, idd, outd
+
+    # ---- live counter passes: rocprofv3 --pmc around a child of this script that loads the SAME index (saved to a
+    #      temporary file) and runs the SAME batch; one pass per counter group (MI355X_MICROARCH.md: separate --pmc
+    #      passes; FETCH_SIZE x 2 on gfx950).  Gives roofline.traffic and roofline.issue of THIS run. ----
+    pmc = {}
+    if world == 1 and rank == 0 and not args.no_pmc and not args.dataset:
+        import csv
+        import glob
+        import shutil
+        import subprocess
+        import tempfile
+        t0 = time.time()
+        rp = shutil.which("rocprofv3")
+        if rp is None:
+            pmc = {"skipped": "rocprofv3 not on PATH"}
+        else:
+            tmpd = tempfile.mkdtemp(prefix="hnsw_pmc_", dir="/tmp")
+            try:
+                idx_file = os.path.join(tmpd, "c2.idx")
+                hg.save(idx_file)
+                groups = {"inst": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"],
+                          "fetch": ["FETCH_SIZE"]}
+                env_ = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
+                for gname, counters in groups.items():
+                    outd = os.path.join(tmpd, gname)
+                    cmd = [rp, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", outd, "--", sys.executable,
+                           os.path.abspath(__file__), "--pmc-child", idx_file, "--nq", str(nq), "--d", str(d), "--ef", str(ef), "--k", str(k)]
+                    r_ = subprocess.run(cmd, cwd="/tmp", env=env_, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+                    if r_.returncode != 0:
+                        pmc.setdefault("failed", {})[gname] = r_.stderr.decode(errors="replace")[-300:]
+                        continue
+                    for f_ in glob.glob(os.path.join(outd, "**", "*counter_collection.csv"), recursive=True):
+                        for row in csv.DictReader(open(f_)):
+                            kn = row.get("Kernel_Name", "")
+                            if "hnsw_search_kernel" not in kn:
+                                continue
+                            key_ = "bytes" if kn.replace(" ", "").startswith(("voidhnsw_dev::hnsw_search_kernel<2,4,2,0,0,2>", "hnsw_dev::hnsw_search_kernel<2,4,2,0,0,2>")) or "<2,4,2,0,0,2>" in kn.replace(" ", "") else "float32"
+                            a_ = pmc.setdefault(key_, {}).setdefault(row["Counter_Name"], [0.0, 0])
+                            a_[0] += float(row["Counter_Value"]); a_[1] += 1
+                for key_ in ("bytes", "float32"):
+                    if key_ in pmc:
+                        pmc[key_] = {c_: v_[0] / v_[1] for c_, v_ in pmc[key_].items()}
+            except Exception as e:
+                pmc = {"skipped": "live counter pass failed: %r" % (e,)}
+            finally:
+                shutil.rmtree(tmpd, ignore_errors=True)
+        log("live rocprofv3 counter passes: %s (%.0fs)" % ({k_: (sorted(v_) if isinstance(v_, dict) else v_) for k_, v_ in pmc.items()}, time.time() - t0))
+
+    def live_counters(rows_key, kernel_ms_):
+        """(traffic bytes per launch, issue dict) of one search-kernel variant from this run's counter passes"""
+        c_ = pmc.get(rows_key) if isinstance(pmc.get(rows_key), dict) else None
+        if not c_:
+            return None, None
+        traffic_ = int(2 * c_["FETCH_SIZE"] * 1024) if "FETCH_SIZE" in c_ else None     # gfx950: FETCH_SIZE (KB) counts 128-B requests at 64 B
+        issue_ = None
+        if "SQ_INSTS_VALU" in c_ and c_.get("SQ_BUSY_CYCLES"):
+            cyc = c_["SQ_BUSY_CYCLES"] / 32.0            # summed over the chip's 32 shader engines
+            tot = c_["SQ_INSTS_VALU"] + c_["SQ_INSTS_SALU"] + c_.get("SQ_INSTS_LDS", 0) + c_.get("SQ_INSTS_VMEM_RD", 0)
+            issue_ = {"valu": round(c_["SQ_INSTS_VALU"] * 4.0 / (1024 * cyc), 4), "salu": round(c_["SQ_INSTS_SALU"] / (256 * cyc), 4),
+                      "what": "share of the issue slots the launch had: vector = wave-instructions x 4 cycles / (1024 SIMDs x kernel cycles); "
+                              "scalar = instructions / (256 CUs x kernel cycles) (one scalar unit per CU, shared by its four SIMDs)",
+                      "SQ_INSTS_VALU": c_["SQ_INSTS_VALU"], "SQ_INSTS_SALU": c_["SQ_INSTS_SALU"], "SQ_INSTS_LDS": c_.get("SQ_INSTS_LDS"),
+                      "SQ_INSTS_VMEM_RD": c_.get("SQ_INSTS_VMEM_RD"), "kernel_cycles": round(cyc, 1),
+                      "clock_GHz": round(cyc / (kernel_ms_ * 1e6), 3) if kernel_ms_ else None,
+                      "instructions_per_hop": None, "wave_occupancy": round(c_["SQ_WAVE_CYCLES"] * 4.0 / (8192 * cyc), 4) if c_.get("SQ_WAVE_CYCLES") else None,
+                      "instructions_per_dispatch": tot,
+                      "source": "rocprofv3 --pmc pass of this run (a child process on the same index and batch, 5 dispatches)"}
+        return traffic_, issue_
+
     # ---- algorithmic bytes (SURVEY 8d) from the CPU oracle's counters on the same graph/queries,
     #      parity spot-check, and the CPU baseline (rank 0) ----
     roofline, cpu_baseline = None, None
@@ -784,9 +917,15 @@ def main():
         else:
             bq, kernel_ms, kname = bq_total, search_ms, kernel_name(byte_rows)
         achieved = bq * nq / (kernel_ms * 1e-3) / 1e9
-        traffic = traffic_of(kname, ordered)
+        traffic, issue = live_counters("bytes" if byte_rows else "float32", kernel_ms)
+        traffic_src = "live rocprofv3 FETCH_SIZE pass of this run x 2 (gfx950)" if traffic is not None else None
+        if traffic is None:
+            traffic = traffic_of(kname, ordered)
+            traffic_src = "profiles/traffic.json (static)" if traffic is not None else None
+        if issue is not None and n_hops_mean:
+            issue["instructions_per_hop"] = round(issue["instructions_per_dispatch"] / (nq * n_hops_mean), 1)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "issue": issue,
                     "kernel": kname, "kernel_ms": round(kernel_ms, 4), "row_bytes": row_bytes,
                     "bytes_per_query": round(bq, 1), "n_dist_per_query": round(n_dist_mean, 1),
                     "n_hops_per_query": round(n_hops_mean, 1), "counters": src,
@@ -809,7 +948,9 @@ def main():
                                         "ms_per_step": round(1e3 * fp32_leg["wall"] / args.steps, 4),
                                         "kernel": kernel_name(False), "kernel_ms": round(f_ms, 4), "prepass_ms": round(fp32_leg["prepass_ms"], 4),
                                         "bytes_per_query": round(f_bq, 1), "achieved": round(f_ach, 1), "peak": HBM_PEAK_GBS, "unit_bw": "GB/s",
-                                        "frac": round(f_ach / HBM_PEAK_GBS, 4), "traffic": traffic_of(kernel_name(False), f_ord),
+                                        "frac": round(f_ach / HBM_PEAK_GBS, 4),
+                                        "traffic": live_counters("float32", f_ms)[0] if live_counters("float32", f_ms)[0] is not None else traffic_of(kernel_name(False), f_ord),
+                                        "issue": live_counters("float32", f_ms)[1],
                                         "what": "option byte_rows = 0: the same index, batch and steps through the float32 rows"}
 
     if rank == 0:
@@ -837,7 +978,7 @@ def main():
                             "harder_set": (None if not secondary else
                                            ({"ef": ef, "recall_at_10": secondary["checks"]["recall_at_10"], "value": secondary["value"]}
                                             if secondary["checks"]["recall_at_10"] >= 0.95 else secondary.get("at_recall_0.95")))} if rank == 0 and world == 1 else None,
-            "others": others, "strong": strong, "pipelined": pipelined, "checks": checks,
+            "others": others, "bench_dist": bench_dist, "strong": strong, "pipelined": pipelined, "checks": checks,
         }
         _restore_stdout(saved_stdout)
         saved_stdout = None
