@@ -144,9 +144,10 @@ def load():
     L.hnsw_multi_search_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp]
     L.hnsw_multi_search_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp]
     L.hnsw_multi_copy_result.argtypes = [vp, i32, vp, vp]
-    L.hnsw_host_register.argtypes = [vp, i64]
-    L.hnsw_host_unregister.argtypes = [vp]
-    L.hnsw_host_register.restype = L.hnsw_host_unregister.restype = i32
+    if hasattr(L, "hnsw_host_register"):      # (an older build of the library, loaded by tools/ab.py for comparison, lacks them)
+        L.hnsw_host_register.argtypes = [vp, i64]
+        L.hnsw_host_unregister.argtypes = [vp]
+        L.hnsw_host_register.restype = L.hnsw_host_unregister.restype = i32
     for f in ("hnsw_search_layer_batch", "hnsw_search_one_batch", "hnsw_multi_create", "hnsw_multi_destroy",
               "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
               "hnsw_multi_search_batch_device", "hnsw_multi_copy_result"):

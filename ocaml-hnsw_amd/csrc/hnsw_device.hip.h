@@ -970,9 +970,13 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     const int lane = cx.lane;
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
 #if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING) && !defined(HNSW_TIMING)
-    if constexpr (NCH == 2 && NSLOT == 2 && METRIC == 0 && SEM == 0 && ROWS == 2) {
-        // the headline shape (d <= 128 byte rows, byte query, L2, Ohnsw rule, ef 65..128): hand-scheduled loop, same results
+    if constexpr (NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4) && METRIC == 0 && SEM == 0 && ROWS == 2) {
+        // the headline shape (d <= 128 byte rows, byte query, L2, Ohnsw rule; ef <= 64 / 65..128 / 129..256): hand-scheduled
+        // loop, same results
         if (layer == 0 && cx.qint && cx.ovf.g == nullptr && (uint64_t)iv.n * (uint64_t)iv.S0 < (1ull << 30)) {
+            if constexpr (NSLOT == 1) { search_layer0_bytes_l2_asm1(iv, w, cx, n_dist, n_hops, status); return; }
+            if constexpr (NSLOT == 4) { search_layer0_bytes_l2_asm4(iv, w, cx, n_dist, n_hops, status); return; }
+            if constexpr (NSLOT == 2) {
 #ifdef HNSW_ASM_DEBUG
 #ifdef HNSW_ASM_DEBUG_HOPS
             search_layer0_bytes_l2_asm(iv, w, cx, n_dist, n_hops, status, HNSW_ASM_DEBUG_HOPS);
@@ -983,6 +987,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             search_layer0_bytes_l2_asm(iv, w, cx, n_dist, n_hops, status);
             return;
 #endif
+            }
         }
     }
 #endif
@@ -1130,7 +1135,8 @@ __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv,
 #ifndef HNSW_SEARCH_MIN_WAVES
 #define HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS, SEMF) \
     (((NCH) <= 2 && (NSLOT) <= 2 && (METRIC) == 0 && (ROWS) == 1) ? 7 : \
-     (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) == 2 && (METRIC) == 0 && (ROWS) == 2 && (SEMF) == 0) ? 8 : 1)
+     (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) <= 2 && (METRIC) == 0 && (ROWS) == 2 && (SEMF) == 0) ? 8 : \
+     (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) == 4 && (METRIC) == 0 && (ROWS) == 2 && (SEMF) == 0) ? 7 : 1)
 #endif
 // SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); ROWS: 0 | 1 | 2, see hop_round
 template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, int ROWS>

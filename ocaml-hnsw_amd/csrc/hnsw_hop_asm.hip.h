@@ -21,9 +21,6 @@ namespace hnsw_dev {
 #ifndef HNSW_ASM_LOOP
 #define HNSW_ASM_LOOP 1
 #endif
-#ifndef HNSW_ASM_MAXNB
-#define HNSW_ASM_MAXNB 4         // debugging: 1 / 2 restrict a round to one / two 4-row batches
-#endif
 #ifndef HNSW_ASM_PREFETCH
 #define HNSW_ASM_PREFETCH 1
 #endif
@@ -174,6 +171,238 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_cmp_gt_u32_e64 %[fresh], %[wmax], %[ckey]\n\t"                                     \
     "s_and_b64 %[fresh], %[fresh], vcc\n\t"
 
+// label 4: the hop's node is in klo: count it, then its adjacency row (Graph.adjacent, :570) -- fetched during the previous hop
+// if the guess was right -- into nb
+#define HNSW_HOP_ADJACENCY \
+        "4:\n\t"                                                                                                              \
+        "s_add_u32 %[nh], %[nh], 1\n\t"                                                                                       \
+  /* adjacency row (Graph.adjacent, :570): fetched during the previous hop if the guess was right */                          \
+        "s_cmp_eq_u32 %[klo], %[pref]\n\t"                                                                                    \
+        "s_cbranch_scc1 5f\n\t"                                                                                               \
+        "s_mul_i32 %[tmp], %[klo], %[rowb]\n\t"  /* byte offset of the row (the caller checked that the table is < 4 GiB) */  \
+        "v_add_u32_e32 %[t0], %[tmp], %[lane4]\n\t"                                                                           \
+        "s_waitcnt vmcnt(0)\n\t"  /* a wrong guess still in flight is drained first (its target is pnb) */                    \
+        "v_mov_b32_e32 %[nb], -1\n\t"                                                                                         \
+        "s_mov_b64 exec, %[rowm]\n\t"                                                                                         \
+        "global_load_dword %[nb], %[t0], %[nbr]\n\t"                                                                          \
+        "s_mov_b64 exec, -1\n\t"                                                                                              \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                              \
+        "s_branch 6f\n"                                                                                                       \
+        "5:\n\t"                                                                                                              \
+        "s_add_u32 %[st], %[st], 0x100\n\t"                                                                                   \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                              \
+        "v_mov_b32_e32 %[nb], %[pnb]\n"                                                                                       
+
+// label 6: visited filter (Visited.mem, :571), first half: the set's word is requested, the tag computed
+#define HNSW_HOP_FILTER_ISSUE \
+        "6:\n\t"                                                               \
+  /* visited filter (Visited.mem, :571): 2-way set of 16-bit tags per word */  \
+        "v_and_b32_e32 %[va], %[setm], %[nb]\n\t"                              \
+        "v_lshl_add_u32 %[va], %[va], 2, %[vtb]\n\t"                           \
+        "ds_read_b32 %[vw], %[va]\n\t"                                         \
+        "v_lshrrev_b32_e32 %[tag], %[setb], %[nb]\n\t"                         \
+        "v_cmp_lt_i32_e32 vcc, -1, %[nb]\n\t"                                  
+
+// visited filter, second half: 2-way compare -> fresh; nothing fresh: next hop (1b); Visited.add (:572) and the list of
+// fresh neighbours in row order; the round variables
+#define HNSW_HOP_FILTER_COMPACT \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+        "v_cmp_ne_u32_sdwa %[um0], %[vw], %[tag] src0_sel:WORD_0 src1_sel:DWORD\n\t"   \
+        "v_cmp_ne_u32_sdwa %[um1], %[vw], %[tag] src0_sel:WORD_1 src1_sel:DWORD\n\t"   \
+        "s_and_b64 %[fresh], %[um0], %[um1]\n\t"                                       \
+        "s_and_b64 %[fresh], %[fresh], vcc\n\t"                                        \
+        "s_cbranch_scc0 1b\n\t"  /* nothing fresh: next hop */                         \
+  /* Visited.add (:572) and the list of fresh neighbours, in row order */              \
+        "s_bcnt1_i32_b64 %[cnt], %[fresh]\n\t"                                         \
+        "s_mov_b64 exec, %[fresh]\n\t"                                                 \
+        "v_mbcnt_lo_u32_b32 %[t0], exec_lo, 0\n\t"  /* exec is the fresh mask here */  \
+        "v_mbcnt_hi_u32_b32 %[t0], exec_hi, %[t0]\n\t"                                 \
+        "v_lshl_or_b32 %[vw], %[vw], 16, %[tag]\n\t"                                   \
+        "ds_write_b32 %[va], %[vw]\n\t"                                                \
+        "v_lshl_add_u32 %[t0], %[t0], 2, %[cand]\n\t"                                  \
+        "ds_write_b32 %[t0], %[nb]\n\t"                                                \
+        "s_mov_b64 exec, -1\n\t"                                                       \
+        "s_add_u32 %[nd], %[nd], %[cnt]\n\t"                                           \
+        "s_mov_b32 %[base], 0\n\t"                                                     \
+        "s_lshl_b32 %[lastad], %[cnt], 2\n\t"                                          \
+        "s_add_u32 %[lastad], %[lastad], %[cand]\n\t"                                  \
+        "s_sub_u32 %[lastad], %[lastad], 4\n"                                          
+
+// labels 20 / 30 / 40: one round of 4 / 8 / 16 rows -> ckey, cid, the accept mask in `fresh`, base advanced; falls through to 50
+#define HNSW_HOP_ROUNDS \
+        "20:\n\t"                                                                                                                     \
+        "s_sub_u32 %[tmp], %[cnt], %[base]\n\t"                                                                                       \
+        "s_lshl_b32 %[sx], %[base], 2\n\t"                                                                                            \
+        "s_add_u32 %[sx], %[sx], %[cand]\n\t"                                                                                         \
+        "s_cmp_gt_u32 %[tmp], 8\n\t"                                                                                                  \
+        "s_cbranch_scc1 40f\n\t"                                                                                                      \
+        "s_cmp_gt_u32 %[tmp], 4\n\t"                                                                                                  \
+        "s_cbranch_scc1 30f\n\t"                                                                                                      \
+  /* ---- 4 rows: one batch */                                                                                                        \
+        HNSW_ID_READ(0, "%[id0]", 0)                                                                                                  \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
+        "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
+        "s_nop 2\n\t"                                                                                                                 \
+        HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:4" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:2" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:1" HNSW_DPP_BC "\n\t"                                                              \
+        "v_add_u32_e32 %[d0], %[q2], %[d0]\n\t"                                                                                       \
+        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"                                                                                        \
+        HNSW_ACCEPT("%[co1]")                                                                                                         \
+        "s_add_u32 %[base], %[base], 4\n\t"                                                                                           \
+        "s_branch 50f\n"                                                                                                              \
+  /* ---- 8 rows: two batches */                                                                                                      \
+        "30:\n\t"                                                                                                                     \
+        HNSW_ID_READ(0, "%[id0]", 1)                                                                                                  \
+        HNSW_ID_READ(1, "%[id1]", 1)                                                                                                  \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")                                                                           \
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"                                                                        \
+        "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
+        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_DOTS("%[d2]", "%[d3]", "%[tb]")                                                                                          \
+        HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        "s_nop 2\n\t"                                                                                                                 \
+        HNSW_COMBINE("%[d2]", "%[tb]")                                                                                                \
+        "v_cndmask_b32_e64 %[ta], %[d0], %[d2], %[b3m]\n\t"  /* keep: the sum this half of the group is for */                        \
+        "v_cndmask_b32_e64 %[tb], %[d2], %[d0], %[b3m]\n\t"  /* give: the other half's */                                             \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[ta], %[tb], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[ta], %[ta], %[ta] row_half_mirror" HNSW_DPP_BC "\n\t"                                                        \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"                                                    \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
+        "v_add_u32_e32 %[ta], %[q2], %[ta]\n\t"                                                                                       \
+        "v_cvt_f32_i32_e32 %[ckey], %[ta]\n\t"                                                                                        \
+        HNSW_ACCEPT("%[co2]")                                                                                                         \
+        "s_add_u32 %[base], %[base], 8\n\t"                                                                                           \
+        "s_branch 50f\n"                                                                                                              \
+  /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
+        "40:\n\t"                                                                                                                     \
+        HNSW_ID_READ(0, "%[id0]", 2)                                                                                                  \
+        HNSW_ID_READ(1, "%[id1]", 2)                                                                                                  \
+        HNSW_ID_READ(2, "%[id2]", 2)                                                                                                  \
+        HNSW_ID_READ(3, "%[id3]", 2)                                                                                                  \
+        "s_waitcnt lgkmcnt(3)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")                                                                           \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD("%[id2]", "%[ad2]", "%[d4]", "%[d5]")                                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD("%[id3]", "%[ad3]", "%[d6]", "%[d7]")                                                                           \
+        "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"                                                                        \
+        "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"                                                                        \
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"                                                                        \
+        "s_waitcnt vmcnt(6)\n\t"                                                                                                      \
+        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
+        "s_waitcnt vmcnt(4)\n\t"                                                                                                      \
+        HNSW_DOTS("%[d2]", "%[d3]", "%[tb]")                                                                                          \
+        "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
+        HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        HNSW_DOTS("%[d4]", "%[d5]", "%[ta]")                                                                                          \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_COMBINE("%[d2]", "%[tb]")                                                                                                \
+        HNSW_DOTS("%[d6]", "%[d7]", "%[tb]")                                                                                          \
+        HNSW_COMBINE("%[d4]", "%[ta]")                                                                                                \
+        "s_nop 2\n\t"                                                                                                                 \
+        HNSW_COMBINE("%[d6]", "%[tb]")                                                                                                \
+  /* sums of candidates 0..3 of the group in d0, d2, d4, d6 -> quads of the group's 16 lanes */                                       \
+        "v_cndmask_b32_e64 %[ta], %[d0], %[d4], %[b3m]\n\t"                                                                           \
+        "v_cndmask_b32_e64 %[d1], %[d4], %[d0], %[b3m]\n\t"                                                                           \
+        "v_cndmask_b32_e64 %[tb], %[d2], %[d6], %[b3m]\n\t"                                                                           \
+        "v_cndmask_b32_e64 %[d3], %[d6], %[d2], %[b3m]\n\t"                                                                           \
+        "v_add_u32_dpp %[ta], %[d1], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"  /* candidates 0 | 2 (d1 written three instructions ago) */  \
+        "s_nop 0\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[tb], %[d3], %[tb] row_ror:8" HNSW_DPP_BC "\n\t"  /* candidates 1 | 3 */                                      \
+        "v_cndmask_b32_e64 %[d0], %[ta], %[tb], %[b2m]\n\t"                                                                           \
+        "v_cndmask_b32_e64 %[d1], %[tb], %[ta], %[b2m]\n\t"                                                                           \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d1], %[d0] row_half_mirror" HNSW_DPP_BC "\n\t"                                                        \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"                                                    \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
+        "v_add_u32_e32 %[d0], %[q2], %[d0]\n\t"                                                                                       \
+        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"                                                                                        \
+        HNSW_ACCEPT("%[co4]")                                                                                                         \
+        "s_add_u32 %[base], %[base], 16\n"                                                                                            
+
+// labels 90 / 99: no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568), else done
+#define HNSW_HOP_TAIL \
+        "90:\n\t"                                                                   \
+        "s_cmp_eq_u32 %[oc], 0\n\t"                                                 \
+        "s_cbranch_scc1 99f\n\t"                                                    \
+        "s_sub_u32 %[oc], %[oc], 1\n\t"                                             \
+        "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                           \
+        "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                     \
+        "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                           \
+        "ds_read_b32 %[t0], %[t0] offset:768\n\t"                                   \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                  \
+        "v_readfirstlane_b32 %[klo], %[t0]\n\t"                                     \
+        "s_mov_b64 %[um0], 0\n\t"                                                   \
+        "s_mov_b64 %[um1], 0\n\t"                                                   \
+        "s_branch 4b\n"                                                             \
+        "99:\n\t"                                                                   \
+        "s_waitcnt vmcnt(0)"  /* a speculative row fetch may still be in flight */  
+
+// per-lane constants of the hop: byte offsets, the candidate a lane's sum belongs to in a round of 1 / 2 / 4 batches (0x1000 on
+// the lanes that hold no candidate's sum), the lane-bit masks of the transposing reduction
+#define HNSW_HOP_CONSTANTS \
+        "v_lshlrev_b32_e32 %[lane4], 2, %[lane]\n\t"                                                   \
+        "v_lshrrev_b32_e32 %[r4], 4, %[lane]\n\t"  /* r */                                             \
+        "v_bfe_u32 %[t0], %[lane], 3, 1\n\t"                                                           \
+        "v_lshl_add_u32 %[co2], %[r4], 1, %[t0]\n\t"  /* NB 2: 2 r + bit 3 of the lane */              \
+        "v_bfe_u32 %[t0], %[lane], 2, 2\n\t"                                                           \
+        "v_lshl_add_u32 %[co4], %[r4], 2, %[t0]\n\t"  /* NB 4: 4 r + bits 3:2 */                       \
+        "v_mov_b32_e32 %[co1], %[r4]\n\t"  /* NB 1: candidate r */                                     \
+        "v_mov_b32_e32 %[t1], 0x1000\n\t"  /* lanes that hold no candidate's sum: never below cnt */   \
+        "v_and_b32_e32 %[t0], 15, %[lane]\n\t"                                                         \
+        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
+        "s_nop 1\n\t"  /* gfx950: a vector write of vcc, then 2 wait states before a vector read */    \
+        "v_cndmask_b32_e32 %[co1], %[t1], %[co1], vcc\n\t"                                             \
+        "v_and_b32_e32 %[t0], 7, %[lane]\n\t"                                                          \
+        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
+        "s_nop 1\n\t"                                                                                  \
+        "v_cndmask_b32_e32 %[co2], %[t1], %[co2], vcc\n\t"                                             \
+        "v_and_b32_e32 %[t0], 3, %[lane]\n\t"                                                          \
+        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
+        "s_nop 1\n\t"                                                                                  \
+        "v_cndmask_b32_e32 %[co4], %[t1], %[co4], vcc\n\t"                                             \
+        "v_lshlrev_b32_e32 %[r4], 2, %[r4]\n\t"  /* 4 r: byte offset of candidate r in the id list */  \
+        "v_and_b32_e32 %[t0], 8, %[lane]\n\t"                                                          \
+        "v_cmp_ne_u32_e64 %[b3m], 0, %[t0]\n\t"                                                        \
+        "v_and_b32_e32 %[t0], 4, %[lane]\n\t"                                                          \
+        "v_cmp_ne_u32_e64 %[b2m], 0, %[t0]\n\t"                                                        
+
+// labels 8 / 9: pref holds the low key half of the next nearest unexpanded member of W: its node, and its adjacency row
+// requested into pnb beside this hop's vectors
+#define HNSW_HOP_PREFETCH_LOAD \
+        "8:\n\t"                                                  \
+        "s_lshr_b32 %[pref], %[pref], 1\n\t"                      \
+        "s_sub_u32 %[pref], %[pref], 1\n\t"                       \
+        "s_mul_i32 %[tmp], %[pref], %[rowb]\n\t"                  \
+        "v_add_u32_e32 %[t1], %[tmp], %[lane4]\n\t"               \
+        "v_mov_b32_e32 %[pnb], -1\n\t"                            \
+        "s_mov_b64 exec, %[rowm]\n\t"                             \
+        "global_load_dword %[pnb], %[t1], %[nbr]\n\t"             \
+        "s_mov_b64 exec, -1\n"                                    \
+        "9:\n\t"
+
 // Runs the layer-0 search to completion.  On entry W holds the start node (unexpanded) and the visited cache knows it.
 __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, WList<2> &w, const WaveCtx &cx,
                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status, uint32_t maxhops = 0xFFFFFFFFu) {
@@ -192,32 +421,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     uint64_t um0, um1, fresh, b3m, b2m;   // um0 / um1 double as the insertion's equality masks, fresh as the round's accept mask
     uint32_t pref, cnt, base, sx, lastad, i, kd, klo, p, t, nw, tmp;   // klo doubles as the hop's node, sx / tmp as the shift's carries
     asm volatile(
-        // ---- per-lane constants
-        "v_lshlrev_b32_e32 %[lane4], 2, %[lane]\n\t"
-        "v_lshrrev_b32_e32 %[r4], 4, %[lane]\n\t"                         // r
-        "v_bfe_u32 %[t0], %[lane], 3, 1\n\t"
-        "v_lshl_add_u32 %[co2], %[r4], 1, %[t0]\n\t"                      // NB 2: 2 r + bit 3 of the lane
-        "v_bfe_u32 %[t0], %[lane], 2, 2\n\t"
-        "v_lshl_add_u32 %[co4], %[r4], 2, %[t0]\n\t"                      // NB 4: 4 r + bits 3:2
-        "v_mov_b32_e32 %[co1], %[r4]\n\t"                                 // NB 1: candidate r
-        "v_mov_b32_e32 %[t1], 0x1000\n\t"                                 // lanes that hold no candidate's sum: never below cnt
-        "v_and_b32_e32 %[t0], 15, %[lane]\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
-        "s_nop 1\n\t"                                                     // gfx950: a vector write of vcc, then 2 wait states before a vector read
-        "v_cndmask_b32_e32 %[co1], %[t1], %[co1], vcc\n\t"
-        "v_and_b32_e32 %[t0], 7, %[lane]\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
-        "s_nop 1\n\t"
-        "v_cndmask_b32_e32 %[co2], %[t1], %[co2], vcc\n\t"
-        "v_and_b32_e32 %[t0], 3, %[lane]\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
-        "s_nop 1\n\t"
-        "v_cndmask_b32_e32 %[co4], %[t1], %[co4], vcc\n\t"
-        "v_lshlrev_b32_e32 %[r4], 2, %[r4]\n\t"                           // 4 r: byte offset of candidate r in the id list
-        "v_and_b32_e32 %[t0], 8, %[lane]\n\t"
-        "v_cmp_ne_u32_e64 %[b3m], 0, %[t0]\n\t"
-        "v_and_b32_e32 %[t0], 4, %[lane]\n\t"
-        "v_cmp_ne_u32_e64 %[b2m], 0, %[t0]\n\t"
+        HNSW_HOP_CONSTANTS
         "s_mov_b32 %[pref], -1\n"
         // ================================ one hop ================================
         "1:\n\t"
@@ -255,31 +459,8 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "3:\n\t"
         "s_lshr_b32 %[klo], %[kd], 1\n\t"
         "s_sub_u32 %[klo], %[klo], 1\n"                                       // node id
-        "4:\n\t"
-        "s_add_u32 %[nh], %[nh], 1\n\t"
-        // adjacency row (Graph.adjacent, :570): fetched during the previous hop if the guess was right
-        "s_cmp_eq_u32 %[klo], %[pref]\n\t"
-        "s_cbranch_scc1 5f\n\t"
-        "s_mul_i32 %[tmp], %[klo], %[rowb]\n\t"                             // byte offset of the row (the caller checked that the table is < 4 GiB)
-        "v_add_u32_e32 %[t0], %[tmp], %[lane4]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"                                          // a wrong guess still in flight is drained first (its target is pnb)
-        "v_mov_b32_e32 %[nb], -1\n\t"
-        "s_mov_b64 exec, %[rowm]\n\t"
-        "global_load_dword %[nb], %[t0], %[nbr]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_branch 6f\n"
-        "5:\n\t"
-        "s_add_u32 %[st], %[st], 0x100\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_mov_b32_e32 %[nb], %[pnb]\n"
-        "6:\n\t"
-        // visited filter (Visited.mem, :571): 2-way set of 16-bit tags per word
-        "v_and_b32_e32 %[va], %[setm], %[nb]\n\t"
-        "v_lshl_add_u32 %[va], %[va], 2, %[vtb]\n\t"
-        "ds_read_b32 %[vw], %[va]\n\t"
-        "v_lshrrev_b32_e32 %[tag], %[setb], %[nb]\n\t"
-        "v_cmp_lt_i32_e32 vcc, -1, %[nb]\n\t"
+        HNSW_HOP_ADJACENCY
+        HNSW_HOP_FILTER_ISSUE
 #if HNSW_ASM_PREFETCH
         // the next nearest unexpanded member of W: its row is fetched now, beside this hop's vectors
         "s_mov_b32 %[pref], -1\n\t"
@@ -293,176 +474,17 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "s_cbranch_scc1 9f\n\t"
         "s_ff1_i32_b64 %[i], %[um1]\n\t"
         "v_readlane_b32 %[pref], %[l1], %[i]\n"
-        "8:\n\t"
-        "s_lshr_b32 %[pref], %[pref], 1\n\t"
-        "s_sub_u32 %[pref], %[pref], 1\n\t"
-        "s_mul_i32 %[tmp], %[pref], %[rowb]\n\t"
-        "v_add_u32_e32 %[t1], %[tmp], %[lane4]\n\t"
-        "v_mov_b32_e32 %[pnb], -1\n\t"
-        "s_mov_b64 exec, %[rowm]\n\t"
-        "global_load_dword %[pnb], %[t1], %[nbr]\n\t"
-        "s_mov_b64 exec, -1\n"
-        "9:\n\t"
+        HNSW_HOP_PREFETCH_LOAD
 #endif
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_ne_u32_sdwa %[um0], %[vw], %[tag] src0_sel:WORD_0 src1_sel:DWORD\n\t"
-        "v_cmp_ne_u32_sdwa %[um1], %[vw], %[tag] src0_sel:WORD_1 src1_sel:DWORD\n\t"
-        "s_and_b64 %[fresh], %[um0], %[um1]\n\t"
-        "s_and_b64 %[fresh], %[fresh], vcc\n\t"
-        "s_cbranch_scc0 1b\n\t"                                           // nothing fresh: next hop
-        // Visited.add (:572) and the list of fresh neighbours, in row order
-        "s_bcnt1_i32_b64 %[cnt], %[fresh]\n\t"
-        "s_mov_b64 exec, %[fresh]\n\t"
-        "v_mbcnt_lo_u32_b32 %[t0], exec_lo, 0\n\t"                        // exec is the fresh mask here
-        "v_mbcnt_hi_u32_b32 %[t0], exec_hi, %[t0]\n\t"
-        "v_lshl_or_b32 %[vw], %[vw], 16, %[tag]\n\t"
-        "ds_write_b32 %[va], %[vw]\n\t"
-        "v_lshl_add_u32 %[t0], %[t0], 2, %[cand]\n\t"
-        "ds_write_b32 %[t0], %[nb]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_add_u32 %[nd], %[nd], %[cnt]\n\t"
-        "s_mov_b32 %[base], 0\n\t"
-        "s_lshl_b32 %[lastad], %[cnt], 2\n\t"
-        "s_add_u32 %[lastad], %[lastad], %[cand]\n\t"
-        "s_sub_u32 %[lastad], %[lastad], 4\n"
-        // ================================ one round ================================
-        "20:\n\t"
-        "s_sub_u32 %[tmp], %[cnt], %[base]\n\t"
-        "s_lshl_b32 %[sx], %[base], 2\n\t"
-        "s_add_u32 %[sx], %[sx], %[cand]\n\t"
-#if HNSW_ASM_MAXNB >= 4
-        "s_cmp_gt_u32 %[tmp], 8\n\t"
-        "s_cbranch_scc1 40f\n\t"
-#endif
-#if HNSW_ASM_MAXNB >= 2
-        "s_cmp_gt_u32 %[tmp], 4\n\t"
-        "s_cbranch_scc1 30f\n\t"
-#endif
-        // ---- 4 rows: one batch
-        HNSW_ID_READ(0, "%[id0]", 0)
-        "s_waitcnt lgkmcnt(0)\n\t"
-        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")
-        "s_waitcnt vmcnt(0)\n\t"
-        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")
-        "v_mov_b32_e32 %[cid], %[id0]\n\t"
-        "s_nop 2\n\t"
-        HNSW_COMBINE("%[d0]", "%[ta]")
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:8" HNSW_DPP_BC "\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:4" HNSW_DPP_BC "\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:2" HNSW_DPP_BC "\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:1" HNSW_DPP_BC "\n\t"
-        "v_add_u32_e32 %[d0], %[q2], %[d0]\n\t"
-        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"
-        HNSW_ACCEPT("%[co1]")
-        "s_add_u32 %[base], %[base], 4\n\t"
-        "s_branch 50f\n"
-        // ---- 8 rows: two batches
-        "30:\n\t"
-        HNSW_ID_READ(0, "%[id0]", 1)
-        HNSW_ID_READ(1, "%[id1]", 1)
-        "s_waitcnt lgkmcnt(1)\n\t"
-        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")
-        "s_waitcnt lgkmcnt(0)\n\t"
-        HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")
-        "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")
-        "s_waitcnt vmcnt(0)\n\t"
-        HNSW_DOTS("%[d2]", "%[d3]", "%[tb]")
-        HNSW_COMBINE("%[d0]", "%[ta]")
-        "s_nop 2\n\t"
-        HNSW_COMBINE("%[d2]", "%[tb]")
-        "v_cndmask_b32_e64 %[ta], %[d0], %[d2], %[b3m]\n\t"               // keep: the sum this half of the group is for
-        "v_cndmask_b32_e64 %[tb], %[d2], %[d0], %[b3m]\n\t"               // give: the other half's
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[ta], %[tb], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[ta], %[ta], %[ta] row_half_mirror" HNSW_DPP_BC "\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"
-        "v_add_u32_e32 %[ta], %[q2], %[ta]\n\t"
-        "v_cvt_f32_i32_e32 %[ckey], %[ta]\n\t"
-        HNSW_ACCEPT("%[co2]")
-        "s_add_u32 %[base], %[base], 8\n\t"
-        "s_branch 50f\n"
-        // ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end)
-        "40:\n\t"
-        HNSW_ID_READ(0, "%[id0]", 2)
-        HNSW_ID_READ(1, "%[id1]", 2)
-        HNSW_ID_READ(2, "%[id2]", 2)
-        HNSW_ID_READ(3, "%[id3]", 2)
-        "s_waitcnt lgkmcnt(3)\n\t"
-        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")
-        "s_waitcnt lgkmcnt(2)\n\t"
-        HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")
-        "s_waitcnt lgkmcnt(1)\n\t"
-        HNSW_ROW_LOAD("%[id2]", "%[ad2]", "%[d4]", "%[d5]")
-        "s_waitcnt lgkmcnt(0)\n\t"
-        HNSW_ROW_LOAD("%[id3]", "%[ad3]", "%[d6]", "%[d7]")
-        "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"
-        "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"
-        "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"
-        "s_waitcnt vmcnt(6)\n\t"
-        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")
-        "s_waitcnt vmcnt(4)\n\t"
-        HNSW_DOTS("%[d2]", "%[d3]", "%[tb]")
-        "s_waitcnt vmcnt(2)\n\t"
-        HNSW_COMBINE("%[d0]", "%[ta]")
-        HNSW_DOTS("%[d4]", "%[d5]", "%[ta]")
-        "s_waitcnt vmcnt(0)\n\t"
-        HNSW_COMBINE("%[d2]", "%[tb]")
-        HNSW_DOTS("%[d6]", "%[d7]", "%[tb]")
-        HNSW_COMBINE("%[d4]", "%[ta]")
-        "s_nop 2\n\t"
-        HNSW_COMBINE("%[d6]", "%[tb]")
-        // sums of candidates 0..3 of the group in d0, d2, d4, d6 -> quads of the group's 16 lanes
-        "v_cndmask_b32_e64 %[ta], %[d0], %[d4], %[b3m]\n\t"
-        "v_cndmask_b32_e64 %[d1], %[d4], %[d0], %[b3m]\n\t"
-        "v_cndmask_b32_e64 %[tb], %[d2], %[d6], %[b3m]\n\t"
-        "v_cndmask_b32_e64 %[d3], %[d6], %[d2], %[b3m]\n\t"
-        "v_add_u32_dpp %[ta], %[d1], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"  // candidates 0 | 2 (d1 written three instructions ago)
-        "s_nop 0\n\t"
-        "v_add_u32_dpp %[tb], %[d3], %[tb] row_ror:8" HNSW_DPP_BC "\n\t"  // candidates 1 | 3
-        "v_cndmask_b32_e64 %[d0], %[ta], %[tb], %[b2m]\n\t"
-        "v_cndmask_b32_e64 %[d1], %[tb], %[ta], %[b2m]\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[d0], %[d1], %[d0] row_half_mirror" HNSW_DPP_BC "\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"
-        "v_add_u32_e32 %[d0], %[q2], %[d0]\n\t"
-        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"
-        HNSW_ACCEPT("%[co4]")
-        "s_add_u32 %[base], %[base], 16\n"
-        // ---- the round's accepted candidates, in row order, each against the current W (:574-577)
+        HNSW_HOP_FILTER_COMPACT
+        HNSW_HOP_ROUNDS
         "50:\n\t"
         HNSW_INSERT_LOOP
         "s_cmp_lt_u32 %[base], %[cnt]\n\t"
         "s_cbranch_scc1 20b\n\t"
         "s_branch 1b\n"
         // ---- no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568)
-        "90:\n\t"
-        "s_cmp_eq_u32 %[oc], 0\n\t"
-        "s_cbranch_scc1 99f\n\t"
-        "s_sub_u32 %[oc], %[oc], 1\n\t"
-        "s_lshl_b32 %[tmp], %[oc], 2\n\t"
-        "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"
-        "v_mov_b32_e32 %[t0], %[tmp]\n\t"
-        "ds_read_b32 %[t0], %[t0] offset:768\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 %[klo], %[t0]\n\t"
-        "s_mov_b64 %[um0], 0\n\t"
-        "s_mov_b64 %[um1], 0\n\t"
-        "s_branch 4b\n"
-        "99:\n\t"
-        "s_waitcnt vmcnt(0)"                                              // a speculative row fetch may still be in flight
+        HNSW_HOP_TAIL
         : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
@@ -482,6 +504,388 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
 #ifdef HNSW_ASM_DEBUG
           , [maxh] "s"(maxhops)
 #endif
+        : "vcc", "scc", "m0", "memory");
+    w.wmax = wmax; w.ovf_cnt = (int)oc;
+    n_dist = nd; n_hops = nh; status = st;
+}
+
+// =====================================================================================================================
+// The same loop for W in FOUR key registers per lane (ef 129..256) and in ONE (ef <= 64).  Shared with the two-slot
+// loop: everything between the pop and the insertion (HNSW_HOP_* above).  Different: where the flags are looked for
+// (one mask per slot) and the insertion.
+//
+// Four slots: the rank is found in two steps, as in wlist_insert's NSLOT > 2 path: the slot first, from the slots'
+// maxima (mx0..mx2 = the keys' distance halves in lane 63 of slots 0..2, kept in scalar registers: max(W) is slot 3's),
+// then the position inside that slot (one compare + count).  The shift cascades: every slot above the rank's slot
+// moves by one whole and takes its lower neighbour's last key in lane 0, the rank's slot moves from the rank on.
+// A member of W at exactly the candidate's distance (ids decide; the run of equal keys may cross a slot boundary)
+// takes the general path, which ranks over all four slots.
+// =====================================================================================================================
+
+// pop from slot S (key halves LS): label LBL; continues at NEXT when the slot has no unexpanded member
+#define HNSW_POP_SLOT(LBL, UM, LS, NEXT)                            \
+    LBL ":\n\t"                                                     \
+    "s_cmp_eq_u64 " UM ", 0\n\t"                                    \
+    "s_cbranch_scc1 " NEXT "\n\t"                                   \
+    "s_ff1_i32_b64 %[i], " UM "\n\t"                                \
+    "v_readlane_b32 %[kd], " LS ", %[i]\n\t"                        \
+    "s_bitset0_b64 " UM ", %[i]\n\t"                                \
+    "s_mov_b32 m0, %[i]\n\t"                                        \
+    "s_or_b32 %[t], %[kd], 1\n\t"                                   \
+    "v_writelane_b32 " LS ", %[t], m0\n\t"                          \
+    "s_branch 3f\n"
+// the same walk for the speculative row fetch: the first remaining unexpanded member's low half -> pref, then 8f; none: 9f
+#define HNSW_PEEK_SLOT(LBL, UM, LS, NEXT)                           \
+    LBL ":\n\t"                                                     \
+    "s_cmp_eq_u64 " UM ", 0\n\t"                                    \
+    "s_cbranch_scc1 " NEXT "\n\t"                                   \
+    "s_ff1_i32_b64 %[i], " UM "\n\t"                                \
+    "v_readlane_b32 %[pref], " LS ", %[i]\n\t"                      \
+    "s_branch 8f\n"
+// slot J moves by one whole position and takes slot J-1's last key in lane 0 (read BEFORE slot J-1 moves)
+#define HNSW_SHIFT_WHOLE(HJ, LJ, HJM1, LJM1)                        \
+    "v_readlane_b32 %[sx], " HJM1 ", 63\n\t"                        \
+    "v_readlane_b32 %[tmp], " LJM1 ", 63\n\t"                       \
+    "v_mov_b32_dpp " HJ ", " HJ " wave_shr:1" HNSW_DPP_ALL "\n\t"   \
+    "v_mov_b32_dpp " LJ ", " LJ " wave_shr:1" HNSW_DPP_ALL "\n\t"   \
+    "v_writelane_b32 " HJ ", %[sx], 0\n\t"                          \
+    "v_writelane_b32 " LJ ", %[tmp], 0\n\t"
+// the rank's slot moves from lane p on (EXEC narrowed; lane p keeps its value until the new key is written there)
+#define HNSW_SHIFT_FROM(HS, LS)                                     \
+    "s_lshl_b64 exec, -1, %[p]\n\t"                                 \
+    "v_mov_b32_dpp " HS ", " HS " wave_shr:1" HNSW_DPP_ALL "\n\t"   \
+    "v_mov_b32_dpp " LS ", " LS " wave_shr:1" HNSW_DPP_ALL "\n\t"   \
+    "s_mov_b64 exec, -1\n\t"                                        \
+    "s_mov_b32 m0, %[p]\n\t"                                        \
+    "v_writelane_b32 " HS ", %[kd], m0\n\t"                         \
+    "v_writelane_b32 " LS ", %[klo], m0\n\t"
+// rank inside slot S (BASE = 64 S): a member at this very distance -> general path (14); else P = BASE + keys below -> 11
+#define HNSW_RANK_IN_SLOT(LBL, HS, BASE)                            \
+    LBL ":\n\t"                                                     \
+    "v_cmp_eq_u32_e32 vcc, %[kd], " HS "\n\t"                       \
+    "s_cmp_lg_u64 vcc, 0\n\t"                                       \
+    "s_cbranch_scc1 14f\n\t"                                        \
+    "v_cmp_gt_u32_e32 vcc, %[kd], " HS "\n\t"                       \
+    "s_bcnt1_i32_b64 %[P], vcc\n\t"                                 \
+    "s_add_u32 %[P], %[P], " #BASE "\n\t"                           \
+    "s_branch 11f\n"
+// general path, per slot: keys below by distance, plus the members at this distance with a smaller id; the node itself
+// (flag bit either way) in W -> dup
+#define HNSW_RANK_GENERAL_SLOT(HS, LS)                              \
+    "v_cmp_gt_u32_e32 vcc, %[kd], " HS "\n\t"                       \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                 \
+    "s_add_u32 %[P], %[P], %[t]\n\t"                                \
+    "v_cmp_eq_u32_e64 %[um0], %[kd], " HS "\n\t"                    \
+    "v_cmp_gt_u32_e32 vcc, %[klo], " LS "\n\t"                      \
+    "s_and_b64 vcc, vcc, %[um0]\n\t"                                \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                 \
+    "s_add_u32 %[P], %[P], %[t]\n\t"                                \
+    "v_or_b32_e32 %[t0], 1, " LS "\n\t"                             \
+    "v_cmp_eq_u32_e32 vcc, %[p], %[t0]\n\t"                         \
+    "s_and_b64 vcc, vcc, %[um0]\n\t"                                \
+    "s_or_b64 %[um1], %[um1], vcc\n\t"
+
+#define HNSW_INSERT_LOOP4                                                                                                \
+    "10:\n\t"                                                                                                            \
+    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 19f\n\t"                                                                                             \
+    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                   \
+    "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
+    "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
+    "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
+    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
+    "s_lshl_b32 %[klo], %[klo], 1\n\t"                                                                                   \
+    "s_add_u32 %[klo], %[klo], 2\n\t"                                     /* low half: (id + 1) << 1, unexpanded */      \
+    "s_cmp_lt_u32 %[mx2], %[kd]\n\t"                                      /* the rank's slot, from the slots' maxima */  \
+    "s_cbranch_scc1 83f\n\t"                                                                                             \
+    "s_cmp_lt_u32 %[mx1], %[kd]\n\t"                                                                                     \
+    "s_cbranch_scc1 82f\n\t"                                                                                             \
+    "s_cmp_lt_u32 %[mx0], %[kd]\n\t"                                                                                     \
+    "s_cbranch_scc1 81f\n"                                                                                               \
+    HNSW_RANK_IN_SLOT("80", "%[h0]", 0)                                                                                  \
+    HNSW_RANK_IN_SLOT("81", "%[h1]", 64)                                                                                 \
+    HNSW_RANK_IN_SLOT("82", "%[h2]", 128)                                                                                \
+    HNSW_RANK_IN_SLOT("83", "%[h3]", 192)                                                                                \
+    "11:\n\t"                                                                                                            \
+    "v_readlane_b32 %[nw], %[h3], 62\n\t"                                                                                \
+    "s_cmp_eq_u32 %[P], 255\n\t"                                                                                         \
+    "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                               /* the new max(W).d */                         \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
+    "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */      \
+    "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
+    "12:\n\t"                                                                                                            \
+    "s_and_b32 %[p], %[P], 63\n\t"                                                                                       \
+    "s_cmp_ge_u32 %[P], 192\n\t"                                                                                         \
+    "s_cbranch_scc1 86f\n\t"                                                                                             \
+    "s_cmp_ge_u32 %[P], 128\n\t"                                                                                         \
+    "s_cbranch_scc1 85f\n\t"                                                                                             \
+    "s_cmp_ge_u32 %[P], 64\n\t"                                                                                          \
+    "s_cbranch_scc1 84f\n\t"                                                                                             \
+    /* rank in slot 0 */                                                                                                 \
+    HNSW_SHIFT_WHOLE("%[h3]", "%[l3]", "%[h2]", "%[l2]")                                                                 \
+    HNSW_SHIFT_WHOLE("%[h2]", "%[l2]", "%[h1]", "%[l1]")                                                                 \
+    HNSW_SHIFT_WHOLE("%[h1]", "%[l1]", "%[h0]", "%[l0]")                                                                 \
+    HNSW_SHIFT_FROM("%[h0]", "%[l0]")                                                                                    \
+    "v_readlane_b32 %[mx0], %[h0], 63\n\t"                                                                               \
+    "v_readlane_b32 %[mx1], %[h1], 63\n\t"                                                                               \
+    "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                               \
+    "s_branch 17f\n"                                                                                                     \
+    "84:\n\t"                                                                                                            \
+    HNSW_SHIFT_WHOLE("%[h3]", "%[l3]", "%[h2]", "%[l2]")                                                                 \
+    HNSW_SHIFT_WHOLE("%[h2]", "%[l2]", "%[h1]", "%[l1]")                                                                 \
+    HNSW_SHIFT_FROM("%[h1]", "%[l1]")                                                                                    \
+    "v_readlane_b32 %[mx1], %[h1], 63\n\t"                                                                               \
+    "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                               \
+    "s_branch 17f\n"                                                                                                     \
+    "85:\n\t"                                                                                                            \
+    HNSW_SHIFT_WHOLE("%[h3]", "%[l3]", "%[h2]", "%[l2]")                                                                 \
+    HNSW_SHIFT_FROM("%[h2]", "%[l2]")                                                                                    \
+    "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                               \
+    "s_branch 17f\n"                                                                                                     \
+    "86:\n\t"                                                                                                            \
+    HNSW_SHIFT_FROM("%[h3]", "%[l3]")                                                                                    \
+    "17:\n\t"                                                                                                            \
+    "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
+    "18:\n\t"                                                                                                            \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
+    "s_branch 10b\n"                                                                                                     \
+    /* rare: a member of W at exactly this distance: rank over all four slots, ids decide; the node itself in W: ignored */ \
+    "14:\n\t"                                                                                                            \
+    "s_mov_b32 %[P], 0\n\t"                                                                                              \
+    "s_mov_b64 %[um1], 0\n\t"                                                                                            \
+    "s_or_b32 %[p], %[klo], 1\n\t"                                                                                       \
+    HNSW_RANK_GENERAL_SLOT("%[h0]", "%[l0]")                                                                             \
+    HNSW_RANK_GENERAL_SLOT("%[h1]", "%[l1]")                                                                             \
+    HNSW_RANK_GENERAL_SLOT("%[h2]", "%[l2]")                                                                             \
+    HNSW_RANK_GENERAL_SLOT("%[h3]", "%[l3]")                                                                             \
+    "s_cmp_lg_u64 %[um1], 0\n\t"                                                                                         \
+    "s_cbranch_scc1 18b\n\t"                                              /* already in W */                             \
+    "s_branch 11b\n"                                                                                                     \
+    /* rare: the entry that falls off is at the new maximum's distance (see the two-slot loop) */                        \
+    "15:\n\t"                                                                                                            \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                       \
+    "s_cbranch_scc1 12b\n\t"                                                                                             \
+    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                 \
+    "s_bitcmp1_b32 %[t], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
+    "s_cbranch_scc1 16f\n\t"                                                                                             \
+    "s_lshr_b32 %[t], %[t], 1\n\t"                                                                                       \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
+    "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                                                                    \
+    "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                                                              \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                    \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                      \
+    "s_mov_b64 exec, 1\n\t"                                                                                              \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                           \
+    "s_mov_b64 exec, -1\n\t"                                                                                             \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                      \
+    "s_branch 12b\n"                                                                                                     \
+    "16:\n\t"                                                                                                            \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 12b\n"                                                                                                     \
+    "19:\n\t"
+
+__device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv, WList<4> &w, const WaveCtx &cx,
+                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+    const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
+    const uint64_t nbr = (uint64_t)(uintptr_t)iv.nbr0;
+    const uint64_t rowm = iv.S0 >= 64 ? ~0ull : ((1ull << iv.S0) - 1ull);
+    const uint32_t rowb = (uint32_t)iv.S0 * 4u, st8 = (uint32_t)iv.stride8;
+    const uint32_t vtb = lds_offset(cx.vt), cand = lds_offset(cx.cand_id);
+    const uint32_t setm = cx.set_mask, setb = (uint32_t)cx.set_bits;
+    const uint32_t q2 = (uint32_t)uniform(cx.q2);
+    uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
+    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt);
+    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint64_t ad0, ad1, ad2, ad3;
+    uint64_t um0, um1, um2, um3, fresh, b3m, b2m;
+    uint32_t pref, cnt, base, sx, lastad, i, kd, klo, p, P, t, nw, tmp, mx0, mx1, mx2;
+    asm volatile(
+        HNSW_HOP_CONSTANTS
+        "v_readlane_b32 %[mx0], %[h0], 63\n\t"                            // the slots' maxima (distance halves)
+        "v_readlane_b32 %[mx1], %[h1], 63\n\t"
+        "v_readlane_b32 %[mx2], %[h2], 63\n\t"
+        "s_mov_b32 %[pref], -1\n"
+        // ================================ one hop ================================
+        "1:\n\t"
+        // pop: the first unexpanded member of W (pop_min, :565) and its flag
+        "v_and_b32_e32 %[t0], 1, %[l0]\n\t"
+        "v_and_b32_e32 %[t1], 1, %[l1]\n\t"
+        "v_cmp_eq_u32_e64 %[um0], 0, %[t0]\n\t"
+        "v_cmp_eq_u32_e64 %[um1], 0, %[t1]\n\t"
+        "v_and_b32_e32 %[t0], 1, %[l2]\n\t"
+        "v_and_b32_e32 %[t1], 1, %[l3]\n\t"
+        "v_cmp_eq_u32_e64 %[um2], 0, %[t0]\n\t"
+        "v_cmp_eq_u32_e64 %[um3], 0, %[t1]\n"
+        HNSW_POP_SLOT("60", "%[um0]", "%[l0]", "61f")
+        HNSW_POP_SLOT("61", "%[um1]", "%[l1]", "62f")
+        HNSW_POP_SLOT("62", "%[um2]", "%[l2]", "63f")
+        HNSW_POP_SLOT("63", "%[um3]", "%[l3]", "90f")
+        "3:\n\t"
+        "s_lshr_b32 %[klo], %[kd], 1\n\t"
+        "s_sub_u32 %[klo], %[klo], 1\n"                                   // node id
+        HNSW_HOP_ADJACENCY
+        HNSW_HOP_FILTER_ISSUE
+#if HNSW_ASM_PREFETCH
+        "s_mov_b32 %[pref], -1\n"
+        HNSW_PEEK_SLOT("70", "%[um0]", "%[l0]", "71f")
+        HNSW_PEEK_SLOT("71", "%[um1]", "%[l1]", "72f")
+        HNSW_PEEK_SLOT("72", "%[um2]", "%[l2]", "73f")
+        HNSW_PEEK_SLOT("73", "%[um3]", "%[l3]", "9f")
+        HNSW_HOP_PREFETCH_LOAD
+#endif
+        HNSW_HOP_FILTER_COMPACT
+        HNSW_HOP_ROUNDS
+        "50:\n\t"
+        HNSW_INSERT_LOOP4
+        "s_cmp_lt_u32 %[base], %[cnt]\n\t"
+        "s_cbranch_scc1 20b\n\t"
+        "s_branch 1b\n"
+        HNSW_HOP_TAIL
+        : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [h2] "+&v"(w.hi[2]), [h3] "+&v"(w.hi[3]),
+          [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]), [l2] "+&v"(w.lo[2]), [l3] "+&v"(w.lo[3]),
+          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
+          [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
+          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4),
+          [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
+          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
+          [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
+          [um0] "=&s"(um0), [um1] "=&s"(um1), [um2] "=&s"(um2), [um3] "=&s"(um3), [fresh] "=&s"(fresh),
+          [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
+          [pref] "=&s"(pref), [cnt] "=&s"(cnt), [base] "=&s"(base),
+          [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [P] "=&s"(P), [t] "=&s"(t),
+          [nw] "=&s"(nw), [tmp] "=&s"(tmp), [mx0] "=&s"(mx0), [mx1] "=&s"(mx1), [mx2] "=&s"(mx2)
+        : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
+          [nbr] "s"(nbr), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
+          [cand] "s"(cand), [q2] "s"(q2)
+        : "vcc", "scc", "m0", "memory");
+    w.wmax = wmax; w.ovf_cnt = (int)oc;
+    n_dist = nd; n_hops = nh; status = st;
+}
+
+// ---- one slot (ef <= 64): no cascade, the rank is one compare + count -------------------------------------------------
+#define HNSW_INSERT_LOOP1                                                                                                \
+    "10:\n\t"                                                                                                            \
+    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 19f\n\t"                                                                                             \
+    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                   \
+    "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
+    "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
+    "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
+    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
+    "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                          \
+    "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                             \
+    "s_bcnt1_i32_b64 %[p], vcc\n\t"                                       /* rank = keys at a smaller distance */       \
+    "s_lshl_b32 %[klo], %[klo], 1\n\t"                                                                                   \
+    "s_add_u32 %[klo], %[klo], 2\n\t"                                     /* low half: (id + 1) << 1, unexpanded */      \
+    "s_cmp_lg_u64 %[um0], 0\n\t"                                                                                         \
+    "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
+    "11:\n\t"                                                                                                            \
+    "v_readlane_b32 %[nw], %[h0], 62\n\t"                                                                                \
+    "s_cmp_eq_u32 %[p], 63\n\t"                                                                                          \
+    "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                               /* the new max(W).d */                         \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
+    "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */      \
+    "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
+    "12:\n\t"                                                                                                            \
+    HNSW_SHIFT_FROM("%[h0]", "%[l0]")                                                                                    \
+    "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
+    "18:\n\t"                                                                                                            \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
+    "s_branch 10b\n"                                                                                                     \
+    "14:\n\t"                                                                                                            \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[l0]\n\t"                                                                            \
+    "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                      \
+    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                     \
+    "s_or_b32 %[t], %[klo], 1\n\t"                                                                                       \
+    "v_or_b32_e32 %[t0], 1, %[l0]\n\t"                                                                                   \
+    "v_cmp_eq_u32_e32 vcc, %[t], %[t0]\n\t"                                                                              \
+    "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
+    "s_cbranch_scc1 18b\n\t"                                              /* already in W */                             \
+    "s_branch 11b\n"                                                                                                     \
+    "15:\n\t"                                                                                                            \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                       \
+    "s_cbranch_scc1 12b\n\t"                                                                                             \
+    "v_readlane_b32 %[t], %[l0], 63\n\t"                                                                                 \
+    "s_bitcmp1_b32 %[t], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
+    "s_cbranch_scc1 16f\n\t"                                                                                             \
+    "s_lshr_b32 %[t], %[t], 1\n\t"                                                                                       \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
+    "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                                                                    \
+    "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                                                              \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                    \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                      \
+    "s_mov_b64 exec, 1\n\t"                                                                                              \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                           \
+    "s_mov_b64 exec, -1\n\t"                                                                                             \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                      \
+    "s_branch 12b\n"                                                                                                     \
+    "16:\n\t"                                                                                                            \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 12b\n"                                                                                                     \
+    "19:\n\t"
+
+__device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv, WList<1> &w, const WaveCtx &cx,
+                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+    const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
+    const uint64_t nbr = (uint64_t)(uintptr_t)iv.nbr0;
+    const uint64_t rowm = iv.S0 >= 64 ? ~0ull : ((1ull << iv.S0) - 1ull);
+    const uint32_t rowb = (uint32_t)iv.S0 * 4u, st8 = (uint32_t)iv.stride8;
+    const uint32_t vtb = lds_offset(cx.vt), cand = lds_offset(cx.cand_id);
+    const uint32_t setm = cx.set_mask, setb = (uint32_t)cx.set_bits;
+    const uint32_t q2 = (uint32_t)uniform(cx.q2);
+    uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
+    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt);
+    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint64_t ad0, ad1, ad2, ad3;
+    uint64_t um0, um1, fresh, b3m, b2m;    // um1: the visited filter's second compare only
+    uint32_t pref, cnt, base, sx, lastad, i, kd, klo, p, t, nw, tmp;
+    asm volatile(
+        HNSW_HOP_CONSTANTS
+        "s_mov_b32 %[pref], -1\n"
+        "1:\n\t"
+        "v_and_b32_e32 %[t0], 1, %[l0]\n\t"
+        "v_cmp_eq_u32_e64 %[um0], 0, %[t0]\n"
+        HNSW_POP_SLOT("60", "%[um0]", "%[l0]", "90f")
+        "3:\n\t"
+        "s_lshr_b32 %[klo], %[kd], 1\n\t"
+        "s_sub_u32 %[klo], %[klo], 1\n"                                   // node id
+        HNSW_HOP_ADJACENCY
+        HNSW_HOP_FILTER_ISSUE
+#if HNSW_ASM_PREFETCH
+        "s_mov_b32 %[pref], -1\n"
+        HNSW_PEEK_SLOT("70", "%[um0]", "%[l0]", "9f")
+        HNSW_HOP_PREFETCH_LOAD
+#endif
+        HNSW_HOP_FILTER_COMPACT
+        HNSW_HOP_ROUNDS
+        "50:\n\t"
+        HNSW_INSERT_LOOP1
+        "s_cmp_lt_u32 %[base], %[cnt]\n\t"
+        "s_cbranch_scc1 20b\n\t"
+        "s_branch 1b\n"
+        HNSW_HOP_TAIL
+        : [h0] "+&v"(w.hi[0]), [l0] "+&v"(w.lo[0]),
+          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
+          [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
+          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4),
+          [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
+          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
+          [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
+          [um0] "=&s"(um0), [um1] "=&s"(um1), [fresh] "=&s"(fresh),
+          [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
+          [pref] "=&s"(pref), [cnt] "=&s"(cnt), [base] "=&s"(base),
+          [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t),
+          [nw] "=&s"(nw), [tmp] "=&s"(tmp)
+        : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
+          [nbr] "s"(nbr), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
+          [cand] "s"(cand), [q2] "s"(q2)
         : "vcc", "scc", "m0", "memory");
     w.wmax = wmax; w.ovf_cnt = (int)oc;
     n_dist = nd; n_hops = nh; status = st;
