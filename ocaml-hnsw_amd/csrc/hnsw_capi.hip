@@ -126,7 +126,10 @@ int64_t resident_queries(hnsw_index *idx, int ef, int semf) {
 // Chosen: the fewest waves per CU that still cover nq / passes.
 int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
     const int forced = idx->lds_pad >= 0 ? idx->lds_pad : env_int("HNSW_LDS_PAD", -1);
-    if (forced >= 0) return std::min(forced, 32768);
+    if (forced >= 0) {     // an explicit request is clamped to what a workgroup may ask for beside its own scratch
+        const int64_t base_f = (int64_t)(hnsw_dev::wave_lds_words(search_vt_bits(idx, ef)) * sizeof(uint32_t));
+        return (int)std::max<int64_t>(0, std::min<int64_t>(std::min(forced, 32768), 65536 - base_f));
+    }
     const int64_t resident = resident_queries(idx, ef, semf);
     if (nq <= resident || idx->resident_per_cu <= 0) return 0;
     // byte rows: a quarter of the bytes per evaluation, the launch is bound by the latency of a hop, not by the
@@ -143,7 +146,17 @@ int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
         if (w < want_per_cu) break;
         best = k;
     }
-    const int64_t pad = best > k0 ? best * GRANULE - base : 0;
+    int64_t pad = best > k0 ? best * GRANULE - base : 0;
+    // The granule arithmetic above is gfx950's (1280-byte granules, 128 per CU: profiles/r02_residency_sweep.txt).  The
+    // runtime has the last word: the padded request must still hold the wanted waves per CU by ITS count, and fit the
+    // largest dynamic LDS a workgroup may ask for; otherwise the padding is stepped back.
+    if (pad > 0) {
+        int max_lds = 0;
+        if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, idx->device) != hipSuccess) { (void)hipGetLastError(); max_lds = 65536; }
+        const int nslot_ = pick_nslot(ef), nch_ = pick_nch(idx->iv.nchunks);
+        const search_occupancy_fn occ = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)];
+        while (pad > 0 && (base + pad > max_lds || occ(nch_, nslot_, (size_t)(base + pad)) < want_per_cu)) pad = pad > GRANULE ? pad - GRANULE : 0;
+    }
     if (idx->debug_last_nq != nq && env_int("HNSW_DEBUG_RESIDENT", 0) && ((idx->debug_last_nq = nq), true))
         fprintf(stderr, "hnsw: nq %lld, %d waves/CU x %d CUs resident, %lld passes -> want %lld waves/CU: LDS %lld + %lld B\n",
                 (long long)nq, idx->resident_per_cu, idx->cus, (long long)passes, (long long)want_per_cu, (long long)base, (long long)pad);

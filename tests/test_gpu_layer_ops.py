@@ -224,6 +224,64 @@ def test_multi_rccl_exchange_leaves_the_full_result_on_every_device(H, oracle, b
     three.release()
 
 
+def test_multi_device_call_reuses_buffers_checks_parameters_and_repairs_flagged_shards(H, oracle, built):
+    """hnsw_multi_search_batch_device twice in a row hands back the same device tables (buffers are kept, nothing is
+    re-allocated for an equal-sized batch) with the second batch's results; a bad k is a parameter error, not an
+    allocation; and a shard whose queries overflow their tie lists is searched again AFTER the exchange and its slice
+    re-sent, so the table every device ends with is the exact one."""
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    rng = np.random.default_rng(9)
+    three = H.MultiHgraph(hg, [0, 0, 0])
+    Qa = (X[rng.integers(0, g.n, 100)] + 1).astype(np.float32)
+    Qb = (X[rng.integers(0, g.n, 100)] + 2).astype(np.float32)
+    pa = three.search_device(Qa, 48, 10)
+    pb = three.search_device(Qb, 48, 10)
+    assert pa == pb                                                        # same tables, reused
+    want_i, want_d = H.Ohnsw.knn_batch_bigarray(hg, 10, Qb, ef=48)
+    for r in range(3):
+        gi, gd = three.copy_result(r)
+        np.testing.assert_array_equal(gi, want_i)
+        np.testing.assert_array_equal(gd.view(np.uint32), want_d.view(np.uint32))
+    with pytest.raises(H.InvalidArgument, match="k=10 > ef=5"):
+        three.search_device(Qa, 5, 10)
+    three.release()
+    # the tie-overflow scenario of tests/test_gpu_parity.py::test_tie_overflow_beyond_lds_stack on two replicas
+    n = 229
+    pos = np.zeros(n, np.float32)
+    pos[0] = 20.0
+    pos[1:128] = 10.0
+    pos[128:228] = 9.0 - 0.01 * np.arange(100)
+    pos[228] = 0.1
+    rows = [[] for _ in range(n)]
+    rows[0] = [1] + list(range(2, 65))
+    rows[1] = list(range(65, 128)) + [128]
+    for i in range(99):
+        rows[128 + i] = [129 + i]
+    rows[40] = [228]
+    deg0 = np.array([len(r) for r in rows], np.int32)
+    nbr0 = np.full((n, 64), -1, np.int32)
+    for i, r in enumerate(rows):
+        nbr0[i, :len(r)] = r
+    Xo = pos[:, None]
+    go = oracle.Graph(n, 0, deg0, nbr0)
+    spo = oracle.Space.l2(Xo, arith=oracle.TREE16)
+    hgo = H.Hgraph(Xo, deg0, nbr0, entry_point=0, max_degree=32)
+    Q = np.zeros((5, 1), np.float32)
+    Q[3] = 30.0                                                            # one query of the second shard that does not overflow
+    want = oracle.Ohnsw.knn_batch_bigarray(go, spo, Q, k=10, ef=128, ties=oracle.TIES_CANONICAL)
+    two = H.MultiHgraph(hgo, [0, 0])
+    got = two.knn_batch_bigarray(10, Q, ef=128)
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    two.search_device(Q, 128, 10)
+    for r in range(2):
+        gi, gd = two.copy_result(r)                                        # repaired on EVERY device
+        np.testing.assert_array_equal(gi, want[0])
+        np.testing.assert_array_equal(gd.view(np.uint32), want[1].view(np.uint32))
+    two.release()
+
+
 def test_multi_device_errors(H, oracle, built):
     X, sp, g = built
     hg = _hgraph(H, X, g, M=6)
