@@ -784,8 +784,11 @@ def main():
         import tempfile
         t0 = time.time()
         rp = shutil.which("rocprofv3")
+        under_profiler = any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
         if rp is None:
             pmc = {"skipped": "rocprofv3 not on PATH"}
+        elif under_profiler:
+            pmc = {"skipped": "this process is itself being profiled: no nested rocprofv3 passes"}
         else:
             tmpd = tempfile.mkdtemp(prefix="hnsw_pmc_", dir="/tmp")
             try:
