@@ -969,7 +969,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
                                              uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
     const int lane = cx.lane;
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
-#if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING) && !defined(HNSW_TIMING)
+#if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING)
     if constexpr (NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4) && METRIC == 0 && SEM == 0 && ROWS == 2) {
         // the headline shape (d <= 128 byte rows, byte query, L2, Ohnsw rule; ef <= 64 / 65..128 / 129..256): hand-scheduled
         // loop, same results

@@ -21,6 +21,40 @@ namespace hnsw_dev {
 #ifndef HNSW_ASM_LOOP
 #define HNSW_ASM_LOOP 1
 #endif
+// measurement builds (-DHNSW_ASM_PHASE=k, tools/asm_phases.sh): shader-clock cycles spent between probe point k and k + 1 of
+// every hop, summed into the n_dist counter.  Points: 0 hop start, 1 adjacency row in registers, 2 fresh list written,
+// 3 round evaluated and accept mask known, 4 insertions done.  s[90:93] are used by name (declared clobbered).
+#ifdef HNSW_ASM_PHASE
+#define HNSW_PROBE_BEGIN "s_memtime s[90:91]\n\ts_waitcnt lgkmcnt(0)\n\t"
+#define HNSW_PROBE_END "s_memtime s[92:93]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s92, s92, s90\n\ts_add_u32 %[nd], %[nd], s92\n\t"
+#define HNSW_PROBE(K) HNSW_PROBE_SEL(K, HNSW_ASM_PHASE)
+#define HNSW_PROBE_SEL(K, P) HNSW_PROBE_SEL2(K, P)
+#define HNSW_PROBE_SEL2(K, P) HNSW_PROBE_##K##_##P
+#define HNSW_PROBE_0_0 HNSW_PROBE_BEGIN
+#define HNSW_PROBE_1_0 HNSW_PROBE_END
+#define HNSW_PROBE_2_0
+#define HNSW_PROBE_3_0
+#define HNSW_PROBE_4_0
+#define HNSW_PROBE_0_1
+#define HNSW_PROBE_1_1 HNSW_PROBE_BEGIN
+#define HNSW_PROBE_2_1 HNSW_PROBE_END
+#define HNSW_PROBE_3_1
+#define HNSW_PROBE_4_1
+#define HNSW_PROBE_0_2
+#define HNSW_PROBE_1_2
+#define HNSW_PROBE_2_2 HNSW_PROBE_BEGIN
+#define HNSW_PROBE_3_2 HNSW_PROBE_END
+#define HNSW_PROBE_4_2
+#define HNSW_PROBE_0_3
+#define HNSW_PROBE_1_3
+#define HNSW_PROBE_2_3
+#define HNSW_PROBE_3_3 HNSW_PROBE_BEGIN
+#define HNSW_PROBE_4_3 HNSW_PROBE_END
+#define HNSW_PROBE_CLOBBER , "s90", "s91", "s92", "s93"
+#else
+#define HNSW_PROBE(K)
+#define HNSW_PROBE_CLOBBER
+#endif
 #ifndef HNSW_ASM_PREFETCH
 #define HNSW_ASM_PREFETCH 1
 #endif
@@ -61,7 +95,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_INSERT_LOOP                                                                                                 \
     "10:\n\t"                                                                                                            \
     "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                        \
-    "s_cbranch_scc1 19f\n\t"                                                                                             \
+    "s_cbranch_scc1 19f\n"                                                                                               \
+    "110:\n\t"                                                                                                           \
     "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                    \
     "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
     "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
@@ -73,8 +108,6 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_bcnt1_i32_b64 %[p], vcc\n\t"                                                                                      \
     "v_cmp_gt_u32_e32 vcc, %[kd], %[h1]\n\t"                                                                             \
     "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                      \
-    "s_lshl_b32 %[klo], %[klo], 1\n\t"                                                                                   \
-    "s_add_u32 %[klo], %[klo], 2\n\t"                                     /* low half: (id + 1) << 1, unexpanded */      \
     "s_add_u32 %[p], %[p], %[t]\n\t"                                      /* rank = keys at a smaller distance */       \
     "s_or_b64 vcc, %[um0], %[um1]\n\t"                                                                                     \
     "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
@@ -115,7 +148,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
     "18:\n\t"                                                                                                            \
     "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                    \
-    "s_branch 10b\n"                                                                                                     \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 110b\n\t"                                             /* the next accepted candidate */              \
+    "s_branch 19f\n"                                                                                                     \
     /* rare: distance tie inside W.  rank += members at this distance with a smaller id; a member with this id (flag */ \
     /* bit either way) means the node is already in W (a re-evaluation the visited cache forgot): ignored */            \
     "14:\n\t"                                                                                                            \
@@ -166,6 +201,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 // accept ballot of a round: candidate index of this lane = base + CO (per-lane constant; a lane that holds no
 // candidate's sum has 0x1000 there), valid below cnt, and below the current max(W) (lib/ohnsw.ml:574)
 #define HNSW_ACCEPT(CO)                                                                  \
+    "v_lshl_add_u32 %[cid], %[cid], 1, 2\n\t"       /* ids -> low key halves: (id + 1) << 1, unexpanded */  \
     "v_add_u32_e32 %[t0], %[base], " CO "\n\t"                                           \
     "v_cmp_gt_u32_e32 vcc, %[cnt], %[t0]\n\t"                                            \
     "v_cmp_gt_u32_e64 %[fresh], %[wmax], %[ckey]\n\t"                                     \
@@ -433,6 +469,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "s_cmp_ge_u32 %[nh], %[maxh]\n\t"                                 // debugging: leave after maxh hops, the C++ loop goes on from here
         "s_cbranch_scc1 99f\n\t"
 #endif
+        HNSW_PROBE(0)
         // pop: the first unexpanded member of W (pop_min, :565) and its flag
         "v_and_b32_e32 %[t0], 1, %[l0]\n\t"
         "v_and_b32_e32 %[t1], 1, %[l1]\n\t"
@@ -461,6 +498,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "s_sub_u32 %[klo], %[klo], 1\n"                                       // node id
         HNSW_HOP_ADJACENCY
         HNSW_HOP_FILTER_ISSUE
+        HNSW_PROBE(1)
 #if HNSW_ASM_PREFETCH
         // the next nearest unexpanded member of W: its row is fetched now, beside this hop's vectors
         "s_mov_b32 %[pref], -1\n\t"
@@ -477,9 +515,12 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         HNSW_HOP_PREFETCH_LOAD
 #endif
         HNSW_HOP_FILTER_COMPACT
+        HNSW_PROBE(2)
         HNSW_HOP_ROUNDS
         "50:\n\t"
+        HNSW_PROBE(3)
         HNSW_INSERT_LOOP
+        HNSW_PROBE(4)
         "s_cmp_lt_u32 %[base], %[cnt]\n\t"
         "s_cbranch_scc1 20b\n\t"
         "s_branch 1b\n"
@@ -504,7 +545,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
 #ifdef HNSW_ASM_DEBUG
           , [maxh] "s"(maxhops)
 #endif
-        : "vcc", "scc", "m0", "memory");
+        : "vcc", "scc", "m0", "memory" HNSW_PROBE_CLOBBER);
     w.wmax = wmax; w.ovf_cnt = (int)oc;
     n_dist = nd; n_hops = nh; status = st;
 }
@@ -588,14 +629,13 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
 #define HNSW_INSERT_LOOP4                                                                                                \
     "10:\n\t"                                                                                                            \
     "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 19f\n\t"                                                                                             \
+    "s_cbranch_scc1 19f\n"                                                                                               \
+    "110:\n\t"                                                                                                           \
     "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                   \
     "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
     "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
     "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
     "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
-    "s_lshl_b32 %[klo], %[klo], 1\n\t"                                                                                   \
-    "s_add_u32 %[klo], %[klo], 2\n\t"                                     /* low half: (id + 1) << 1, unexpanded */      \
     "s_cmp_lt_u32 %[mx2], %[kd]\n\t"                                      /* the rank's slot, from the slots' maxima */  \
     "s_cbranch_scc1 83f\n\t"                                                                                             \
     "s_cmp_lt_u32 %[mx1], %[kd]\n\t"                                                                                     \
@@ -648,7 +688,9 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
     "18:\n\t"                                                                                                            \
     "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
-    "s_branch 10b\n"                                                                                                     \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 110b\n\t"                                             /* the next accepted candidate */              \
+    "s_branch 19f\n"                                                                                                     \
     /* rare: a member of W at exactly this distance: rank over all four slots, ids decide; the node itself in W: ignored */ \
     "14:\n\t"                                                                                                            \
     "s_mov_b32 %[P], 0\n\t"                                                                                              \
@@ -769,7 +811,8 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
 #define HNSW_INSERT_LOOP1                                                                                                \
     "10:\n\t"                                                                                                            \
     "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 19f\n\t"                                                                                             \
+    "s_cbranch_scc1 19f\n"                                                                                               \
+    "110:\n\t"                                                                                                           \
     "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                   \
     "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
     "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
@@ -778,8 +821,6 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                          \
     "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                             \
     "s_bcnt1_i32_b64 %[p], vcc\n\t"                                       /* rank = keys at a smaller distance */       \
-    "s_lshl_b32 %[klo], %[klo], 1\n\t"                                                                                   \
-    "s_add_u32 %[klo], %[klo], 2\n\t"                                     /* low half: (id + 1) << 1, unexpanded */      \
     "s_cmp_lg_u64 %[um0], 0\n\t"                                                                                         \
     "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
     "11:\n\t"                                                                                                            \
@@ -794,7 +835,9 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
     "18:\n\t"                                                                                                            \
     "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
-    "s_branch 10b\n"                                                                                                     \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 110b\n\t"                                             /* the next accepted candidate */              \
+    "s_branch 19f\n"                                                                                                     \
     "14:\n\t"                                                                                                            \
     "v_cmp_gt_u32_e32 vcc, %[klo], %[l0]\n\t"                                                                            \
     "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
