@@ -55,6 +55,11 @@ namespace hnsw_dev {
 #define HNSW_PROBE(K)
 #define HNSW_PROBE_CLOBBER
 #endif
+#ifdef HNSW_ASM_STATS      /* measurement build: status bits 8.. count the hops whose adjacency row had been fetched speculatively */
+#define HNSW_ASM_COUNT_HIT "s_add_u32 %[st], %[st], 0x100\n\t"
+#else
+#define HNSW_ASM_COUNT_HIT
+#endif
 #ifndef HNSW_ASM_PREFETCH
 #define HNSW_ASM_PREFETCH 1
 #endif
@@ -72,6 +77,10 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_ID_READ(B, ID, SH)                                                          \
     "s_add_u32 %[tmp], %[sx], 4*" #B "\n\t"                                              \
     "v_lshl_add_u32 " ID ", %[r4], " #SH ", %[tmp]\n\t"                                  \
+    "v_min_u32 " ID ", %[lastad], " ID "\n\t"                                            \
+    "ds_read_b32 " ID ", " ID "\n\t"
+#define HNSW_ID_READ0(ID, SH)                                                            \
+    "v_lshl_add_u32 " ID ", %[r4], " #SH ", %[sx]\n\t"                                   \
     "v_min_u32 " ID ", %[lastad], " ID "\n\t"                                            \
     "ds_read_b32 " ID ", " ID "\n\t"
 // row address (one 64-bit multiply-add) and the row's two dwords per lane
@@ -102,6 +111,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
     "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
     "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
+    "v_readlane_b32 %[nw], %[h1], 62\n\t"                                                                                \
     "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                           \
     "v_cmp_eq_u32_e64 %[um1], %[kd], %[h1]\n\t"                                                                           \
     "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                             \
@@ -112,7 +122,6 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_or_b64 vcc, %[um0], %[um1]\n\t"                                                                                     \
     "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
     "11:\n\t"                                                                                                            \
-    "v_readlane_b32 %[nw], %[h1], 62\n\t"                                                                                \
     "s_cmp_eq_u32 %[p], 127\n\t"                                                                                         \
     "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                               /* the new max(W).d */                         \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
@@ -225,7 +234,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_waitcnt vmcnt(0)\n\t"                                                                                              \
         "s_branch 6f\n"                                                                                                       \
         "5:\n\t"                                                                                                              \
-        "s_add_u32 %[st], %[st], 0x100\n\t"                                                                                   \
+        HNSW_ASM_COUNT_HIT                                                                                   \
         "s_waitcnt vmcnt(0)\n\t"                                                                                              \
         "v_mov_b32_e32 %[nb], %[pnb]\n"                                                                                       
 
@@ -260,22 +269,20 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_mov_b64 exec, -1\n\t"                                                       \
         "s_add_u32 %[nd], %[nd], %[cnt]\n\t"                                           \
         "s_mov_b32 %[base], 0\n\t"                                                     \
-        "s_lshl_b32 %[lastad], %[cnt], 2\n\t"                                          \
-        "s_add_u32 %[lastad], %[lastad], %[cand]\n\t"                                  \
+        "s_lshl2_add_u32 %[lastad], %[cnt], %[cand]\n\t"                               \
         "s_sub_u32 %[lastad], %[lastad], 4\n"                                          
 
 // labels 20 / 30 / 40: one round of 4 / 8 / 16 rows -> ckey, cid, the accept mask in `fresh`, base advanced; falls through to 50
 #define HNSW_HOP_ROUNDS \
         "20:\n\t"                                                                                                                     \
         "s_sub_u32 %[tmp], %[cnt], %[base]\n\t"                                                                                       \
-        "s_lshl_b32 %[sx], %[base], 2\n\t"                                                                                            \
-        "s_add_u32 %[sx], %[sx], %[cand]\n\t"                                                                                         \
+        "s_lshl2_add_u32 %[sx], %[base], %[cand]\n\t"                                                                                 \
         "s_cmp_gt_u32 %[tmp], 8\n\t"                                                                                                  \
         "s_cbranch_scc1 40f\n\t"                                                                                                      \
         "s_cmp_gt_u32 %[tmp], 4\n\t"                                                                                                  \
         "s_cbranch_scc1 30f\n\t"                                                                                                      \
   /* ---- 4 rows: one batch */                                                                                                        \
-        HNSW_ID_READ(0, "%[id0]", 0)                                                                                                  \
+        HNSW_ID_READ0("%[id0]", 0)                                                                                                  \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
         HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
         "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
@@ -298,7 +305,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_branch 50f\n"                                                                                                              \
   /* ---- 8 rows: two batches */                                                                                                      \
         "30:\n\t"                                                                                                                     \
-        HNSW_ID_READ(0, "%[id0]", 1)                                                                                                  \
+        HNSW_ID_READ0("%[id0]", 1)                                                                                                  \
         HNSW_ID_READ(1, "%[id1]", 1)                                                                                                  \
         "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
         HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
@@ -329,7 +336,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_branch 50f\n"                                                                                                              \
   /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
         "40:\n\t"                                                                                                                     \
-        HNSW_ID_READ(0, "%[id0]", 2)                                                                                                  \
+        HNSW_ID_READ0("%[id0]", 2)                                                                                                  \
         HNSW_ID_READ(1, "%[id1]", 2)                                                                                                  \
         HNSW_ID_READ(2, "%[id2]", 2)                                                                                                  \
         HNSW_ID_READ(3, "%[id3]", 2)                                                                                                  \
@@ -636,6 +643,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
     "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
     "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
+    "v_readlane_b32 %[nw], %[h3], 62\n\t"                                                                                \
     "s_cmp_lt_u32 %[mx2], %[kd]\n\t"                                      /* the rank's slot, from the slots' maxima */  \
     "s_cbranch_scc1 83f\n\t"                                                                                             \
     "s_cmp_lt_u32 %[mx1], %[kd]\n\t"                                                                                     \
@@ -647,7 +655,6 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     HNSW_RANK_IN_SLOT("82", "%[h2]", 128)                                                                                \
     HNSW_RANK_IN_SLOT("83", "%[h3]", 192)                                                                                \
     "11:\n\t"                                                                                                            \
-    "v_readlane_b32 %[nw], %[h3], 62\n\t"                                                                                \
     "s_cmp_eq_u32 %[P], 255\n\t"                                                                                         \
     "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                               /* the new max(W).d */                         \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
@@ -818,13 +825,13 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
     "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
     "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
+    "v_readlane_b32 %[nw], %[h0], 62\n\t"                                                                                \
     "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                          \
     "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                             \
     "s_bcnt1_i32_b64 %[p], vcc\n\t"                                       /* rank = keys at a smaller distance */       \
     "s_cmp_lg_u64 %[um0], 0\n\t"                                                                                         \
     "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
     "11:\n\t"                                                                                                            \
-    "v_readlane_b32 %[nw], %[h0], 62\n\t"                                                                                \
     "s_cmp_eq_u32 %[p], 63\n\t"                                                                                          \
     "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                               /* the new max(W).d */                         \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
