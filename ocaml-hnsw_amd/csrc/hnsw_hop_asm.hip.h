@@ -71,9 +71,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_DPP_ALL " row_mask:0xf bank_mask:0xf"
 #define HNSW_DPP_BC " row_mask:0xf bank_mask:0xf bound_ctrl:1"
 
-// ids of batch B of a round -> LDS read.  Group r reads candidate base + NB r + B, clamped to the last candidate of the
-// list (a group past the end re-reads a row that is in flight anyway; its key is masked out below).
-//   sx = cand + 4 base; lastad = cand + 4 (cnt - 1); r4 = 4 r per lane; SH = log2 NB
+// ids of batch B of a round -> LDS read.  Group r reads the round's candidate NB r + B, clamped to the last candidate of
+// the list (a group past the end re-reads a row that is in flight anyway; its key is masked out below).
+//   sx = address of the round's first candidate; lastad = address of the list's last; r4 = 4 r per lane; SH = log2 NB
 #define HNSW_ID_READ(B, ID, SH)                                                          \
     "s_add_u32 %[tmp], %[sx], 4*" #B "\n\t"                                              \
     "v_lshl_add_u32 " ID ", %[r4], " #SH ", %[tmp]\n\t"                                  \
@@ -94,7 +94,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 // as its accumulator is fine), so the combines come after other batches' dot products or after an s_nop.
 #define HNSW_DOTS(DA, DB, TA)                                                            \
     "v_dot4_u32_u8 " TA ", " DA ", %[qb0], 0\n\t"                                        \
-    "v_dot4_u32_u8 " DA ", " DA ", " DA ", 0\n\t"                                        \
+    "v_dot4_u32_u8 " DA ", " DA ", " DA ", %[q2v]\n\t"                                     \
     "v_dot4_u32_u8 " TA ", " DB ", %[qb1], " TA "\n\t"                                   \
     "v_dot4_u32_u8 " DA ", " DB ", " DB ", " DA "\n\t"
 #define HNSW_COMBINE(DA, TA) "v_mad_i32_i24 " DA ", " TA ", -2, " DA "\n\t"
@@ -122,23 +122,25 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_or_b64 vcc, %[um0], %[um1]\n\t"                                                                                     \
     "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
     "11:\n\t"                                                                                                            \
-    "s_cmp_eq_u32 %[p], 127\n\t"                                                                                         \
-    "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                               /* the new max(W).d */                         \
+    "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
     "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */      \
     "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
     "12:\n\t"                                                                                                            \
     "s_cmp_lt_u32 %[p], 64\n\t"                                                                                          \
     "s_cbranch_scc1 13f\n\t"                                                                                             \
-    "s_sub_u32 %[p], %[p], 64\n\t"                                        /* rank in the upper slot */                   \
-    "s_lshl_b64 exec, -1, %[p]\n\t"                                                                                      \
+    "s_lshl_b64 exec, -1, %[p]\n\t"                                       /* upper slot: shift count, lane select = bits 5:0 */ \
     "v_mov_b32_dpp %[h1], %[h1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
     "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
     "s_mov_b64 exec, -1\n\t"                                                                                             \
     "s_mov_b32 m0, %[p]\n\t"                                                                                             \
     "v_writelane_b32 %[h1], %[kd], m0\n\t"                                                                               \
     "v_writelane_b32 %[l1], %[klo], m0\n\t"                                                                              \
-    "s_branch 17f\n"                                                                                                     \
+    "s_mov_b32 %[wmax], %[nw]\n\t"                                                                                       \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 110b\n\t"                                                                                            \
+    "s_branch 19f\n"                                                                                                     \
     "13:\n\t"                                                             /* rank in the lower slot */                   \
     "v_readlane_b32 %[sx], %[h0], 63\n\t"                                                                                \
     "v_readlane_b32 %[tmp], %[l0], 63\n\t"                                                                                \
@@ -207,12 +209,14 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_branch 12b\n"                                                                                                     \
     "19:\n\t"
 
-// accept ballot of a round: candidate index of this lane = base + CO (per-lane constant; a lane that holds no
+// accept ballot of a round: candidate index of this lane within the round = CO (per-lane constant; a lane that holds no
 // candidate's sum has 0x1000 there), valid below cnt, and below the current max(W) (lib/ohnsw.ml:574)
-#define HNSW_ACCEPT(CO)                                                                  \
+// (cnt = candidates not yet evaluated when the round starts).  The first half does not depend on the sums: it fills the
+// two wait states a DPP read of a just-written register needs anyway.
+#define HNSW_ACCEPT_EARLY(CO)                                                            \
     "v_lshl_add_u32 %[cid], %[cid], 1, 2\n\t"       /* ids -> low key halves: (id + 1) << 1, unexpanded */  \
-    "v_add_u32_e32 %[t0], %[base], " CO "\n\t"                                           \
-    "v_cmp_gt_u32_e32 vcc, %[cnt], %[t0]\n\t"                                            \
+    "v_cmp_gt_u32_e32 vcc, %[cnt], " CO "\n\t"
+#define HNSW_ACCEPT_LATE                                                                 \
     "v_cmp_gt_u32_e64 %[fresh], %[wmax], %[ckey]\n\t"                                     \
     "s_and_b64 %[fresh], %[fresh], vcc\n\t"
 
@@ -268,18 +272,23 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "ds_write_b32 %[t0], %[nb]\n\t"                                                \
         "s_mov_b64 exec, -1\n\t"                                                       \
         "s_add_u32 %[nd], %[nd], %[cnt]\n\t"                                           \
-        "s_mov_b32 %[base], 0\n\t"                                                     \
         "s_lshl2_add_u32 %[lastad], %[cnt], %[cand]\n\t"                               \
-        "s_sub_u32 %[lastad], %[lastad], 4\n"                                          
+        "s_sub_u32 %[lastad], %[lastad], 4\n\t"                                        \
+        "s_mov_b32 %[sx], %[cand]\n"                                                   
 
-// labels 20 / 30 / 40: one round of 4 / 8 / 16 rows -> ckey, cid, the accept mask in `fresh`, base advanced; falls through to 50
+// a list longer than one round (rare): the next candidate's address from what is left, then the next round
+#define HNSW_HOP_NEXT_ROUND \
+        "s_lshl_b32 %[tmp], %[cnt], 2\n\t"         \
+        "s_sub_u32 %[sx], %[lastad], %[tmp]\n\t"   \
+        "s_add_u32 %[sx], %[sx], 4\n\t"            \
+        "s_branch 20b\n"
+
+// labels 20 / 30 / 40: one round of 4 / 8 / 16 rows -> ckey, cid, the accept mask in `fresh`, cnt reduced by the round's size; falls through to 50
 #define HNSW_HOP_ROUNDS \
         "20:\n\t"                                                                                                                     \
-        "s_sub_u32 %[tmp], %[cnt], %[base]\n\t"                                                                                       \
-        "s_lshl2_add_u32 %[sx], %[base], %[cand]\n\t"                                                                                 \
-        "s_cmp_gt_u32 %[tmp], 8\n\t"                                                                                                  \
+        "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
         "s_cbranch_scc1 40f\n\t"                                                                                                      \
-        "s_cmp_gt_u32 %[tmp], 4\n\t"                                                                                                  \
+        "s_cmp_gt_u32 %[cnt], 4\n\t"                                                                                                  \
         "s_cbranch_scc1 30f\n\t"                                                                                                      \
   /* ---- 4 rows: one batch */                                                                                                        \
         HNSW_ID_READ0("%[id0]", 0)                                                                                                  \
@@ -290,7 +299,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
         "s_nop 2\n\t"                                                                                                                 \
         HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
-        "s_nop 1\n\t"                                                                                                                 \
+        HNSW_ACCEPT_EARLY("%[co1]")                                                                                                   \
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:4" HNSW_DPP_BC "\n\t"                                                              \
@@ -298,10 +307,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:2" HNSW_DPP_BC "\n\t"                                                              \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:1" HNSW_DPP_BC "\n\t"                                                              \
-        "v_add_u32_e32 %[d0], %[q2], %[d0]\n\t"                                                                                       \
         "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"                                                                                        \
-        HNSW_ACCEPT("%[co1]")                                                                                                         \
-        "s_add_u32 %[base], %[base], 4\n\t"                                                                                           \
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 4\n\t"                                                                                           \
         "s_branch 50f\n"                                                                                                              \
   /* ---- 8 rows: two batches */                                                                                                      \
         "30:\n\t"                                                                                                                     \
@@ -321,7 +329,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         HNSW_COMBINE("%[d2]", "%[tb]")                                                                                                \
         "v_cndmask_b32_e64 %[ta], %[d0], %[d2], %[b3m]\n\t"  /* keep: the sum this half of the group is for */                        \
         "v_cndmask_b32_e64 %[tb], %[d2], %[d0], %[b3m]\n\t"  /* give: the other half's */                                             \
-        "s_nop 1\n\t"                                                                                                                 \
+        HNSW_ACCEPT_EARLY("%[co2]")                                                                                                               \
         "v_add_u32_dpp %[ta], %[tb], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[ta], %[ta], %[ta] row_half_mirror" HNSW_DPP_BC "\n\t"                                                        \
@@ -329,10 +337,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"                                                    \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
-        "v_add_u32_e32 %[ta], %[q2], %[ta]\n\t"                                                                                       \
         "v_cvt_f32_i32_e32 %[ckey], %[ta]\n\t"                                                                                        \
-        HNSW_ACCEPT("%[co2]")                                                                                                         \
-        "s_add_u32 %[base], %[base], 8\n\t"                                                                                           \
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 8\n\t"                                                                                           \
         "s_branch 50f\n"                                                                                                              \
   /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
         "40:\n\t"                                                                                                                     \
@@ -374,16 +381,15 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[tb], %[d3], %[tb] row_ror:8" HNSW_DPP_BC "\n\t"  /* candidates 1 | 3 */                                      \
         "v_cndmask_b32_e64 %[d0], %[ta], %[tb], %[b2m]\n\t"                                                                           \
         "v_cndmask_b32_e64 %[d1], %[tb], %[ta], %[b2m]\n\t"                                                                           \
-        "s_nop 1\n\t"                                                                                                                 \
+        HNSW_ACCEPT_EARLY("%[co4]")                                                                                                                \
         "v_add_u32_dpp %[d0], %[d1], %[d0] row_half_mirror" HNSW_DPP_BC "\n\t"                                                        \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"                                                    \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
-        "v_add_u32_e32 %[d0], %[q2], %[d0]\n\t"                                                                                       \
         "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"                                                                                        \
-        HNSW_ACCEPT("%[co4]")                                                                                                         \
-        "s_add_u32 %[base], %[base], 16\n"                                                                                            
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 16\n"                                                                                            
 
 // labels 90 / 99: no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568), else done
 #define HNSW_HOP_TAIL \
@@ -418,6 +424,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
         "s_nop 1\n\t"  /* gfx950: a vector write of vcc, then 2 wait states before a vector read */    \
         "v_cndmask_b32_e32 %[co1], %[t1], %[co1], vcc\n\t"                                             \
+        "v_mov_b32_e32 %[q2v], %[q2]\n\t"  /* q.q, once per 16 lanes: the accumulator x.x starts from */ \
+        "v_cndmask_b32_e32 %[q2v], 0, %[q2v], vcc\n\t"                                                 \
         "v_and_b32_e32 %[t0], 7, %[lane]\n\t"                                                          \
         "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
         "s_nop 1\n\t"                                                                                  \
@@ -459,10 +467,10 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
     uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt);
     // temporaries
-    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
     uint64_t ad0, ad1, ad2, ad3;
     uint64_t um0, um1, fresh, b3m, b2m;   // um0 / um1 double as the insertion's equality masks, fresh as the round's accept mask
-    uint32_t pref, cnt, base, sx, lastad, i, kd, klo, p, t, nw, tmp;   // klo doubles as the hop's node, sx / tmp as the shift's carries
+    uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;   // klo doubles as the hop's node, sx / tmp as the shift's carries
     asm volatile(
         HNSW_HOP_CONSTANTS
         "s_mov_b32 %[pref], -1\n"
@@ -528,22 +536,22 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         HNSW_PROBE(3)
         HNSW_INSERT_LOOP
         HNSW_PROBE(4)
-        "s_cmp_lt_u32 %[base], %[cnt]\n\t"
-        "s_cbranch_scc1 20b\n\t"
-        "s_branch 1b\n"
+        "s_cmp_gt_i32 %[cnt], 0\n\t"
+        "s_cbranch_scc0 1b\n\t"
+        HNSW_HOP_NEXT_ROUND
         // ---- no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568)
         HNSW_HOP_TAIL
         : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
-          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4),
+          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4), [q2v] "=&v"(q2v),
           [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
           [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
           [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
           [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
           [um0] "=&s"(um0), [um1] "=&s"(um1), [fresh] "=&s"(fresh),
           [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
-          [pref] "=&s"(pref), [cnt] "=&s"(cnt), [base] "=&s"(base),
+          [pref] "=&s"(pref), [cnt] "=&s"(cnt),
           [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t),
           [nw] "=&s"(nw), [tmp] "=&s"(tmp)
         : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
@@ -655,8 +663,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     HNSW_RANK_IN_SLOT("82", "%[h2]", 128)                                                                                \
     HNSW_RANK_IN_SLOT("83", "%[h3]", 192)                                                                                \
     "11:\n\t"                                                                                                            \
-    "s_cmp_eq_u32 %[P], 255\n\t"                                                                                         \
-    "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                               /* the new max(W).d */                         \
+    "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
     "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */      \
     "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
@@ -746,10 +753,10 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     const uint32_t q2 = (uint32_t)uniform(cx.q2);
     uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
     uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt);
-    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
     uint64_t ad0, ad1, ad2, ad3;
     uint64_t um0, um1, um2, um3, fresh, b3m, b2m;
-    uint32_t pref, cnt, base, sx, lastad, i, kd, klo, p, P, t, nw, tmp, mx0, mx1, mx2;
+    uint32_t pref, cnt, sx, lastad, i, kd, klo, p, P, t, nw, tmp, mx0, mx1, mx2;
     asm volatile(
         HNSW_HOP_CONSTANTS
         "v_readlane_b32 %[mx0], %[h0], 63\n\t"                            // the slots' maxima (distance halves)
@@ -788,22 +795,22 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
         HNSW_HOP_ROUNDS
         "50:\n\t"
         HNSW_INSERT_LOOP4
-        "s_cmp_lt_u32 %[base], %[cnt]\n\t"
-        "s_cbranch_scc1 20b\n\t"
-        "s_branch 1b\n"
+        "s_cmp_gt_i32 %[cnt], 0\n\t"
+        "s_cbranch_scc0 1b\n\t"
+        HNSW_HOP_NEXT_ROUND
         HNSW_HOP_TAIL
         : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [h2] "+&v"(w.hi[2]), [h3] "+&v"(w.hi[3]),
           [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]), [l2] "+&v"(w.lo[2]), [l3] "+&v"(w.lo[3]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
-          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4),
+          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4), [q2v] "=&v"(q2v),
           [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
           [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
           [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
           [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
           [um0] "=&s"(um0), [um1] "=&s"(um1), [um2] "=&s"(um2), [um3] "=&s"(um3), [fresh] "=&s"(fresh),
           [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
-          [pref] "=&s"(pref), [cnt] "=&s"(cnt), [base] "=&s"(base),
+          [pref] "=&s"(pref), [cnt] "=&s"(cnt),
           [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [P] "=&s"(P), [t] "=&s"(t),
           [nw] "=&s"(nw), [tmp] "=&s"(tmp), [mx0] "=&s"(mx0), [mx1] "=&s"(mx1), [mx2] "=&s"(mx2)
         : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
@@ -832,8 +839,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "s_cmp_lg_u64 %[um0], 0\n\t"                                                                                         \
     "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
     "11:\n\t"                                                                                                            \
-    "s_cmp_eq_u32 %[p], 63\n\t"                                                                                          \
-    "s_cselect_b32 %[nw], %[kd], %[nw]\n\t"                               /* the new max(W).d */                         \
+    "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
     "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */      \
     "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
@@ -891,10 +897,10 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
     const uint32_t q2 = (uint32_t)uniform(cx.q2);
     uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
     uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt);
-    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
     uint64_t ad0, ad1, ad2, ad3;
     uint64_t um0, um1, fresh, b3m, b2m;    // um1: the visited filter's second compare only
-    uint32_t pref, cnt, base, sx, lastad, i, kd, klo, p, t, nw, tmp;
+    uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;
     asm volatile(
         HNSW_HOP_CONSTANTS
         "s_mov_b32 %[pref], -1\n"
@@ -916,21 +922,21 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
         HNSW_HOP_ROUNDS
         "50:\n\t"
         HNSW_INSERT_LOOP1
-        "s_cmp_lt_u32 %[base], %[cnt]\n\t"
-        "s_cbranch_scc1 20b\n\t"
-        "s_branch 1b\n"
+        "s_cmp_gt_i32 %[cnt], 0\n\t"
+        "s_cbranch_scc0 1b\n\t"
+        HNSW_HOP_NEXT_ROUND
         HNSW_HOP_TAIL
         : [h0] "+&v"(w.hi[0]), [l0] "+&v"(w.lo[0]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
-          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4),
+          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4), [q2v] "=&v"(q2v),
           [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
           [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
           [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
           [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
           [um0] "=&s"(um0), [um1] "=&s"(um1), [fresh] "=&s"(fresh),
           [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
-          [pref] "=&s"(pref), [cnt] "=&s"(cnt), [base] "=&s"(base),
+          [pref] "=&s"(pref), [cnt] "=&s"(cnt),
           [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t),
           [nw] "=&s"(nw), [tmp] "=&s"(tmp)
         : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
