@@ -165,20 +165,19 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     /* rare: distance tie inside W.  rank += members at this distance with a smaller id; a member with this id (flag */ \
     /* bit either way) means the node is already in W (a re-evaluation the visited cache forgot): ignored */            \
     "14:\n\t"                                                                                                            \
-    "v_cmp_gt_u32_e32 vcc, %[klo], %[l0]\n\t"                                                                            \
+    "v_and_b32_e32 %[t0], 0x7fffffff, %[l0]\n\t"                         /* id + 1 without the flag */                  \
+    "v_and_b32_e32 %[t1], 0x7fffffff, %[l1]\n\t"                                                                         \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                            \
     "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
     "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                     \
     "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                     \
-    "v_cmp_gt_u32_e32 vcc, %[klo], %[l1]\n\t"                                                                            \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[t1]\n\t"                                                                            \
     "s_and_b64 vcc, vcc, %[um1]\n\t"                                                                                     \
     "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                     \
     "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                     \
-    "s_or_b32 %[t], %[klo], 1\n\t"                                                                                       \
-    "v_or_b32_e32 %[t0], 1, %[l0]\n\t"                                                                                   \
-    "v_or_b32_e32 %[t1], 1, %[l1]\n\t"                                                                                   \
-    "v_cmp_eq_u32_e32 vcc, %[t], %[t0]\n\t"                                                                              \
+    "v_cmp_eq_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                            \
     "s_and_b64 %[um0], vcc, %[um0]\n\t"                                                                                    \
-    "v_cmp_eq_u32_e32 vcc, %[t], %[t1]\n\t"                                                                              \
+    "v_cmp_eq_u32_e32 vcc, %[klo], %[t1]\n\t"                                                                            \
     "s_and_b64 %[um1], vcc, %[um1]\n\t"                                                                                    \
     "s_or_b64 %[um0], %[um0], %[um1]\n\t"                                                                                   \
     "s_cbranch_scc1 18b\n\t"                                              /* already in W */                             \
@@ -189,11 +188,10 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                       \
     "s_cbranch_scc1 12b\n\t"                                                                                             \
     "v_readlane_b32 %[t], %[l1], 63\n\t"                                                                                 \
-    "s_bitcmp1_b32 %[t], 0\n\t"                                                                                          \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                         \
     "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
     "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
     "s_cbranch_scc1 16f\n\t"                                                                                             \
-    "s_lshr_b32 %[t], %[t], 1\n\t"                                                                                       \
     "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
     "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                                                                    \
     "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                                                              \
@@ -214,7 +212,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 // (cnt = candidates not yet evaluated when the round starts).  The first half does not depend on the sums: it fills the
 // two wait states a DPP read of a just-written register needs anyway.
 #define HNSW_ACCEPT_EARLY(CO)                                                            \
-    "v_lshl_add_u32 %[cid], %[cid], 1, 2\n\t"       /* ids -> low key halves: (id + 1) << 1, unexpanded */  \
+    "v_add_u32_e32 %[cid], 1, %[cid]\n\t"           /* ids -> low key halves: id + 1, unexpanded */          \
     "v_cmp_gt_u32_e32 vcc, %[cnt], " CO "\n\t"
 #define HNSW_ACCEPT_LATE                                                                 \
     "v_cmp_gt_u32_e64 %[fresh], %[wmax], %[ckey]\n\t"                                     \
@@ -444,7 +442,6 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 // requested into pnb beside this hop's vectors
 #define HNSW_HOP_PREFETCH_LOAD \
         "8:\n\t"                                                  \
-        "s_lshr_b32 %[pref], %[pref], 1\n\t"                      \
         "s_sub_u32 %[pref], %[pref], 1\n\t"                       \
         "s_mul_i32 %[tmp], %[pref], %[rowb]\n\t"                  \
         "v_add_u32_e32 %[t1], %[tmp], %[lane4]\n\t"               \
@@ -472,6 +469,10 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     uint64_t um0, um1, fresh, b3m, b2m;   // um0 / um1 double as the insertion's equality masks, fresh as the round's accept mask
     uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;   // klo doubles as the hop's node, sx / tmp as the shift's carries
     asm volatile(
+        // low key halves inside the loop: id + 1 with the expanded flag in bit 31 (a rotation of the (id + 1) << 1 | flag the
+        // rest of the kernel keeps): the unexpanded members are the non-negative ones, a node id is one subtraction away
+        "v_alignbit_b32 %[l0], %[l0], %[l0], 1\n\t"
+        "v_alignbit_b32 %[l1], %[l1], %[l1], 1\n\t"
         HNSW_HOP_CONSTANTS
         "s_mov_b32 %[pref], -1\n"
         // ================================ one hop ================================
@@ -486,17 +487,15 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
 #endif
         HNSW_PROBE(0)
         // pop: the first unexpanded member of W (pop_min, :565) and its flag
-        "v_and_b32_e32 %[t0], 1, %[l0]\n\t"
-        "v_and_b32_e32 %[t1], 1, %[l1]\n\t"
-        "v_cmp_eq_u32_e64 %[um0], 0, %[t0]\n\t"
-        "v_cmp_eq_u32_e64 %[um1], 0, %[t1]\n\t"
+        "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n\t"
+        "v_cmp_lt_i32_e64 %[um1], -1, %[l1]\n\t"
         "s_cmp_eq_u64 %[um0], 0\n\t"
         "s_cbranch_scc1 2f\n\t"
         "s_ff1_i32_b64 %[i], %[um0]\n\t"
         "v_readlane_b32 %[kd], %[l0], %[i]\n\t"
         "s_bitset0_b64 %[um0], %[i]\n\t"
         "s_mov_b32 m0, %[i]\n\t"
-        "s_or_b32 %[t], %[kd], 1\n\t"
+        "s_or_b32 %[t], %[kd], 0x80000000\n\t"
         "v_writelane_b32 %[l0], %[t], m0\n\t"
         "s_branch 3f\n"
         "2:\n\t"
@@ -506,11 +505,10 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "v_readlane_b32 %[kd], %[l1], %[i]\n\t"
         "s_bitset0_b64 %[um1], %[i]\n\t"
         "s_mov_b32 m0, %[i]\n\t"
-        "s_or_b32 %[t], %[kd], 1\n\t"
+        "s_or_b32 %[t], %[kd], 0x80000000\n\t"
         "v_writelane_b32 %[l1], %[t], m0\n"
         "3:\n\t"
-        "s_lshr_b32 %[klo], %[kd], 1\n\t"
-        "s_sub_u32 %[klo], %[klo], 1\n"                                       // node id
+        "s_sub_u32 %[klo], %[kd], 1\n"                                       // node id
         HNSW_HOP_ADJACENCY
         HNSW_HOP_FILTER_ISSUE
         HNSW_PROBE(1)
@@ -541,6 +539,9 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         HNSW_HOP_NEXT_ROUND
         // ---- no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568)
         HNSW_HOP_TAIL
+        // back to the flag-in-bit-0 form
+        "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
+        "\n\tv_alignbit_b32 %[l1], %[l1], %[l1], 31"
         : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
@@ -587,7 +588,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_readlane_b32 %[kd], " LS ", %[i]\n\t"                        \
     "s_bitset0_b64 " UM ", %[i]\n\t"                                \
     "s_mov_b32 m0, %[i]\n\t"                                        \
-    "s_or_b32 %[t], %[kd], 1\n\t"                                   \
+    "s_or_b32 %[t], %[kd], 0x80000000\n\t"                          \
     "v_writelane_b32 " LS ", %[t], m0\n\t"                          \
     "s_branch 3f\n"
 // the same walk for the speculative row fetch: the first remaining unexpanded member's low half -> pref, then 8f; none: 9f
@@ -632,12 +633,12 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "s_bcnt1_i32_b64 %[t], vcc\n\t"                                 \
     "s_add_u32 %[P], %[P], %[t]\n\t"                                \
     "v_cmp_eq_u32_e64 %[um0], %[kd], " HS "\n\t"                    \
-    "v_cmp_gt_u32_e32 vcc, %[klo], " LS "\n\t"                      \
+    "v_and_b32_e32 %[t0], 0x7fffffff, " LS "\n\t"                   \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[t0]\n\t"                       \
     "s_and_b64 vcc, vcc, %[um0]\n\t"                                \
     "s_bcnt1_i32_b64 %[t], vcc\n\t"                                 \
     "s_add_u32 %[P], %[P], %[t]\n\t"                                \
-    "v_or_b32_e32 %[t0], 1, " LS "\n\t"                             \
-    "v_cmp_eq_u32_e32 vcc, %[p], %[t0]\n\t"                         \
+    "v_cmp_eq_u32_e32 vcc, %[klo], %[t0]\n\t"                       \
     "s_and_b64 vcc, vcc, %[um0]\n\t"                                \
     "s_or_b64 %[um1], %[um1], vcc\n\t"
 
@@ -709,7 +710,6 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "14:\n\t"                                                                                                            \
     "s_mov_b32 %[P], 0\n\t"                                                                                              \
     "s_mov_b64 %[um1], 0\n\t"                                                                                            \
-    "s_or_b32 %[p], %[klo], 1\n\t"                                                                                       \
     HNSW_RANK_GENERAL_SLOT("%[h0]", "%[l0]")                                                                             \
     HNSW_RANK_GENERAL_SLOT("%[h1]", "%[l1]")                                                                             \
     HNSW_RANK_GENERAL_SLOT("%[h2]", "%[l2]")                                                                             \
@@ -722,11 +722,10 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                       \
     "s_cbranch_scc1 12b\n\t"                                                                                             \
     "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                 \
-    "s_bitcmp1_b32 %[t], 0\n\t"                                                                                          \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                         \
     "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
     "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
     "s_cbranch_scc1 16f\n\t"                                                                                             \
-    "s_lshr_b32 %[t], %[t], 1\n\t"                                                                                       \
     "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
     "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                                                                    \
     "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                                                              \
@@ -758,6 +757,12 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     uint64_t um0, um1, um2, um3, fresh, b3m, b2m;
     uint32_t pref, cnt, sx, lastad, i, kd, klo, p, P, t, nw, tmp, mx0, mx1, mx2;
     asm volatile(
+        // low key halves inside the loop: id + 1 with the expanded flag in bit 31 (a rotation of the (id + 1) << 1 | flag the
+        // rest of the kernel keeps): the unexpanded members are the non-negative ones, a node id is one subtraction away
+        "v_alignbit_b32 %[l0], %[l0], %[l0], 1\n\t"
+        "v_alignbit_b32 %[l1], %[l1], %[l1], 1\n\t"
+        "v_alignbit_b32 %[l2], %[l2], %[l2], 1\n\t"
+        "v_alignbit_b32 %[l3], %[l3], %[l3], 1\n\t"
         HNSW_HOP_CONSTANTS
         "v_readlane_b32 %[mx0], %[h0], 63\n\t"                            // the slots' maxima (distance halves)
         "v_readlane_b32 %[mx1], %[h1], 63\n\t"
@@ -766,21 +771,16 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
         // ================================ one hop ================================
         "1:\n\t"
         // pop: the first unexpanded member of W (pop_min, :565) and its flag
-        "v_and_b32_e32 %[t0], 1, %[l0]\n\t"
-        "v_and_b32_e32 %[t1], 1, %[l1]\n\t"
-        "v_cmp_eq_u32_e64 %[um0], 0, %[t0]\n\t"
-        "v_cmp_eq_u32_e64 %[um1], 0, %[t1]\n\t"
-        "v_and_b32_e32 %[t0], 1, %[l2]\n\t"
-        "v_and_b32_e32 %[t1], 1, %[l3]\n\t"
-        "v_cmp_eq_u32_e64 %[um2], 0, %[t0]\n\t"
-        "v_cmp_eq_u32_e64 %[um3], 0, %[t1]\n"
+        "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n\t"
+        "v_cmp_lt_i32_e64 %[um1], -1, %[l1]\n\t"
+        "v_cmp_lt_i32_e64 %[um2], -1, %[l2]\n\t"
+        "v_cmp_lt_i32_e64 %[um3], -1, %[l3]\n"
         HNSW_POP_SLOT("60", "%[um0]", "%[l0]", "61f")
         HNSW_POP_SLOT("61", "%[um1]", "%[l1]", "62f")
         HNSW_POP_SLOT("62", "%[um2]", "%[l2]", "63f")
         HNSW_POP_SLOT("63", "%[um3]", "%[l3]", "90f")
         "3:\n\t"
-        "s_lshr_b32 %[klo], %[kd], 1\n\t"
-        "s_sub_u32 %[klo], %[klo], 1\n"                                   // node id
+        "s_sub_u32 %[klo], %[kd], 1\n"                                   // node id
         HNSW_HOP_ADJACENCY
         HNSW_HOP_FILTER_ISSUE
 #if HNSW_ASM_PREFETCH
@@ -799,6 +799,11 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
         "s_cbranch_scc0 1b\n\t"
         HNSW_HOP_NEXT_ROUND
         HNSW_HOP_TAIL
+        // back to the flag-in-bit-0 form
+        "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
+        "\n\tv_alignbit_b32 %[l1], %[l1], %[l1], 31"
+        "\n\tv_alignbit_b32 %[l2], %[l2], %[l2], 31"
+        "\n\tv_alignbit_b32 %[l3], %[l3], %[l3], 31"
         : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [h2] "+&v"(w.hi[2]), [h3] "+&v"(w.hi[3]),
           [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]), [l2] "+&v"(w.lo[2]), [l3] "+&v"(w.lo[3]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
@@ -852,13 +857,12 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "s_cbranch_scc1 110b\n\t"                                             /* the next accepted candidate */              \
     "s_branch 19f\n"                                                                                                     \
     "14:\n\t"                                                                                                            \
-    "v_cmp_gt_u32_e32 vcc, %[klo], %[l0]\n\t"                                                                            \
+    "v_and_b32_e32 %[t0], 0x7fffffff, %[l0]\n\t"                                                                         \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                            \
     "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
     "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                      \
     "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                     \
-    "s_or_b32 %[t], %[klo], 1\n\t"                                                                                       \
-    "v_or_b32_e32 %[t0], 1, %[l0]\n\t"                                                                                   \
-    "v_cmp_eq_u32_e32 vcc, %[t], %[t0]\n\t"                                                                              \
+    "v_cmp_eq_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                            \
     "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
     "s_cbranch_scc1 18b\n\t"                                              /* already in W */                             \
     "s_branch 11b\n"                                                                                                     \
@@ -866,11 +870,10 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                       \
     "s_cbranch_scc1 12b\n\t"                                                                                             \
     "v_readlane_b32 %[t], %[l0], 63\n\t"                                                                                 \
-    "s_bitcmp1_b32 %[t], 0\n\t"                                                                                          \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                         \
     "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
     "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
     "s_cbranch_scc1 16f\n\t"                                                                                             \
-    "s_lshr_b32 %[t], %[t], 1\n\t"                                                                                       \
     "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
     "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                                                                    \
     "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                                                              \
@@ -902,15 +905,16 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
     uint64_t um0, um1, fresh, b3m, b2m;    // um1: the visited filter's second compare only
     uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;
     asm volatile(
+        // low key halves inside the loop: id + 1 with the expanded flag in bit 31 (a rotation of the (id + 1) << 1 | flag the
+        // rest of the kernel keeps): the unexpanded members are the non-negative ones, a node id is one subtraction away
+        "v_alignbit_b32 %[l0], %[l0], %[l0], 1\n\t"
         HNSW_HOP_CONSTANTS
         "s_mov_b32 %[pref], -1\n"
         "1:\n\t"
-        "v_and_b32_e32 %[t0], 1, %[l0]\n\t"
-        "v_cmp_eq_u32_e64 %[um0], 0, %[t0]\n"
+        "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n"
         HNSW_POP_SLOT("60", "%[um0]", "%[l0]", "90f")
         "3:\n\t"
-        "s_lshr_b32 %[klo], %[kd], 1\n\t"
-        "s_sub_u32 %[klo], %[klo], 1\n"                                   // node id
+        "s_sub_u32 %[klo], %[kd], 1\n"                                   // node id
         HNSW_HOP_ADJACENCY
         HNSW_HOP_FILTER_ISSUE
 #if HNSW_ASM_PREFETCH
@@ -926,6 +930,8 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
         "s_cbranch_scc0 1b\n\t"
         HNSW_HOP_NEXT_ROUND
         HNSW_HOP_TAIL
+        // back to the flag-in-bit-0 form
+        "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
         : [h0] "+&v"(w.hi[0]), [l0] "+&v"(w.lo[0]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
