@@ -99,32 +99,36 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_dot4_u32_u8 " DA ", " DB ", " DB ", " DA "\n\t"
 #define HNSW_COMBINE(DA, TA) "v_mad_i32_i24 " DA ", " TA ", -2, " DA "\n\t"
 
-// the insertion loop of one round: insert_island2's code plus the two rare cases it left to C++
-//   labels: 10 loop, 19 done
-#define HNSW_INSERT_LOOP                                                                                                 \
+// The insertion loop of one round (labels 10 loop entry, 110 next candidate, 19 done): insert_island2's steps, ordered for a
+// wave that runs alone: a scalar instruction that reads what a vector instruction has just written (v_readlane,
+// v_cmp -> SGPR) waits ~16 cycles beyond its issue slot and a taken branch costs ~20 (profiles/r03_issue_latency.txt), so
+// the candidate's key halves, max(W)'s predecessor and all four rank compares are issued before the first scalar use,
+// and the common way through (rank in the upper slot, another candidate or none) falls through.  The lower-slot shift and
+// the rare cases are in HNSW_INSERT_RARE, behind the hop loop.
+#define HNSW_INSERT_LOOP                                                                                                  \
     "10:\n\t"                                                                                                            \
-    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                        \
+    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                       \
     "s_cbranch_scc1 19f\n"                                                                                               \
     "110:\n\t"                                                                                                           \
-    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                    \
+    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                   \
     "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
     "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
+    "v_readlane_b32 %[nw], %[h1], 62\n\t"                                                                                \
+    "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                          \
+    "v_cmp_eq_u32_e64 %[um1], %[kd], %[h1]\n\t"                                                                          \
+    "v_cmp_gt_u32_e64 %[g0], %[kd], %[h0]\n\t"                                                                           \
+    "v_cmp_gt_u32_e32 vcc, %[kd], %[h1]\n\t"                                                                             \
     "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
     "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
-    "v_readlane_b32 %[nw], %[h1], 62\n\t"                                                                                \
-    "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                           \
-    "v_cmp_eq_u32_e64 %[um1], %[kd], %[h1]\n\t"                                                                           \
-    "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                             \
-    "s_bcnt1_i32_b64 %[p], vcc\n\t"                                                                                      \
-    "v_cmp_gt_u32_e32 vcc, %[kd], %[h1]\n\t"                                                                             \
+    "s_bcnt1_i32_b64 %[p], %[g0]\n\t"                                                                                    \
     "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                      \
-    "s_add_u32 %[p], %[p], %[t]\n\t"                                      /* rank = keys at a smaller distance */       \
-    "s_or_b64 vcc, %[um0], %[um1]\n\t"                                                                                     \
-    "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
+    "s_add_u32 %[p], %[p], %[t]\n\t"                                      /* rank = keys at a smaller distance */        \
+    "s_or_b64 vcc, %[um0], %[um1]\n\t"                                                                                   \
+    "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */       \
     "11:\n\t"                                                                                                            \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
-    "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */      \
+    "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */       \
     "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
     "12:\n\t"                                                                                                            \
     "s_cmp_lt_u32 %[p], 64\n\t"                                                                                          \
@@ -136,14 +140,17 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_mov_b32 m0, %[p]\n\t"                                                                                             \
     "v_writelane_b32 %[h1], %[kd], m0\n\t"                                                                               \
     "v_writelane_b32 %[l1], %[klo], m0\n\t"                                                                              \
-    "s_mov_b32 %[wmax], %[nw]\n\t"                                                                                       \
+    "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
+    "18:\n\t"                                                                                                            \
     "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
     "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 110b\n\t"                                                                                            \
-    "s_branch 19f\n"                                                                                                     \
-    "13:\n\t"                                                             /* rank in the lower slot */                   \
+    "s_cbranch_scc1 110b\n"                                               /* the next accepted candidate */              \
+    "19:\n\t"
+
+#define HNSW_INSERT_RARE                                                                                                  \
+    "13:\n\t"                                                             /* rank in the lower slot: both slots move */  \
     "v_readlane_b32 %[sx], %[h0], 63\n\t"                                                                                \
-    "v_readlane_b32 %[tmp], %[l0], 63\n\t"                                                                                \
+    "v_readlane_b32 %[tmp], %[l0], 63\n\t"                                                                               \
     "v_mov_b32_dpp %[h1], %[h1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
     "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
     "s_lshl_b64 exec, -1, %[p]\n\t"                                                                                      \
@@ -151,17 +158,15 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_mov_b32_dpp %[l0], %[l0] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
     "s_mov_b64 exec, -1\n\t"                                                                                             \
     "v_writelane_b32 %[h1], %[sx], 0\n\t"                                                                                \
-    "v_writelane_b32 %[l1], %[tmp], 0\n\t"                                                                                \
+    "v_writelane_b32 %[l1], %[tmp], 0\n\t"                                                                               \
     "s_mov_b32 m0, %[p]\n\t"                                                                                             \
     "v_writelane_b32 %[h0], %[kd], m0\n\t"                                                                               \
-    "v_writelane_b32 %[l0], %[klo], m0\n"                                                                                \
-    "17:\n\t"                                                                                                            \
-    "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
-    "18:\n\t"                                                                                                            \
-    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                    \
+    "v_writelane_b32 %[l0], %[klo], m0\n\t"                                                                              \
+    "s_mov_b32 %[wmax], %[nw]\n\t"                                                                                       \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
     "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 110b\n\t"                                             /* the next accepted candidate */              \
-    "s_branch 19f\n"                                                                                                     \
+    "s_cbranch_scc1 110b\n\t"                                                                                            \
+    "s_branch 19b\n"                                                                                                     \
     /* rare: distance tie inside W.  rank += members at this distance with a smaller id; a member with this id (flag */ \
     /* bit either way) means the node is already in W (a re-evaluation the visited cache forgot): ignored */            \
     "14:\n\t"                                                                                                            \
@@ -204,8 +209,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_branch 12b\n"                                                                                                     \
     "16:\n\t"                                                                                                            \
     "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 12b\n"                                                                                                     \
-    "19:\n\t"
+    "s_branch 12b\n"
 
 // accept ballot of a round: candidate index of this lane within the round = CO (per-lane constant; a lane that holds no
 // candidate's sum has 0x1000 there), valid below cnt, and below the current max(W) (lib/ohnsw.ml:574)
@@ -218,14 +222,19 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_cmp_gt_u32_e64 %[fresh], %[wmax], %[ckey]\n\t"                                     \
     "s_and_b64 %[fresh], %[fresh], vcc\n\t"
 
-// label 4: the hop's node is in klo: count it, then its adjacency row (Graph.adjacent, :570) -- fetched during the previous hop
-// if the guess was right -- into nb
+// label 4: the hop's node is in klo: count it, then its adjacency row (Graph.adjacent, :570).  The row was requested during
+// the previous hop if the guess of the next node was right (nine hops in ten): that path falls through; a miss leaves the
+// line (44, HNSW_HOP_ADJACENCY_MISS) and comes back at 6 -- a taken branch costs a lone wave five issue slots.
 #define HNSW_HOP_ADJACENCY \
-        "4:\n\t"                                                                                                              \
-        "s_add_u32 %[nh], %[nh], 1\n\t"                                                                                       \
-  /* adjacency row (Graph.adjacent, :570): fetched during the previous hop if the guess was right */                          \
-        "s_cmp_eq_u32 %[klo], %[pref]\n\t"                                                                                    \
-        "s_cbranch_scc1 5f\n\t"                                                                                               \
+        "4:\n\t"                            \
+        "s_add_u32 %[nh], %[nh], 1\n\t"     \
+        "s_cmp_lg_u32 %[klo], %[pref]\n\t"  \
+        "s_cbranch_scc1 44f\n\t"            \
+        HNSW_ASM_COUNT_HIT                  \
+        "s_waitcnt vmcnt(0)\n\t"            \
+        "v_mov_b32_e32 %[nb], %[pnb]\n"
+#define HNSW_HOP_ADJACENCY_MISS \
+        "44:\n\t"                                                                                                             \
         "s_mul_i32 %[tmp], %[klo], %[rowb]\n\t"  /* byte offset of the row (the caller checked that the table is < 4 GiB) */  \
         "v_add_u32_e32 %[t0], %[tmp], %[lane4]\n\t"                                                                           \
         "s_waitcnt vmcnt(0)\n\t"  /* a wrong guess still in flight is drained first (its target is pnb) */                    \
@@ -234,11 +243,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "global_load_dword %[nb], %[t0], %[nbr]\n\t"                                                                          \
         "s_mov_b64 exec, -1\n\t"                                                                                              \
         "s_waitcnt vmcnt(0)\n\t"                                                                                              \
-        "s_branch 6f\n"                                                                                                       \
-        "5:\n\t"                                                                                                              \
-        HNSW_ASM_COUNT_HIT                                                                                   \
-        "s_waitcnt vmcnt(0)\n\t"                                                                                              \
-        "v_mov_b32_e32 %[nb], %[pnb]\n"                                                                                       
+        "s_branch 6b\n"
 
 // label 6: visited filter (Visited.mem, :571), first half: the set's word is requested, the tag computed
 #define HNSW_HOP_FILTER_ISSUE \
@@ -281,34 +286,15 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_add_u32 %[sx], %[sx], 4\n\t"            \
         "s_branch 20b\n"
 
-// labels 20 / 30 / 40: one round of 4 / 8 / 16 rows -> ckey, cid, the accept mask in `fresh`, cnt reduced by the round's size; falls through to 50
-#define HNSW_HOP_ROUNDS \
+// One round of 4 / 8 / 16 rows -> ckey, cid, the accept mask in `fresh`, cnt reduced by the round's size, then the insertion
+// (50).  Label 20 picks the shape; the 8-row round (5..8 candidates left: the usual case of an M = 16 graph) follows in
+// line and falls into 50, the other two shapes (25, 40: HNSW_HOP_ROUNDS_RARE) sit behind the loop and branch back.
+#define HNSW_HOP_ROUND_COMMON \
         "20:\n\t"                                                                                                                     \
         "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
         "s_cbranch_scc1 40f\n\t"                                                                                                      \
-        "s_cmp_gt_u32 %[cnt], 4\n\t"                                                                                                  \
-        "s_cbranch_scc1 30f\n\t"                                                                                                      \
-  /* ---- 4 rows: one batch */                                                                                                        \
-        HNSW_ID_READ0("%[id0]", 0)                                                                                                  \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
-        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
-        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
-        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
-        "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
-        "s_nop 2\n\t"                                                                                                                 \
-        HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
-        HNSW_ACCEPT_EARLY("%[co1]")                                                                                                   \
-        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:4" HNSW_DPP_BC "\n\t"                                                              \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:2" HNSW_DPP_BC "\n\t"                                                              \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:1" HNSW_DPP_BC "\n\t"                                                              \
-        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"                                                                                        \
-        HNSW_ACCEPT_LATE                                                                                                              \
-        "s_sub_u32 %[cnt], %[cnt], 4\n\t"                                                                                           \
-        "s_branch 50f\n"                                                                                                              \
+        "s_cmp_lt_u32 %[cnt], 5\n\t"                                                                                                  \
+        "s_cbranch_scc1 25f\n\t"                                                                                                      \
   /* ---- 8 rows: two batches */                                                                                                      \
         "30:\n\t"                                                                                                                     \
         HNSW_ID_READ0("%[id0]", 1)                                                                                                  \
@@ -337,8 +323,31 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
         "v_cvt_f32_i32_e32 %[ckey], %[ta]\n\t"                                                                                        \
         HNSW_ACCEPT_LATE                                                                                                              \
-        "s_sub_u32 %[cnt], %[cnt], 8\n\t"                                                                                           \
-        "s_branch 50f\n"                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 8\n"
+
+#define HNSW_HOP_ROUNDS_RARE \
+        "25:\n\t"                                                                                                                     \
+  /* ---- 4 rows: one batch */                                                                                                        \
+        HNSW_ID_READ0("%[id0]", 0)                                                                                                  \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
+        "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
+        "s_nop 2\n\t"                                                                                                                 \
+        HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        HNSW_ACCEPT_EARLY("%[co1]")                                                                                                   \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:4" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:2" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:1" HNSW_DPP_BC "\n\t"                                                              \
+        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"                                                                                        \
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 4\n\t"                                                                                           \
+        "s_branch 50b\n"                                                                                                              \
   /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
         "40:\n\t"                                                                                                                     \
         HNSW_ID_READ0("%[id0]", 2)                                                                                                  \
@@ -387,7 +396,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
         "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"                                                                                        \
         HNSW_ACCEPT_LATE                                                                                                              \
-        "s_sub_u32 %[cnt], %[cnt], 16\n"                                                                                            
+        "s_sub_u32 %[cnt], %[cnt], 16\n\t"                                                                                            \
+        "s_branch 50b\n"
 
 // labels 90 / 99: no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568), else done
 #define HNSW_HOP_TAIL \
@@ -466,7 +476,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     // temporaries
     uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
     uint64_t ad0, ad1, ad2, ad3;
-    uint64_t um0, um1, fresh, b3m, b2m;   // um0 / um1 double as the insertion's equality masks, fresh as the round's accept mask
+    uint64_t um0, um1, g0, fresh, b3m, b2m;   // um0 / um1 double as the insertion's equality masks, fresh as the round's accept mask
     uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;   // klo doubles as the hop's node, sx / tmp as the shift's carries
     asm volatile(
         // low key halves inside the loop: id + 1 with the expanded flag in bit 31 (a rotation of the (id + 1) << 1 | flag the
@@ -486,7 +496,8 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "s_cbranch_scc1 99f\n\t"
 #endif
         HNSW_PROBE(0)
-        // pop: the first unexpanded member of W (pop_min, :565) and its flag
+        // pop: the first unexpanded member of W (pop_min, :565) and its flag; it is nearly always in the lower slot (the
+        // upper one: label 2, behind the loop)
         "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n\t"
         "v_cmp_lt_i32_e64 %[um1], -1, %[l1]\n\t"
         "s_cmp_eq_u64 %[um0], 0\n\t"
@@ -496,17 +507,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "s_bitset0_b64 %[um0], %[i]\n\t"
         "s_mov_b32 m0, %[i]\n\t"
         "s_or_b32 %[t], %[kd], 0x80000000\n\t"
-        "v_writelane_b32 %[l0], %[t], m0\n\t"
-        "s_branch 3f\n"
-        "2:\n\t"
-        "s_cmp_eq_u64 %[um1], 0\n\t"
-        "s_cbranch_scc1 90f\n\t"
-        "s_ff1_i32_b64 %[i], %[um1]\n\t"
-        "v_readlane_b32 %[kd], %[l1], %[i]\n\t"
-        "s_bitset0_b64 %[um1], %[i]\n\t"
-        "s_mov_b32 m0, %[i]\n\t"
-        "s_or_b32 %[t], %[kd], 0x80000000\n\t"
-        "v_writelane_b32 %[l1], %[t], m0\n"
+        "v_writelane_b32 %[l0], %[t], m0\n"
         "3:\n\t"
         "s_sub_u32 %[klo], %[kd], 1\n"                                       // node id
         HNSW_HOP_ADJACENCY
@@ -518,18 +519,12 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "s_cmp_eq_u64 %[um0], 0\n\t"
         "s_cbranch_scc1 7f\n\t"
         "s_ff1_i32_b64 %[i], %[um0]\n\t"
-        "v_readlane_b32 %[pref], %[l0], %[i]\n\t"
-        "s_branch 8f\n"
-        "7:\n\t"
-        "s_cmp_eq_u64 %[um1], 0\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "s_ff1_i32_b64 %[i], %[um1]\n\t"
-        "v_readlane_b32 %[pref], %[l1], %[i]\n"
+        "v_readlane_b32 %[pref], %[l0], %[i]\n"
         HNSW_HOP_PREFETCH_LOAD
 #endif
         HNSW_HOP_FILTER_COMPACT
         HNSW_PROBE(2)
-        HNSW_HOP_ROUNDS
+        HNSW_HOP_ROUND_COMMON
         "50:\n\t"
         HNSW_PROBE(3)
         HNSW_INSERT_LOOP
@@ -537,6 +532,28 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "s_cmp_gt_i32 %[cnt], 0\n\t"
         "s_cbranch_scc0 1b\n\t"
         HNSW_HOP_NEXT_ROUND
+        // ---- behind the loop: the ways less often taken
+        "2:\n\t"                                                            // pop from the upper slot
+        "s_cmp_eq_u64 %[um1], 0\n\t"
+        "s_cbranch_scc1 90f\n\t"
+        "s_ff1_i32_b64 %[i], %[um1]\n\t"
+        "v_readlane_b32 %[kd], %[l1], %[i]\n\t"
+        "s_bitset0_b64 %[um1], %[i]\n\t"
+        "s_mov_b32 m0, %[i]\n\t"
+        "s_or_b32 %[t], %[kd], 0x80000000\n\t"
+        "v_writelane_b32 %[l1], %[t], m0\n\t"
+        "s_branch 3b\n"
+#if HNSW_ASM_PREFETCH
+        "7:\n\t"                                                            // the next one is in the upper slot, or there is none
+        "s_cmp_eq_u64 %[um1], 0\n\t"
+        "s_cbranch_scc1 9b\n\t"
+        "s_ff1_i32_b64 %[i], %[um1]\n\t"
+        "v_readlane_b32 %[pref], %[l1], %[i]\n\t"
+        "s_branch 8b\n"
+#endif
+        HNSW_HOP_ADJACENCY_MISS
+        HNSW_HOP_ROUNDS_RARE
+        HNSW_INSERT_RARE
         // ---- no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568)
         HNSW_HOP_TAIL
         // back to the flag-in-bit-0 form
@@ -550,7 +567,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
           [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
           [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
           [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
-          [um0] "=&s"(um0), [um1] "=&s"(um1), [fresh] "=&s"(fresh),
+          [um0] "=&s"(um0), [um1] "=&s"(um1), [g0] "=&s"(g0), [fresh] "=&s"(fresh),
           [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
           [pref] "=&s"(pref), [cnt] "=&s"(cnt),
           [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t),
@@ -579,7 +596,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
 // takes the general path, which ranks over all four slots.
 // =====================================================================================================================
 
-// pop from slot S (key halves LS): label LBL; continues at NEXT when the slot has no unexpanded member
+// pop from slot S (key halves LS) behind the loop: label LBL; continues at NEXT when the slot has no unexpanded member; back at 3
 #define HNSW_POP_SLOT(LBL, UM, LS, NEXT)                            \
     LBL ":\n\t"                                                     \
     "s_cmp_eq_u64 " UM ", 0\n\t"                                    \
@@ -590,15 +607,30 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "s_mov_b32 m0, %[i]\n\t"                                        \
     "s_or_b32 %[t], %[kd], 0x80000000\n\t"                          \
     "v_writelane_b32 " LS ", %[t], m0\n\t"                          \
-    "s_branch 3f\n"
-// the same walk for the speculative row fetch: the first remaining unexpanded member's low half -> pref, then 8f; none: 9f
+    "s_branch 3b\n"
+// the lowest slot's pop, in line: falls into 3
+#define HNSW_POP_SLOT0(UM, LS, NEXT)                                \
+    "s_cmp_eq_u64 " UM ", 0\n\t"                                    \
+    "s_cbranch_scc1 " NEXT "\n\t"                                   \
+    "s_ff1_i32_b64 %[i], " UM "\n\t"                                \
+    "v_readlane_b32 %[kd], " LS ", %[i]\n\t"                        \
+    "s_bitset0_b64 " UM ", %[i]\n\t"                                \
+    "s_mov_b32 m0, %[i]\n\t"                                        \
+    "s_or_b32 %[t], %[kd], 0x80000000\n\t"                          \
+    "v_writelane_b32 " LS ", %[t], m0\n"
+// the same walk for the speculative row fetch: the first remaining unexpanded member's low half -> pref, then 8; none: 9
 #define HNSW_PEEK_SLOT(LBL, UM, LS, NEXT)                           \
     LBL ":\n\t"                                                     \
     "s_cmp_eq_u64 " UM ", 0\n\t"                                    \
     "s_cbranch_scc1 " NEXT "\n\t"                                   \
     "s_ff1_i32_b64 %[i], " UM "\n\t"                                \
     "v_readlane_b32 %[pref], " LS ", %[i]\n\t"                      \
-    "s_branch 8f\n"
+    "s_branch 8b\n"
+#define HNSW_PEEK_SLOT0(UM, LS, NEXT)                               \
+    "s_cmp_eq_u64 " UM ", 0\n\t"                                    \
+    "s_cbranch_scc1 " NEXT "\n\t"                                   \
+    "s_ff1_i32_b64 %[i], " UM "\n\t"                                \
+    "v_readlane_b32 %[pref], " LS ", %[i]\n"
 // slot J moves by one whole position and takes slot J-1's last key in lane 0 (read BEFORE slot J-1 moves)
 #define HNSW_SHIFT_WHOLE(HJ, LJ, HJM1, LJM1)                        \
     "v_readlane_b32 %[sx], " HJM1 ", 63\n\t"                        \
@@ -775,29 +807,34 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
         "v_cmp_lt_i32_e64 %[um1], -1, %[l1]\n\t"
         "v_cmp_lt_i32_e64 %[um2], -1, %[l2]\n\t"
         "v_cmp_lt_i32_e64 %[um3], -1, %[l3]\n"
-        HNSW_POP_SLOT("60", "%[um0]", "%[l0]", "61f")
-        HNSW_POP_SLOT("61", "%[um1]", "%[l1]", "62f")
-        HNSW_POP_SLOT("62", "%[um2]", "%[l2]", "63f")
-        HNSW_POP_SLOT("63", "%[um3]", "%[l3]", "90f")
+        HNSW_POP_SLOT0("%[um0]", "%[l0]", "61f")
         "3:\n\t"
         "s_sub_u32 %[klo], %[kd], 1\n"                                   // node id
         HNSW_HOP_ADJACENCY
         HNSW_HOP_FILTER_ISSUE
 #if HNSW_ASM_PREFETCH
-        "s_mov_b32 %[pref], -1\n"
-        HNSW_PEEK_SLOT("70", "%[um0]", "%[l0]", "71f")
-        HNSW_PEEK_SLOT("71", "%[um1]", "%[l1]", "72f")
-        HNSW_PEEK_SLOT("72", "%[um2]", "%[l2]", "73f")
-        HNSW_PEEK_SLOT("73", "%[um3]", "%[l3]", "9f")
+        "s_mov_b32 %[pref], -1\n\t"
+        HNSW_PEEK_SLOT0("%[um0]", "%[l0]", "71f")
         HNSW_HOP_PREFETCH_LOAD
 #endif
         HNSW_HOP_FILTER_COMPACT
-        HNSW_HOP_ROUNDS
+        HNSW_HOP_ROUND_COMMON
         "50:\n\t"
         HNSW_INSERT_LOOP4
         "s_cmp_gt_i32 %[cnt], 0\n\t"
         "s_cbranch_scc0 1b\n\t"
         HNSW_HOP_NEXT_ROUND
+        // ---- behind the loop
+        HNSW_POP_SLOT("61", "%[um1]", "%[l1]", "62f")
+        HNSW_POP_SLOT("62", "%[um2]", "%[l2]", "63f")
+        HNSW_POP_SLOT("63", "%[um3]", "%[l3]", "90f")
+#if HNSW_ASM_PREFETCH
+        HNSW_PEEK_SLOT("71", "%[um1]", "%[l1]", "72f")
+        HNSW_PEEK_SLOT("72", "%[um2]", "%[l2]", "73f")
+        HNSW_PEEK_SLOT("73", "%[um3]", "%[l3]", "9b")
+#endif
+        HNSW_HOP_ADJACENCY_MISS
+        HNSW_HOP_ROUNDS_RARE
         HNSW_HOP_TAIL
         // back to the flag-in-bit-0 form
         "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
@@ -912,23 +949,25 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
         "s_mov_b32 %[pref], -1\n"
         "1:\n\t"
         "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n"
-        HNSW_POP_SLOT("60", "%[um0]", "%[l0]", "90f")
+        HNSW_POP_SLOT0("%[um0]", "%[l0]", "90f")
         "3:\n\t"
         "s_sub_u32 %[klo], %[kd], 1\n"                                   // node id
         HNSW_HOP_ADJACENCY
         HNSW_HOP_FILTER_ISSUE
 #if HNSW_ASM_PREFETCH
-        "s_mov_b32 %[pref], -1\n"
-        HNSW_PEEK_SLOT("70", "%[um0]", "%[l0]", "9f")
+        "s_mov_b32 %[pref], -1\n\t"
+        HNSW_PEEK_SLOT0("%[um0]", "%[l0]", "9f")
         HNSW_HOP_PREFETCH_LOAD
 #endif
         HNSW_HOP_FILTER_COMPACT
-        HNSW_HOP_ROUNDS
+        HNSW_HOP_ROUND_COMMON
         "50:\n\t"
         HNSW_INSERT_LOOP1
         "s_cmp_gt_i32 %[cnt], 0\n\t"
         "s_cbranch_scc0 1b\n\t"
         HNSW_HOP_NEXT_ROUND
+        HNSW_HOP_ADJACENCY_MISS
+        HNSW_HOP_ROUNDS_RARE
         HNSW_HOP_TAIL
         // back to the flag-in-bit-0 form
         "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
