@@ -74,15 +74,14 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 // ids of batch B of a round -> LDS read.  Group r reads the round's candidate NB r + B, clamped to the last candidate of
 // the list (a group past the end re-reads a row that is in flight anyway; its key is masked out below).
 //   sx = address of the round's first candidate; lastad = address of the list's last; r4 = 4 r per lane; SH = log2 NB
-#define HNSW_ID_READ(B, ID, SH)                                                          \
-    "s_add_u32 %[tmp], %[sx], 4*" #B "\n\t"                                              \
-    "v_lshl_add_u32 " ID ", %[r4], " #SH ", %[tmp]\n\t"                                  \
-    "v_min_u32 " ID ", %[lastad], " ID "\n\t"                                            \
-    "ds_read_b32 " ID ", " ID "\n\t"
 #define HNSW_ID_READ0(ID, SH)                                                            \
-    "v_lshl_add_u32 " ID ", %[r4], " #SH ", %[sx]\n\t"                                   \
-    "v_min_u32 " ID ", %[lastad], " ID "\n\t"                                            \
-    "ds_read_b32 " ID ", " ID "\n\t"
+    "v_lshl_add_u32 %[t0], %[r4], " #SH ", %[sx]\n\t"                                    \
+    "v_min_u32 %[t0], %[lastad], %[t0]\n\t"                                              \
+    "ds_read_b32 " ID ", %[t0]\n\t"
+#define HNSW_ID_READN(ID)   /* the next batch: one candidate further, clamped again */    \
+    "v_add_u32_e32 %[t0], 4, %[t0]\n\t"                                                  \
+    "v_min_u32 %[t0], %[lastad], %[t0]\n\t"                                              \
+    "ds_read_b32 " ID ", %[t0]\n\t"
 // row address (one 64-bit multiply-add) and the row's two dwords per lane
 #define HNSW_ROW_LOAD(ID, AD, DA, DB)                                                    \
     "v_mad_u64_u32 " AD ", vcc, " ID ", %[st8], %[xl]\n\t"                               \
@@ -100,116 +99,155 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_COMBINE(DA, TA) "v_mad_i32_i24 " DA ", " TA ", -2, " DA "\n\t"
 
 // The insertion loop of one round (labels 10 loop entry, 110 next candidate, 19 done): insert_island2's steps, ordered for a
-// wave that runs alone: a scalar instruction that reads what a vector instruction has just written (v_readlane,
-// v_cmp -> SGPR) waits ~16 cycles beyond its issue slot and a taken branch costs ~20 (profiles/r03_issue_latency.txt), so
-// the candidate's key halves, max(W)'s predecessor and all four rank compares are issued before the first scalar use,
-// and the common way through (rank in the upper slot, another candidate or none) falls through.  The lower-slot shift and
-// the rare cases are in HNSW_INSERT_RARE, behind the hop loop.
-#define HNSW_INSERT_LOOP                                                                                                  \
-    "10:\n\t"                                                                                                            \
-    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 19f\n"                                                                                               \
-    "110:\n\t"                                                                                                           \
-    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                   \
-    "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
-    "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
-    "v_readlane_b32 %[nw], %[h1], 62\n\t"                                                                                \
-    "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                          \
-    "v_cmp_eq_u32_e64 %[um1], %[kd], %[h1]\n\t"                                                                          \
-    "v_cmp_gt_u32_e64 %[g0], %[kd], %[h0]\n\t"                                                                           \
-    "v_cmp_gt_u32_e32 vcc, %[kd], %[h1]\n\t"                                                                             \
-    "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
-    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
-    "s_bcnt1_i32_b64 %[p], %[g0]\n\t"                                                                                    \
-    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                      \
-    "s_add_u32 %[p], %[p], %[t]\n\t"                                      /* rank = keys at a smaller distance */        \
-    "s_or_b64 vcc, %[um0], %[um1]\n\t"                                                                                   \
-    "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */       \
-    "11:\n\t"                                                                                                            \
+// wave that runs alone and counted for a chip that is full.  Alone: a scalar instruction that reads what a vector
+// instruction has just written (v_readlane, v_cmp -> SGPR) waits ~16 cycles beyond its issue slot and a taken branch costs
+// ~20 (profiles/r03_issue_latency.txt), so the candidate's key halves, max(W)'s predecessor and the rank compares are all
+// issued before the first scalar use, and the common way through (rank in the upper slot, then the next candidate or none)
+// falls through.  Full: the CU's four SIMDs share one scalar unit, so scalar instructions are the dearest: W is sorted, so
+// any key of the upper slot below the candidate puts the rank there (one count gives the position: its SCC picks the slot);
+// the shift is a v_cndmask_b32_dpp under a mask made by one s_bfm (no EXEC writes); the tie list is not cleared when max(W)
+// drops -- it carries the distance it was filled at (od) and is alive only while that is max(W).d.
+// The lower-slot shift and the rare cases are in HNSW_INSERT_RARE, behind the hop loop.
+#define HNSW_INSERT_LOOP                                                                                                    \
+    "10:\n\t"                                                                                                               \
+    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 19f\n"                                                                                                  \
+    "110:\n\t"                                                                                                              \
+    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                      \
+    "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                               \
+    "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                               \
+    "v_readlane_b32 %[nw], %[h1], 62\n\t"                                                                                   \
+    "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                             \
+    "v_cmp_eq_u32_e64 %[um1], %[kd], %[h1]\n\t"                                                                             \
+    "v_cmp_gt_u32_e64 %[g0], %[kd], %[h0]\n\t"                                                                              \
+    "v_cmp_gt_u32_e32 vcc, %[kd], %[h1]\n\t"                                                                                \
+    "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */      \
+    "s_or_b64 %[um0], %[um0], %[um1]\n\t"                                                                                   \
+    "s_cbranch_scc1 14f\n\t"                                              /* members of W at this very distance */          \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
-    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
-    "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */       \
-    "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
-    "12:\n\t"                                                                                                            \
-    "s_cmp_lt_u32 %[p], 64\n\t"                                                                                          \
-    "s_cbranch_scc1 13f\n\t"                                                                                             \
-    "s_lshl_b64 exec, -1, %[p]\n\t"                                       /* upper slot: shift count, lane select = bits 5:0 */ \
-    "v_mov_b32_dpp %[h1], %[h1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
-    "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
-    "s_mov_b64 exec, -1\n\t"                                                                                             \
-    "s_mov_b32 m0, %[p]\n\t"                                                                                             \
-    "v_writelane_b32 %[h1], %[kd], m0\n\t"                                                                               \
-    "v_writelane_b32 %[l1], %[klo], m0\n\t"                                                                              \
-    "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
-    "18:\n\t"                                                                                                            \
-    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
-    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 110b\n"                                               /* the next accepted candidate */              \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 15f\n"                                                /* the entry falling off ties with it */          \
+    "12:\n\t"                                                                                                               \
+    "s_bcnt1_i32_b64 %[p], vcc\n\t"                                       /* upper-slot keys below: any -> the rank is there */ \
+    "s_cbranch_scc0 13f\n"                                                                                                  \
+    "120:\n\t"                                                            /* upper slot from lane p (bits 5:0) on */        \
+    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "v_cndmask_b32_dpp %[h1], %[h1], %[h1], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "v_cndmask_b32_dpp %[l1], %[l1], %[l1], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
+    "v_writelane_b32 %[h1], %[kd], m0\n\t"                                                                                  \
+    "v_writelane_b32 %[l1], %[klo], m0\n\t"                                                                                 \
+    "s_mov_b32 %[wmax], %[nw]\n"                                                                                            \
+    "18:\n\t"                                                                                                               \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                      \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 110b\n"                                               /* the next accepted candidate */                 \
     "19:\n\t"
 
-#define HNSW_INSERT_RARE                                                                                                  \
-    "13:\n\t"                                                             /* rank in the lower slot: both slots move */  \
-    "v_readlane_b32 %[sx], %[h0], 63\n\t"                                                                                \
-    "v_readlane_b32 %[tmp], %[l0], 63\n\t"                                                                               \
-    "v_mov_b32_dpp %[h1], %[h1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
-    "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
-    "s_lshl_b64 exec, -1, %[p]\n\t"                                                                                      \
-    "v_mov_b32_dpp %[h0], %[h0] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
-    "v_mov_b32_dpp %[l0], %[l0] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                          \
-    "s_mov_b64 exec, -1\n\t"                                                                                             \
-    "v_writelane_b32 %[h1], %[sx], 0\n\t"                                                                                \
-    "v_writelane_b32 %[l1], %[tmp], 0\n\t"                                                                               \
-    "s_mov_b32 m0, %[p]\n\t"                                                                                             \
-    "v_writelane_b32 %[h0], %[kd], m0\n\t"                                                                               \
-    "v_writelane_b32 %[l0], %[klo], m0\n\t"                                                                              \
-    "s_mov_b32 %[wmax], %[nw]\n\t"                                                                                       \
-    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
-    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 110b\n\t"                                                                                            \
-    "s_branch 19b\n"                                                                                                     \
-    /* rare: distance tie inside W.  rank += members at this distance with a smaller id; a member with this id (flag */ \
-    /* bit either way) means the node is already in W (a re-evaluation the visited cache forgot): ignored */            \
-    "14:\n\t"                                                                                                            \
-    "v_and_b32_e32 %[t0], 0x7fffffff, %[l0]\n\t"                         /* id + 1 without the flag */                  \
-    "v_and_b32_e32 %[t1], 0x7fffffff, %[l1]\n\t"                                                                         \
-    "v_cmp_gt_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                            \
-    "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
-    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                     \
-    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                     \
-    "v_cmp_gt_u32_e32 vcc, %[klo], %[t1]\n\t"                                                                            \
-    "s_and_b64 vcc, vcc, %[um1]\n\t"                                                                                     \
-    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                     \
-    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                     \
-    "v_cmp_eq_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                            \
-    "s_and_b64 %[um0], vcc, %[um0]\n\t"                                                                                    \
-    "v_cmp_eq_u32_e32 vcc, %[klo], %[t1]\n\t"                                                                            \
-    "s_and_b64 %[um1], vcc, %[um1]\n\t"                                                                                    \
+#define HNSW_INSERT_RARE                                                                                                    \
+    "13:\n\t"                                                             /* no upper-slot key below: the rank is the lower slot's count */ \
+    "s_bcnt1_i32_b64 %[p], %[g0]\n\t"                                                                                       \
+    "s_bitcmp1_b32 %[p], 6\n\t"                                                                                             \
+    "s_cbranch_scc1 120b\n"                                               /* all 64 below: lane 0 of the upper slot (p & 63 = 0) */ \
+    "130:\n\t"                                                            /* lower slot from lane p on; the upper slot moves whole */ \
+    "v_readlane_b32 %[sx], %[h0], 63\n\t"                                                                                   \
+    "v_readlane_b32 %[tmp], %[l0], 63\n\t"                                                                                  \
+    "v_mov_b32_dpp %[h1], %[h1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "s_bfm_b64 vcc, %[p], 0\n\t"                                                                                            \
+    "v_cndmask_b32_dpp %[h0], %[h0], %[h0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "v_cndmask_b32_dpp %[l0], %[l0], %[l0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "v_writelane_b32 %[h1], %[sx], 0\n\t"                                                                                   \
+    "v_writelane_b32 %[l1], %[tmp], 0\n\t"                                                                                  \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
+    "v_writelane_b32 %[h0], %[kd], m0\n\t"                                                                                  \
+    "v_writelane_b32 %[l0], %[klo], m0\n\t"                                                                                 \
+    "s_mov_b32 %[wmax], %[nw]\n\t"                                                                                          \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                      \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 110b\n\t"                                                                                               \
+    "s_branch 19b\n"                                                                                                        \
+    /* rare: distance tie inside W.  The full rank: keys at a smaller distance + members at this distance with a smaller id; a */ \
+    /* member with this id (flag either way) means the node is already in W (a re-evaluation the visited cache forgot): ignored */ \
+    "14:\n\t"                                                                                                               \
+    "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                             \
+    "v_cmp_eq_u32_e64 %[um1], %[kd], %[h1]\n\t"                                                                             \
+    "s_bcnt1_i32_b64 %[p], %[g0]\n\t"                                                                                       \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                         \
+    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                        \
+    "v_and_b32_e32 %[t0], 0x7fffffff, %[l0]\n\t"                          /* id + 1 without the flag */                     \
+    "v_and_b32_e32 %[t1], 0x7fffffff, %[l1]\n\t"                                                                            \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                               \
+    "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                        \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                         \
+    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                        \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[t1]\n\t"                                                                               \
+    "s_and_b64 vcc, vcc, %[um1]\n\t"                                                                                        \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                         \
+    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                        \
+    "v_cmp_eq_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                               \
+    "s_and_b64 %[um0], vcc, %[um0]\n\t"                                                                                     \
+    "v_cmp_eq_u32_e32 vcc, %[klo], %[t1]\n\t"                                                                               \
+    "s_and_b64 %[um1], vcc, %[um1]\n\t"                                                                                     \
     "s_or_b64 %[um0], %[um0], %[um1]\n\t"                                                                                   \
-    "s_cbranch_scc1 18b\n\t"                                              /* already in W */                             \
-    "s_branch 11b\n"                                                                                                     \
-    /* rare: the entry that falls off is at the new maximum's distance.  A dummy: nothing happens.  A real, unexpanded */ \
-    /* one stays in the candidate queue (lib/ohnsw.ml:568 is false for it): pushed on the tie list */                    \
-    "15:\n\t"                                                                                                            \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                       \
-    "s_cbranch_scc1 12b\n\t"                                                                                             \
-    "v_readlane_b32 %[t], %[l1], 63\n\t"                                                                                 \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                         \
-    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
-    "s_cbranch_scc1 16f\n\t"                                                                                             \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
-    "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                                                                    \
-    "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                                                              \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                    \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                      \
-    "s_mov_b64 exec, 1\n\t"                                                                                              \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                           \
-    "s_mov_b64 exec, -1\n\t"                                                                                             \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                      \
-    "s_branch 12b\n"                                                                                                     \
-    "16:\n\t"                                                                                                            \
+    "s_cbranch_scc1 18b\n\t"                                              /* already in W */                                \
+    "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                                                                     \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 151f\n"                                                                                                 \
+    "141:\n\t"                                                                                                              \
+    "s_cmp_lt_u32 %[p], 64\n\t"                                                                                             \
+    "s_cbranch_scc1 130b\n\t"                                                                                               \
+    "s_branch 120b\n"                                                                                                       \
+    /* rare: the entry that falls off is at the new maximum's distance.  A dummy: nothing happens.  A real, unexpanded one   */ \
+    /* stays in the candidate queue (lib/ohnsw.ml:568 is false for it): pushed on the tie list.  The list holds entries at */ \
+    /* distance od; it is alive while od == max(W).d (a list left over from a larger maximum is restarted here)            */ \
+    "15:\n\t"                                                                                                               \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 12b\n\t"                                              /* W still holds dummies: nothing real falls off */ \
+    "v_readlane_b32 %[t], %[l1], 63\n\t"                                                                                    \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
+    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                     \
+    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                                                                         \
+    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
+    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
+    "s_cbranch_scc1 16f\n\t"                                                                                                \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
+    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
+    "s_mov_b64 exec, 1\n\t"                                                                                                 \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n\t"                                                                                                \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
+    "s_branch 12b\n"                                                                                                        \
+    "16:\n\t"                                                                                                               \
     "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 12b\n"
+    "s_branch 12b\n"                                                                                                        \
+    "151:\n\t"                                                                                                              \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 141b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
+    "v_readlane_b32 %[t], %[l1], 63\n\t"                                                                                    \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
+    "s_cbranch_scc1 141b\n\t"                                             /* expanded: gone for good */                     \
+    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                                                                         \
+    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
+    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
+    "s_cbranch_scc1 161f\n\t"                                                                                               \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
+    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
+    "s_mov_b64 exec, 1\n\t"                                                                                                 \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n\t"                                                                                                \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
+    "s_branch 141b\n"                                                                                                       \
+    "161:\n\t"                                                                                                              \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 141b\n"
 
 // accept ballot of a round: candidate index of this lane within the round = CO (per-lane constant; a lane that holds no
 // candidate's sum has 0x1000 there), valid below cnt, and below the current max(W) (lib/ohnsw.ml:574)
@@ -298,7 +336,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
   /* ---- 8 rows: two batches */                                                                                                      \
         "30:\n\t"                                                                                                                     \
         HNSW_ID_READ0("%[id0]", 1)                                                                                                  \
-        HNSW_ID_READ(1, "%[id1]", 1)                                                                                                  \
+        HNSW_ID_READN("%[id1]")                                                                                                  \
         "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
         HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
@@ -351,9 +389,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
   /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
         "40:\n\t"                                                                                                                     \
         HNSW_ID_READ0("%[id0]", 2)                                                                                                  \
-        HNSW_ID_READ(1, "%[id1]", 2)                                                                                                  \
-        HNSW_ID_READ(2, "%[id2]", 2)                                                                                                  \
-        HNSW_ID_READ(3, "%[id3]", 2)                                                                                                  \
+        HNSW_ID_READN("%[id1]")                                                                                                  \
+        HNSW_ID_READN("%[id2]")                                                                                                  \
+        HNSW_ID_READN("%[id3]")                                                                                                  \
         "s_waitcnt lgkmcnt(3)\n\t"                                                                                                    \
         HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
         "s_waitcnt lgkmcnt(2)\n\t"                                                                                                    \
@@ -403,6 +441,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_HOP_TAIL \
         "90:\n\t"                                                                   \
         "s_cmp_eq_u32 %[oc], 0\n\t"                                                 \
+        "s_cbranch_scc1 99f\n\t"                                                    \
+        "s_cmp_lg_u32 %[od], %[wmax]\n\t"  /* a list from a larger max(W): dead */  \
         "s_cbranch_scc1 99f\n\t"                                                    \
         "s_sub_u32 %[oc], %[oc], 1\n\t"                                             \
         "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                           \
@@ -472,7 +512,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     const uint32_t setm = cx.set_mask, setb = (uint32_t)cx.set_bits;
     const uint32_t q2 = (uint32_t)uniform(cx.q2);
     uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
-    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt);
+    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt), od = wmax;   // od: the tie list's distance
     // temporaries
     uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
     uint64_t ad0, ad1, ad2, ad3;
@@ -515,7 +555,6 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         HNSW_PROBE(1)
 #if HNSW_ASM_PREFETCH
         // the next nearest unexpanded member of W: its row is fetched now, beside this hop's vectors
-        "s_mov_b32 %[pref], -1\n\t"
         "s_cmp_eq_u64 %[um0], 0\n\t"
         "s_cbranch_scc1 7f\n\t"
         "s_ff1_i32_b64 %[i], %[um0]\n\t"
@@ -545,6 +584,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "s_branch 3b\n"
 #if HNSW_ASM_PREFETCH
         "7:\n\t"                                                            // the next one is in the upper slot, or there is none
+        "s_mov_b32 %[pref], -1\n\t"
         "s_cmp_eq_u64 %[um1], 0\n\t"
         "s_cbranch_scc1 9b\n\t"
         "s_ff1_i32_b64 %[i], %[um1]\n\t"
@@ -560,7 +600,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
         "\n\tv_alignbit_b32 %[l1], %[l1], %[l1], 31"
         : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]),
-          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
+          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc), [od] "+&s"(od),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
           [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4), [q2v] "=&v"(q2v),
           [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
@@ -579,7 +619,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
           , [maxh] "s"(maxhops)
 #endif
         : "vcc", "scc", "m0", "memory" HNSW_PROBE_CLOBBER);
-    w.wmax = wmax; w.ovf_cnt = (int)oc;
+    w.wmax = wmax; w.ovf_cnt = od == wmax ? (int)oc : 0;
     n_dist = nd; n_hops = nh; status = st;
 }
 
@@ -756,6 +796,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                 \
     "s_bitcmp1_b32 %[t], 31\n\t"                                                                                         \
     "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
+    "s_mov_b32 %[od], %[nw]\n\t"                                        /* the distance the list is at */              \
     "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
     "s_cbranch_scc1 16f\n\t"                                                                                             \
     "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
@@ -783,7 +824,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     const uint32_t setm = cx.set_mask, setb = (uint32_t)cx.set_bits;
     const uint32_t q2 = (uint32_t)uniform(cx.q2);
     uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
-    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt);
+    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt), od = wmax;   // od: the tie list's distance
     uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
     uint64_t ad0, ad1, ad2, ad3;
     uint64_t um0, um1, um2, um3, fresh, b3m, b2m;
@@ -843,7 +884,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
         "\n\tv_alignbit_b32 %[l3], %[l3], %[l3], 31"
         : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [h2] "+&v"(w.hi[2]), [h3] "+&v"(w.hi[3]),
           [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]), [l2] "+&v"(w.lo[2]), [l3] "+&v"(w.lo[3]),
-          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
+          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc), [od] "+&s"(od),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
           [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4), [q2v] "=&v"(q2v),
           [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
@@ -859,7 +900,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
           [nbr] "s"(nbr), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
           [cand] "s"(cand), [q2] "s"(q2)
         : "vcc", "scc", "m0", "memory");
-    w.wmax = wmax; w.ovf_cnt = (int)oc;
+    w.wmax = wmax; w.ovf_cnt = od == wmax ? (int)oc : 0;
     n_dist = nd; n_hops = nh; status = st;
 }
 
@@ -909,6 +950,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "v_readlane_b32 %[t], %[l0], 63\n\t"                                                                                 \
     "s_bitcmp1_b32 %[t], 31\n\t"                                                                                         \
     "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
+    "s_mov_b32 %[od], %[nw]\n\t"                                        /* the distance the list is at */              \
     "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
     "s_cbranch_scc1 16f\n\t"                                                                                             \
     "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
@@ -936,7 +978,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
     const uint32_t setm = cx.set_mask, setb = (uint32_t)cx.set_bits;
     const uint32_t q2 = (uint32_t)uniform(cx.q2);
     uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
-    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt);
+    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt), od = wmax;   // od: the tie list's distance
     uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
     uint64_t ad0, ad1, ad2, ad3;
     uint64_t um0, um1, fresh, b3m, b2m;    // um1: the visited filter's second compare only
@@ -972,7 +1014,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
         // back to the flag-in-bit-0 form
         "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
         : [h0] "+&v"(w.hi[0]), [l0] "+&v"(w.lo[0]),
-          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc),
+          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc), [od] "+&s"(od),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
           [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4), [q2v] "=&v"(q2v),
           [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
@@ -988,7 +1030,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
           [nbr] "s"(nbr), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
           [cand] "s"(cand), [q2] "s"(q2)
         : "vcc", "scc", "m0", "memory");
-    w.wmax = wmax; w.ovf_cnt = (int)oc;
+    w.wmax = wmax; w.ovf_cnt = od == wmax ? (int)oc : 0;
     n_dist = nd; n_hops = nh; status = st;
 }
 
