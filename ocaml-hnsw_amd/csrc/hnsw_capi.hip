@@ -163,6 +163,22 @@ int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
     return (int)pad;
 }
 
+// Issue priorities of an ordered launch (SearchArgs::prio_head / prio_tail; the kernel's comment says why): the first
+// eighth of the blocks that start at once (the walks predicted longest) and, when the launch is one full pass and a
+// partial second one, the blocks that have to wait for a slot.  HNSW_PRIO="head,tail" overrides the bounds (tuning).
+void launch_priorities(hnsw_index *idx, int64_t nq, int ef, int semf, SearchArgs &a) {
+    a.prio_head = 0; a.prio_tail = 0x7FFFFFFF;
+    if (const char *e = getenv("HNSW_PRIO")) {
+        int h = 0, t = 0x7FFFFFFF;
+        if (sscanf(e, "%d,%d", &h, &t) >= 1) { a.prio_head = h; a.prio_tail = t; }
+        return;
+    }
+    const int64_t resident = resident_queries(idx, ef, semf);
+    if (idx->resident_per_cu <= 0) return;
+    a.prio_head = (int32_t)(std::min(nq, resident) / 8);
+    if (nq > resident && nq < 2 * resident) a.prio_tail = (int32_t)resident;
+}
+
 int check_params(const hnsw_index *idx, const hnsw_search_params *p) {
     if (!idx) return fail(HNSW_ERR_BAD_ARG, "null index");
     if (!p) return fail(HNSW_ERR_BAD_ARG, "null params");
@@ -362,7 +378,7 @@ int search_rerun_device(hnsw_index *idx, const float *d_queries, int64_t nq, int
     a.fill = p->fill; a.sem = p->semantics;
     a.vt_bits = search_vt_bits(idx, p->ef);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_nd; a.out_nhops = d_nh; a.out_status = d_st;
-    a.qmap = qmap; a.q_limit = nq; a.ovf_g = slab; a.ovf_gcap = cap;
+    a.qmap = qmap; a.q_limit = nq; a.ovf_g = slab; a.ovf_gcap = cap; a.prio_tail = 0x7FFFFFFF;
     return launch_search_args(idx, a, st);
 }
 } // namespace hnsw_host
@@ -403,6 +419,7 @@ extern "C++" int hnsw_host::search_batch_device_flag(hnsw_index *idx, const floa
     a.vt_bits = search_vt_bits(idx, params->ef);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_ndist; a.out_nhops = d_nhops; a.out_status = d_status;
     a.any_flag = d_any_flag;
+    a.prio_tail = 0x7FFFFFFF;
     // A batch larger than the chip holds at once is searched longest walk first (hnsw_order.hip):
     // per-query results are unchanged, the launch's drain phase is made of short walks.
     void *block = nullptr;
@@ -425,6 +442,7 @@ extern "C++" int hnsw_host::search_batch_device_flag(hnsw_index *idx, const floa
         if (rc) return rc;
         a.q_limit = nq;
         a.lds_pad = balanced_lds_pad(idx, nq, params->ef, params->semantics ? 1 : 0);
+        launch_priorities(idx, nq, params->ef, params->semantics ? 1 : 0, a);
     }
     if (ev) HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
     rc = launch_search_args(idx, a, (hipStream_t)stream);
