@@ -1137,8 +1137,7 @@ __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv,
 #ifndef HNSW_SEARCH_MIN_WAVES
 #define HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS, SEMF) \
     (((NCH) <= 2 && (NSLOT) <= 2 && (METRIC) == 0 && (ROWS) == 1) ? 7 : \
-     (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) <= 2 && (METRIC) == 0 && (ROWS) == 2 && (SEMF) == 0) ? 8 : \
-     (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) == 4 && (METRIC) == 0 && (ROWS) == 2 && (SEMF) == 0) ? 7 : 1)
+     (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) <= 4 && (METRIC) == 0 && (ROWS) == 2 && (SEMF) == 0) ? 8 : 1)
 #endif
 // SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); ROWS: 0 | 1 | 2, see hop_round
 template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, int ROWS>

@@ -60,6 +60,15 @@ namespace hnsw_dev {
 #else
 #define HNSW_ASM_COUNT_HIT
 #endif
+// Where the two-slot hop loop starts relative to a 64-byte instruction line: k dwords past one.  A lone wave's query time
+// moves by +-2 % with k (which branch targets sit at the end of a fetch window): 0.1410 .. 0.1469 ms over k = 0..8 on C2,
+// k = 7, 8 best; pinned so that code added in front of the loop does not move it.  (tools/mkvariant.sh -DHNSW_ASM_ALIGN_PAD=k)
+#ifndef HNSW_ASM_ALIGN_PAD
+#define HNSW_ASM_ALIGN_PAD 8
+#endif
+#define HNSW_STR2(x) #x
+#define HNSW_STR(x) HNSW_STR2(x)
+#define HNSW_ASM_ALIGN ".p2align 6\n\t.rept " HNSW_STR(HNSW_ASM_ALIGN_PAD) "\n\ts_nop 0\n\t.endr\n"
 #ifndef HNSW_ASM_PREFETCH
 #define HNSW_ASM_PREFETCH 1
 #endif
@@ -249,13 +258,13 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
     "s_branch 141b\n"
 
-// accept ballot of a round: candidate index of this lane within the round = CO (per-lane constant; a lane that holds no
-// candidate's sum has 0x1000 there), valid below cnt, and below the current max(W) (lib/ohnsw.ml:574)
+// accept ballot of a round: candidate index of this lane within the round = byte SHAPE of the per-lane constant co (0xff on
+// a lane that holds no candidate's sum), valid below cnt, and below the current max(W) (lib/ohnsw.ml:574)
 // (cnt = candidates not yet evaluated when the round starts).  The first half does not depend on the sums: it fills the
 // two wait states a DPP read of a just-written register needs anyway.
-#define HNSW_ACCEPT_EARLY(CO)                                                            \
+#define HNSW_ACCEPT_EARLY(SHAPE)                                                         \
     "v_add_u32_e32 %[cid], 1, %[cid]\n\t"           /* ids -> low key halves: id + 1, unexpanded */          \
-    "v_cmp_gt_u32_e32 vcc, %[cnt], " CO "\n\t"
+    "v_cmp_gt_u32_sdwa vcc, %[cnt], %[co] src0_sel:DWORD src1_sel:BYTE_" #SHAPE "\n\t"
 #define HNSW_ACCEPT_LATE                                                                 \
     "v_cmp_gt_u32_e64 %[fresh], %[wmax], %[ckey]\n\t"                                     \
     "s_and_b64 %[fresh], %[fresh], vcc\n\t"
@@ -274,7 +283,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_HOP_ADJACENCY_MISS \
         "44:\n\t"                                                                                                             \
         "s_mul_i32 %[tmp], %[klo], %[rowb]\n\t"  /* byte offset of the row (the caller checked that the table is < 4 GiB) */  \
-        "v_add_u32_e32 %[t0], %[tmp], %[lane4]\n\t"                                                                           \
+        "v_lshl_add_u32 %[t0], %[lane], 2, %[tmp]\n\t"                                                                        \
         "s_waitcnt vmcnt(0)\n\t"  /* a wrong guess still in flight is drained first (its target is pnb) */                    \
         "v_mov_b32_e32 %[nb], -1\n\t"                                                                                         \
         "s_mov_b64 exec, %[rowm]\n\t"                                                                                         \
@@ -351,7 +360,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         HNSW_COMBINE("%[d2]", "%[tb]")                                                                                                \
         "v_cndmask_b32_e64 %[ta], %[d0], %[d2], %[b3m]\n\t"  /* keep: the sum this half of the group is for */                        \
         "v_cndmask_b32_e64 %[tb], %[d2], %[d0], %[b3m]\n\t"  /* give: the other half's */                                             \
-        HNSW_ACCEPT_EARLY("%[co2]")                                                                                                               \
+        HNSW_ACCEPT_EARLY(1)                                                                                                               \
         "v_add_u32_dpp %[ta], %[tb], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[ta], %[ta], %[ta] row_half_mirror" HNSW_DPP_BC "\n\t"                                                        \
@@ -374,7 +383,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
         "s_nop 2\n\t"                                                                                                                 \
         HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
-        HNSW_ACCEPT_EARLY("%[co1]")                                                                                                   \
+        HNSW_ACCEPT_EARLY(0)                                                                                                   \
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:4" HNSW_DPP_BC "\n\t"                                                              \
@@ -397,9 +406,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_waitcnt lgkmcnt(2)\n\t"                                                                                                    \
         HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")                                                                           \
         "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
-        HNSW_ROW_LOAD("%[id2]", "%[ad2]", "%[d4]", "%[d5]")                                                                           \
+        HNSW_ROW_LOAD("%[id2]", "%[ad0]", "%[d4]", "%[d5]")                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
-        HNSW_ROW_LOAD("%[id3]", "%[ad3]", "%[d6]", "%[d7]")                                                                           \
+        HNSW_ROW_LOAD("%[id3]", "%[ad1]", "%[d6]", "%[d7]")                                                                           \
         "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"                                                                        \
         "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"                                                                        \
         "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"                                                                        \
@@ -426,7 +435,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[tb], %[d3], %[tb] row_ror:8" HNSW_DPP_BC "\n\t"  /* candidates 1 | 3 */                                      \
         "v_cndmask_b32_e64 %[d0], %[ta], %[tb], %[b2m]\n\t"                                                                           \
         "v_cndmask_b32_e64 %[d1], %[tb], %[ta], %[b2m]\n\t"                                                                           \
-        HNSW_ACCEPT_EARLY("%[co4]")                                                                                                                \
+        HNSW_ACCEPT_EARLY(2)                                                                                                                \
         "v_add_u32_dpp %[d0], %[d1], %[d0] row_half_mirror" HNSW_DPP_BC "\n\t"                                                        \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"                                                    \
@@ -457,31 +466,32 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "99:\n\t"                                                                   \
         "s_waitcnt vmcnt(0)"  /* a speculative row fetch may still be in flight */  
 
-// per-lane constants of the hop: byte offsets, the candidate a lane's sum belongs to in a round of 1 / 2 / 4 batches (0x1000 on
-// the lanes that hold no candidate's sum), the lane-bit masks of the transposing reduction
+// per-lane constants of the hop: the candidate a lane's sum belongs to in a round of 1 / 2 / 4 batches (bytes 0 / 1 / 2 of co; 0xff
+// on the lanes that hold no candidate's sum), the lane-bit masks of the transposing reduction (d0..d2 are scratch here)
 #define HNSW_HOP_CONSTANTS \
-        "v_lshlrev_b32_e32 %[lane4], 2, %[lane]\n\t"                                                   \
         "v_lshrrev_b32_e32 %[r4], 4, %[lane]\n\t"  /* r */                                             \
         "v_bfe_u32 %[t0], %[lane], 3, 1\n\t"                                                           \
-        "v_lshl_add_u32 %[co2], %[r4], 1, %[t0]\n\t"  /* NB 2: 2 r + bit 3 of the lane */              \
+        "v_lshl_add_u32 %[d1], %[r4], 1, %[t0]\n\t"  /* NB 2: 2 r + bit 3 of the lane */               \
         "v_bfe_u32 %[t0], %[lane], 2, 2\n\t"                                                           \
-        "v_lshl_add_u32 %[co4], %[r4], 2, %[t0]\n\t"  /* NB 4: 4 r + bits 3:2 */                       \
-        "v_mov_b32_e32 %[co1], %[r4]\n\t"  /* NB 1: candidate r */                                     \
-        "v_mov_b32_e32 %[t1], 0x1000\n\t"  /* lanes that hold no candidate's sum: never below cnt */   \
+        "v_lshl_add_u32 %[d2], %[r4], 2, %[t0]\n\t"  /* NB 4: 4 r + bits 3:2 */                        \
+        "v_mov_b32_e32 %[d0], %[r4]\n\t"  /* NB 1: candidate r */                                      \
+        "v_mov_b32_e32 %[t1], 0xff\n\t"  /* lanes that hold no candidate's sum: never below cnt */     \
         "v_and_b32_e32 %[t0], 15, %[lane]\n\t"                                                         \
         "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
         "s_nop 1\n\t"  /* gfx950: a vector write of vcc, then 2 wait states before a vector read */    \
-        "v_cndmask_b32_e32 %[co1], %[t1], %[co1], vcc\n\t"                                             \
+        "v_cndmask_b32_e32 %[d0], %[t1], %[d0], vcc\n\t"                                               \
         "v_mov_b32_e32 %[q2v], %[q2]\n\t"  /* q.q, once per 16 lanes: the accumulator x.x starts from */ \
         "v_cndmask_b32_e32 %[q2v], 0, %[q2v], vcc\n\t"                                                 \
         "v_and_b32_e32 %[t0], 7, %[lane]\n\t"                                                          \
         "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
         "s_nop 1\n\t"                                                                                  \
-        "v_cndmask_b32_e32 %[co2], %[t1], %[co2], vcc\n\t"                                             \
+        "v_cndmask_b32_e32 %[d1], %[t1], %[d1], vcc\n\t"                                               \
         "v_and_b32_e32 %[t0], 3, %[lane]\n\t"                                                          \
         "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
         "s_nop 1\n\t"                                                                                  \
-        "v_cndmask_b32_e32 %[co4], %[t1], %[co4], vcc\n\t"                                             \
+        "v_cndmask_b32_e32 %[d2], %[t1], %[d2], vcc\n\t"                                               \
+        "v_lshl_or_b32 %[co], %[d1], 8, %[d0]\n\t"  /* one byte per round shape */                       \
+        "v_lshl_or_b32 %[co], %[d2], 16, %[co]\n\t"                                                      \
         "v_lshlrev_b32_e32 %[r4], 2, %[r4]\n\t"  /* 4 r: byte offset of candidate r in the id list */  \
         "v_and_b32_e32 %[t0], 8, %[lane]\n\t"                                                          \
         "v_cmp_ne_u32_e64 %[b3m], 0, %[t0]\n\t"                                                        \
@@ -494,7 +504,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "8:\n\t"                                                  \
         "s_sub_u32 %[pref], %[pref], 1\n\t"                       \
         "s_mul_i32 %[tmp], %[pref], %[rowb]\n\t"                  \
-        "v_add_u32_e32 %[t1], %[tmp], %[lane4]\n\t"               \
+        "v_lshl_add_u32 %[t1], %[lane], 2, %[tmp]\n\t"            \
         "v_mov_b32_e32 %[pnb], -1\n\t"                            \
         "s_mov_b64 exec, %[rowm]\n\t"                             \
         "global_load_dword %[pnb], %[t1], %[nbr]\n\t"             \
@@ -514,8 +524,8 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
     uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt), od = wmax;   // od: the tie list's distance
     // temporaries
-    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
-    uint64_t ad0, ad1, ad2, ad3;
+    uint32_t nb, pnb, vw, va, tag, r4, co, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint64_t ad0, ad1;    // row addresses, alternating by batch (a load has long read its address when the register's next turn comes)
     uint64_t um0, um1, g0, fresh, b3m, b2m;   // um0 / um1 double as the insertion's equality masks, fresh as the round's accept mask
     uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;   // klo doubles as the hop's node, sx / tmp as the shift's carries
     asm volatile(
@@ -525,12 +535,9 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "v_alignbit_b32 %[l1], %[l1], %[l1], 1\n\t"
         HNSW_HOP_CONSTANTS
         "s_mov_b32 %[pref], -1\n"
+        HNSW_ASM_ALIGN
         // ================================ one hop ================================
         "1:\n\t"
-#ifdef HNSW_ASM_PAD1
-        "s_nop 0\n\t"
-        "s_nop 0\n\t"
-#endif
 #ifdef HNSW_ASM_DEBUG
         "s_cmp_ge_u32 %[nh], %[maxh]\n\t"                                 // debugging: leave after maxh hops, the C++ loop goes on from here
         "s_cbranch_scc1 99f\n\t"
@@ -602,11 +609,11 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc), [od] "+&s"(od),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
-          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4), [q2v] "=&v"(q2v),
+          [co] "=&v"(co), [q2v] "=&v"(q2v),
           [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
           [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
           [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
-          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
+          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1),
           [um0] "=&s"(um0), [um1] "=&s"(um1), [g0] "=&s"(g0), [fresh] "=&s"(fresh),
           [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
           [pref] "=&s"(pref), [cnt] "=&s"(cnt),
@@ -825,8 +832,8 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     const uint32_t q2 = (uint32_t)uniform(cx.q2);
     uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
     uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt), od = wmax;   // od: the tie list's distance
-    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
-    uint64_t ad0, ad1, ad2, ad3;
+    uint32_t nb, pnb, vw, va, tag, r4, co, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint64_t ad0, ad1;    // row addresses, alternating by batch (a load has long read its address when the register's next turn comes)
     uint64_t um0, um1, um2, um3, fresh, b3m, b2m;
     uint32_t pref, cnt, sx, lastad, i, kd, klo, p, P, t, nw, tmp, mx0, mx1, mx2;
     asm volatile(
@@ -886,11 +893,11 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
           [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]), [l2] "+&v"(w.lo[2]), [l3] "+&v"(w.lo[3]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc), [od] "+&s"(od),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
-          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4), [q2v] "=&v"(q2v),
+          [co] "=&v"(co), [q2v] "=&v"(q2v),
           [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
           [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
           [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
-          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
+          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1),
           [um0] "=&s"(um0), [um1] "=&s"(um1), [um2] "=&s"(um2), [um3] "=&s"(um3), [fresh] "=&s"(fresh),
           [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
           [pref] "=&s"(pref), [cnt] "=&s"(cnt),
@@ -979,8 +986,8 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
     const uint32_t q2 = (uint32_t)uniform(cx.q2);
     uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
     uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt), od = wmax;   // od: the tie list's distance
-    uint32_t nb, pnb, vw, va, tag, r4, co1, co2, co4, lane4, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
-    uint64_t ad0, ad1, ad2, ad3;
+    uint32_t nb, pnb, vw, va, tag, r4, co, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint64_t ad0, ad1;    // row addresses, alternating by batch (a load has long read its address when the register's next turn comes)
     uint64_t um0, um1, fresh, b3m, b2m;    // um1: the visited filter's second compare only
     uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;
     asm volatile(
@@ -1016,11 +1023,11 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
         : [h0] "+&v"(w.hi[0]), [l0] "+&v"(w.lo[0]),
           [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc), [od] "+&s"(od),
           [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
-          [co1] "=&v"(co1), [co2] "=&v"(co2), [co4] "=&v"(co4), [lane4] "=&v"(lane4), [q2v] "=&v"(q2v),
+          [co] "=&v"(co), [q2v] "=&v"(q2v),
           [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
           [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
           [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
-          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1), [ad2] "=&v"(ad2), [ad3] "=&v"(ad3),
+          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1),
           [um0] "=&s"(um0), [um1] "=&s"(um1), [fresh] "=&s"(fresh),
           [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
           [pref] "=&s"(pref), [cnt] "=&s"(cnt),
