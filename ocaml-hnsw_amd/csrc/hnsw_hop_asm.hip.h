@@ -678,33 +678,6 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "s_cbranch_scc1 " NEXT "\n\t"                                   \
     "s_ff1_i32_b64 %[i], " UM "\n\t"                                \
     "v_readlane_b32 %[pref], " LS ", %[i]\n"
-// slot J moves by one whole position and takes slot J-1's last key in lane 0 (read BEFORE slot J-1 moves)
-#define HNSW_SHIFT_WHOLE(HJ, LJ, HJM1, LJM1)                        \
-    "v_readlane_b32 %[sx], " HJM1 ", 63\n\t"                        \
-    "v_readlane_b32 %[tmp], " LJM1 ", 63\n\t"                       \
-    "v_mov_b32_dpp " HJ ", " HJ " wave_shr:1" HNSW_DPP_ALL "\n\t"   \
-    "v_mov_b32_dpp " LJ ", " LJ " wave_shr:1" HNSW_DPP_ALL "\n\t"   \
-    "v_writelane_b32 " HJ ", %[sx], 0\n\t"                          \
-    "v_writelane_b32 " LJ ", %[tmp], 0\n\t"
-// the rank's slot moves from lane p on (EXEC narrowed; lane p keeps its value until the new key is written there)
-#define HNSW_SHIFT_FROM(HS, LS)                                     \
-    "s_lshl_b64 exec, -1, %[p]\n\t"                                 \
-    "v_mov_b32_dpp " HS ", " HS " wave_shr:1" HNSW_DPP_ALL "\n\t"   \
-    "v_mov_b32_dpp " LS ", " LS " wave_shr:1" HNSW_DPP_ALL "\n\t"   \
-    "s_mov_b64 exec, -1\n\t"                                        \
-    "s_mov_b32 m0, %[p]\n\t"                                        \
-    "v_writelane_b32 " HS ", %[kd], m0\n\t"                         \
-    "v_writelane_b32 " LS ", %[klo], m0\n\t"
-// rank inside slot S (BASE = 64 S): a member at this very distance -> general path (14); else P = BASE + keys below -> 11
-#define HNSW_RANK_IN_SLOT(LBL, HS, BASE)                            \
-    LBL ":\n\t"                                                     \
-    "v_cmp_eq_u32_e32 vcc, %[kd], " HS "\n\t"                       \
-    "s_cmp_lg_u64 vcc, 0\n\t"                                       \
-    "s_cbranch_scc1 14f\n\t"                                        \
-    "v_cmp_gt_u32_e32 vcc, %[kd], " HS "\n\t"                       \
-    "s_bcnt1_i32_b64 %[P], vcc\n\t"                                 \
-    "s_add_u32 %[P], %[P], " #BASE "\n\t"                           \
-    "s_branch 11f\n"
 // general path, per slot: keys below by distance, plus the members at this distance with a smaller id; the node itself
 // (flag bit either way) in W -> dup
 #define HNSW_RANK_GENERAL_SLOT(HS, LS)                              \
@@ -721,105 +694,294 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "s_and_b64 vcc, vcc, %[um0]\n\t"                                \
     "s_or_b64 %[um1], %[um1], vcc\n\t"
 
-#define HNSW_INSERT_LOOP4                                                                                                \
-    "10:\n\t"                                                                                                            \
-    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 19f\n"                                                                                               \
-    "110:\n\t"                                                                                                           \
-    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                   \
-    "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
-    "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
-    "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
-    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
-    "v_readlane_b32 %[nw], %[h3], 62\n\t"                                                                                \
-    "s_cmp_lt_u32 %[mx2], %[kd]\n\t"                                      /* the rank's slot, from the slots' maxima */  \
-    "s_cbranch_scc1 83f\n\t"                                                                                             \
-    "s_cmp_lt_u32 %[mx1], %[kd]\n\t"                                                                                     \
-    "s_cbranch_scc1 82f\n\t"                                                                                             \
-    "s_cmp_lt_u32 %[mx0], %[kd]\n\t"                                                                                     \
-    "s_cbranch_scc1 81f\n"                                                                                               \
-    HNSW_RANK_IN_SLOT("80", "%[h0]", 0)                                                                                  \
-    HNSW_RANK_IN_SLOT("81", "%[h1]", 64)                                                                                 \
-    HNSW_RANK_IN_SLOT("82", "%[h2]", 128)                                                                                \
-    HNSW_RANK_IN_SLOT("83", "%[h3]", 192)                                                                                \
-    "11:\n\t"                                                                                                            \
+// Four slots (ef 129..256).  The slot of the rank comes from the slots' maxima (scalar registers), then everything is
+// per slot: tie check, position (one compare + count), the cascade (slots above move whole and take their lower
+// neighbour's last key), the slot itself from the position on (v_cndmask_b32_dpp under an s_bfm mask, no EXEC writes).
+// The top slot's way is in line; slots 2, 1, 0, the general rank for distance ties (14; it re-enters at the shifts 8s1
+// with the full rank P) and the tie-list push are HNSW_INSERT_RARE4, behind the hop loop.
+#define HNSW_INSERT_LOOP4                                                                                                   \
+    "10:\n\t"                                                                                                               \
+    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 19f\n"                                                                                                  \
+    "110:\n\t"                                                                                                              \
+    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                      \
+    "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                               \
+    "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                               \
+    "v_readlane_b32 %[nw], %[h3], 62\n\t"                                                                                   \
+    "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */      \
+    "s_cmp_lt_u32 %[mx2], %[kd]\n\t"                                      /* the rank's slot, from the slots' maxima */     \
+    "s_cbranch_scc0 82f\n\t"                                                                                                \
+    "v_cmp_eq_u32_e32 vcc, %[kd], %[h3]\n\t"                                                                                \
+    "v_cmp_gt_u32_e64 %[um0], %[kd], %[h3]\n\t"                                                                             \
+    "s_cmp_lg_u64 vcc, 0\n\t"                                                                                               \
+    "s_cbranch_scc1 14f\n\t"                                              /* a member of W at this very distance */         \
+    "s_bcnt1_i32_b64 %[p], %[um0]\n"                                      /* rank inside the slot */                        \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
-    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
-    "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */      \
-    "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
-    "12:\n\t"                                                                                                            \
-    "s_and_b32 %[p], %[P], 63\n\t"                                                                                       \
-    "s_cmp_ge_u32 %[P], 192\n\t"                                                                                         \
-    "s_cbranch_scc1 86f\n\t"                                                                                             \
-    "s_cmp_ge_u32 %[P], 128\n\t"                                                                                         \
-    "s_cbranch_scc1 85f\n\t"                                                                                             \
-    "s_cmp_ge_u32 %[P], 64\n\t"                                                                                          \
-    "s_cbranch_scc1 84f\n\t"                                                                                             \
-    /* rank in slot 0 */                                                                                                 \
-    HNSW_SHIFT_WHOLE("%[h3]", "%[l3]", "%[h2]", "%[l2]")                                                                 \
-    HNSW_SHIFT_WHOLE("%[h2]", "%[l2]", "%[h1]", "%[l1]")                                                                 \
-    HNSW_SHIFT_WHOLE("%[h1]", "%[l1]", "%[h0]", "%[l0]")                                                                 \
-    HNSW_SHIFT_FROM("%[h0]", "%[l0]")                                                                                    \
-    "v_readlane_b32 %[mx0], %[h0], 63\n\t"                                                                               \
-    "v_readlane_b32 %[mx1], %[h1], 63\n\t"                                                                               \
-    "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                               \
-    "s_branch 17f\n"                                                                                                     \
-    "84:\n\t"                                                                                                            \
-    HNSW_SHIFT_WHOLE("%[h3]", "%[l3]", "%[h2]", "%[l2]")                                                                 \
-    HNSW_SHIFT_WHOLE("%[h2]", "%[l2]", "%[h1]", "%[l1]")                                                                 \
-    HNSW_SHIFT_FROM("%[h1]", "%[l1]")                                                                                    \
-    "v_readlane_b32 %[mx1], %[h1], 63\n\t"                                                                               \
-    "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                               \
-    "s_branch 17f\n"                                                                                                     \
-    "85:\n\t"                                                                                                            \
-    HNSW_SHIFT_WHOLE("%[h3]", "%[l3]", "%[h2]", "%[l2]")                                                                 \
-    HNSW_SHIFT_FROM("%[h2]", "%[l2]")                                                                                    \
-    "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                               \
-    "s_branch 17f\n"                                                                                                     \
-    "86:\n\t"                                                                                                            \
-    HNSW_SHIFT_FROM("%[h3]", "%[l3]")                                                                                    \
-    "17:\n\t"                                                                                                            \
-    "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
-    "18:\n\t"                                                                                                            \
-    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
-    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 110b\n\t"                                             /* the next accepted candidate */              \
-    "s_branch 19f\n"                                                                                                     \
-    /* rare: a member of W at exactly this distance: rank over all four slots, ids decide; the node itself in W: ignored */ \
-    "14:\n\t"                                                                                                            \
-    "s_mov_b32 %[P], 0\n\t"                                                                                              \
-    "s_mov_b64 %[um1], 0\n\t"                                                                                            \
-    HNSW_RANK_GENERAL_SLOT("%[h0]", "%[l0]")                                                                             \
-    HNSW_RANK_GENERAL_SLOT("%[h1]", "%[l1]")                                                                             \
-    HNSW_RANK_GENERAL_SLOT("%[h2]", "%[l2]")                                                                             \
-    HNSW_RANK_GENERAL_SLOT("%[h3]", "%[l3]")                                                                             \
-    "s_cmp_lg_u64 %[um1], 0\n\t"                                                                                         \
-    "s_cbranch_scc1 18b\n\t"                                              /* already in W */                             \
-    "s_branch 11b\n"                                                                                                     \
-    /* rare: the entry that falls off is at the new maximum's distance (see the two-slot loop) */                        \
-    "15:\n\t"                                                                                                            \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                       \
-    "s_cbranch_scc1 12b\n\t"                                                                                             \
-    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                 \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                         \
-    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
-    "s_mov_b32 %[od], %[nw]\n\t"                                        /* the distance the list is at */              \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
-    "s_cbranch_scc1 16f\n\t"                                                                                             \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
-    "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                                                                    \
-    "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                                                              \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                    \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                      \
-    "s_mov_b64 exec, 1\n\t"                                                                                              \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                           \
-    "s_mov_b64 exec, -1\n\t"                                                                                             \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                      \
-    "s_branch 12b\n"                                                                                                     \
-    "16:\n\t"                                                                                                            \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 12b\n"                                                                                                     \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 153f\n"                                               /* the entry falling off ties with it */          \
+    "831:\n\t"                                                                                                              \
+    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "v_cndmask_b32_dpp %[h3], %[h3], %[h3], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "v_cndmask_b32_dpp %[l3], %[l3], %[l3], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
+    "v_writelane_b32 %[h3], %[kd], m0\n\t"                                                                                  \
+    "v_writelane_b32 %[l3], %[klo], m0\n\t"                                                                                 \
+    "s_mov_b32 %[wmax], %[nw]\n"                                                                                            \
+    "18:\n\t"                                                                                                               \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                      \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 110b\n"                                               /* the next accepted candidate */                 \
     "19:\n\t"
+
+#define HNSW_INSERT_RARE4                                                                                                   \
+    "82:\n\t"                                                                                                               \
+    "s_cmp_lt_u32 %[mx1], %[kd]\n\t"                                                                                        \
+    "s_cbranch_scc0 81f\n\t"                                                                                                \
+    "v_cmp_eq_u32_e32 vcc, %[kd], %[h2]\n\t"                                                                                \
+    "v_cmp_gt_u32_e64 %[um0], %[kd], %[h2]\n\t"                                                                             \
+    "s_cmp_lg_u64 vcc, 0\n\t"                                                                                               \
+    "s_cbranch_scc1 14f\n\t"                                              /* a member of W at this very distance */         \
+    "s_bcnt1_i32_b64 %[p], %[um0]\n"                                      /* rank inside the slot */                        \
+    "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 152f\n"                                               /* the entry falling off ties with it */          \
+    "821:\n\t"                                                                                                              \
+    "v_readlane_b32 %[sx], %[h2], 63\n\t"                                                                                   \
+    "v_readlane_b32 %[tmp], %[l2], 63\n\t"                                                                                  \
+    "v_mov_b32_dpp %[h3], %[h3] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_mov_b32_dpp %[l3], %[l3] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_writelane_b32 %[h3], %[sx], 0\n\t"                                                                                   \
+    "v_writelane_b32 %[l3], %[tmp], 0\n\t"                                                                                  \
+    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "v_cndmask_b32_dpp %[h2], %[h2], %[h2], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "v_cndmask_b32_dpp %[l2], %[l2], %[l2], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
+    "v_writelane_b32 %[h2], %[kd], m0\n\t"                                                                                  \
+    "v_writelane_b32 %[l2], %[klo], m0\n\t"                                                                                 \
+    "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                                  \
+    "s_mov_b32 %[wmax], %[nw]\n\t"                                                                                          \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                      \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 110b\n\t"                                                                                               \
+    "s_branch 19b\n"                                                                                                        \
+    "81:\n\t"                                                                                                               \
+    "s_cmp_lt_u32 %[mx0], %[kd]\n\t"                                                                                        \
+    "s_cbranch_scc0 80f\n\t"                                                                                                \
+    "v_cmp_eq_u32_e32 vcc, %[kd], %[h1]\n\t"                                                                                \
+    "v_cmp_gt_u32_e64 %[um0], %[kd], %[h1]\n\t"                                                                             \
+    "s_cmp_lg_u64 vcc, 0\n\t"                                                                                               \
+    "s_cbranch_scc1 14f\n\t"                                              /* a member of W at this very distance */         \
+    "s_bcnt1_i32_b64 %[p], %[um0]\n"                                      /* rank inside the slot */                        \
+    "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 151f\n"                                               /* the entry falling off ties with it */          \
+    "811:\n\t"                                                                                                              \
+    "v_readlane_b32 %[sx], %[h2], 63\n\t"                                                                                   \
+    "v_readlane_b32 %[tmp], %[l2], 63\n\t"                                                                                  \
+    "v_mov_b32_dpp %[h3], %[h3] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_mov_b32_dpp %[l3], %[l3] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_writelane_b32 %[h3], %[sx], 0\n\t"                                                                                   \
+    "v_writelane_b32 %[l3], %[tmp], 0\n\t"                                                                                  \
+    "v_readlane_b32 %[sx], %[h1], 63\n\t"                                                                                   \
+    "v_readlane_b32 %[tmp], %[l1], 63\n\t"                                                                                  \
+    "v_mov_b32_dpp %[h2], %[h2] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_mov_b32_dpp %[l2], %[l2] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_writelane_b32 %[h2], %[sx], 0\n\t"                                                                                   \
+    "v_writelane_b32 %[l2], %[tmp], 0\n\t"                                                                                  \
+    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "v_cndmask_b32_dpp %[h1], %[h1], %[h1], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "v_cndmask_b32_dpp %[l1], %[l1], %[l1], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
+    "v_writelane_b32 %[h1], %[kd], m0\n\t"                                                                                  \
+    "v_writelane_b32 %[l1], %[klo], m0\n\t"                                                                                 \
+    "v_readlane_b32 %[mx1], %[h1], 63\n\t"                                                                                  \
+    "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                                  \
+    "s_mov_b32 %[wmax], %[nw]\n\t"                                                                                          \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                      \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 110b\n\t"                                                                                               \
+    "s_branch 19b\n"                                                                                                        \
+    "80:\n\t"                                                                                                               \
+    "v_cmp_eq_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                                \
+    "v_cmp_gt_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                             \
+    "s_cmp_lg_u64 vcc, 0\n\t"                                                                                               \
+    "s_cbranch_scc1 14f\n\t"                                              /* a member of W at this very distance */         \
+    "s_bcnt1_i32_b64 %[p], %[um0]\n"                                      /* rank inside the slot */                        \
+    "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 150f\n"                                               /* the entry falling off ties with it */          \
+    "801:\n\t"                                                                                                              \
+    "v_readlane_b32 %[sx], %[h2], 63\n\t"                                                                                   \
+    "v_readlane_b32 %[tmp], %[l2], 63\n\t"                                                                                  \
+    "v_mov_b32_dpp %[h3], %[h3] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_mov_b32_dpp %[l3], %[l3] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_writelane_b32 %[h3], %[sx], 0\n\t"                                                                                   \
+    "v_writelane_b32 %[l3], %[tmp], 0\n\t"                                                                                  \
+    "v_readlane_b32 %[sx], %[h1], 63\n\t"                                                                                   \
+    "v_readlane_b32 %[tmp], %[l1], 63\n\t"                                                                                  \
+    "v_mov_b32_dpp %[h2], %[h2] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_mov_b32_dpp %[l2], %[l2] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_writelane_b32 %[h2], %[sx], 0\n\t"                                                                                   \
+    "v_writelane_b32 %[l2], %[tmp], 0\n\t"                                                                                  \
+    "v_readlane_b32 %[sx], %[h0], 63\n\t"                                                                                   \
+    "v_readlane_b32 %[tmp], %[l0], 63\n\t"                                                                                  \
+    "v_mov_b32_dpp %[h1], %[h1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
+    "v_writelane_b32 %[h1], %[sx], 0\n\t"                                                                                   \
+    "v_writelane_b32 %[l1], %[tmp], 0\n\t"                                                                                  \
+    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "v_cndmask_b32_dpp %[h0], %[h0], %[h0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "v_cndmask_b32_dpp %[l0], %[l0], %[l0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
+    "v_writelane_b32 %[h0], %[kd], m0\n\t"                                                                                  \
+    "v_writelane_b32 %[l0], %[klo], m0\n\t"                                                                                 \
+    "v_readlane_b32 %[mx0], %[h0], 63\n\t"                                                                                  \
+    "v_readlane_b32 %[mx1], %[h1], 63\n\t"                                                                                  \
+    "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                                  \
+    "s_mov_b32 %[wmax], %[nw]\n\t"                                                                                          \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                      \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 110b\n\t"                                                                                               \
+    "s_branch 19b\n"                                                                                                        \
+    /* rare: a member of W at exactly this distance: rank over all four slots, ids decide; the node itself in W: ignored */ \
+    "14:\n\t"                                                                                                               \
+    "s_mov_b32 %[P], 0\n\t"                                                                                                 \
+    "s_mov_b64 %[um1], 0\n\t"                                                                                               \
+    HNSW_RANK_GENERAL_SLOT("%[h0]", "%[l0]")                                                                               \
+    HNSW_RANK_GENERAL_SLOT("%[h1]", "%[l1]")                                                                               \
+    HNSW_RANK_GENERAL_SLOT("%[h2]", "%[l2]")                                                                               \
+    HNSW_RANK_GENERAL_SLOT("%[h3]", "%[l3]")                                                                               \
+    "s_cmp_lg_u64 %[um1], 0\n\t"                                                                                            \
+    "s_cbranch_scc1 18b\n\t"                                              /* already in W */                                \
+    "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                                                                     \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 154f\n"                                                                                                 \
+    "141:\n\t"                                                                                                              \
+    "s_and_b32 %[p], %[P], 63\n\t"                                                                                          \
+    "s_cmp_ge_u32 %[P], 192\n\t"                                                                                            \
+    "s_cbranch_scc1 831b\n\t"                                                                                               \
+    "s_cmp_ge_u32 %[P], 128\n\t"                                                                                            \
+    "s_cbranch_scc1 821b\n\t"                                                                                               \
+    "s_cmp_ge_u32 %[P], 64\n\t"                                                                                             \
+    "s_cbranch_scc1 811b\n\t"                                                                                               \
+    "s_branch 801b\n"                                                                                                       \
+    /* rare: the entry that falls off is at the new maximum's distance (see the two-slot loop); one copy per way back */     \
+    "153:\n\t"                                                                                                              \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 831b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
+    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
+    "s_cbranch_scc1 831b\n\t"                                             /* expanded: gone for good */                     \
+    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
+    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
+    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
+    "s_cbranch_scc1 163f\n\t"                                                                                               \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
+    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
+    "s_mov_b64 exec, 1\n\t"                                                                                                 \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n\t"                                                                                                \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
+    "s_branch 831b\n"                                                                                                       \
+    "163:\n\t"                                                                                                              \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 831b\n"                                                                                                       \
+    "152:\n\t"                                                                                                              \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 821b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
+    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
+    "s_cbranch_scc1 821b\n\t"                                             /* expanded: gone for good */                     \
+    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
+    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
+    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
+    "s_cbranch_scc1 162f\n\t"                                                                                               \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
+    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
+    "s_mov_b64 exec, 1\n\t"                                                                                                 \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n\t"                                                                                                \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
+    "s_branch 821b\n"                                                                                                       \
+    "162:\n\t"                                                                                                              \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 821b\n"                                                                                                       \
+    "151:\n\t"                                                                                                              \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 811b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
+    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
+    "s_cbranch_scc1 811b\n\t"                                             /* expanded: gone for good */                     \
+    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
+    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
+    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
+    "s_cbranch_scc1 161f\n\t"                                                                                               \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
+    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
+    "s_mov_b64 exec, 1\n\t"                                                                                                 \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n\t"                                                                                                \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
+    "s_branch 811b\n"                                                                                                       \
+    "161:\n\t"                                                                                                              \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 811b\n"                                                                                                       \
+    "150:\n\t"                                                                                                              \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 801b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
+    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
+    "s_cbranch_scc1 801b\n\t"                                             /* expanded: gone for good */                     \
+    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
+    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
+    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
+    "s_cbranch_scc1 160f\n\t"                                                                                               \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
+    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
+    "s_mov_b64 exec, 1\n\t"                                                                                                 \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n\t"                                                                                                \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
+    "s_branch 801b\n"                                                                                                       \
+    "160:\n\t"                                                                                                              \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 801b\n"                                                                                                       \
+    "154:\n\t"                                                                                                              \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 141b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
+    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
+    "s_cbranch_scc1 141b\n\t"                                             /* expanded: gone for good */                     \
+    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
+    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
+    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
+    "s_cbranch_scc1 164f\n\t"                                                                                               \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
+    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
+    "s_mov_b64 exec, 1\n\t"                                                                                                 \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n\t"                                                                                                \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
+    "s_branch 141b\n"                                                                                                       \
+    "164:\n\t"                                                                                                              \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 141b\n"
 
 __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv, WList<4> &w, const WaveCtx &cx,
                                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
@@ -883,6 +1045,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
 #endif
         HNSW_HOP_ADJACENCY_MISS
         HNSW_HOP_ROUNDS_RARE
+        HNSW_INSERT_RARE4
         HNSW_HOP_TAIL
         // back to the flag-in-bit-0 form
         "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
@@ -911,69 +1074,76 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     n_dist = nd; n_hops = nh; status = st;
 }
 
-// ---- one slot (ef <= 64): no cascade, the rank is one compare + count -------------------------------------------------
-#define HNSW_INSERT_LOOP1                                                                                                \
-    "10:\n\t"                                                                                                            \
-    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 19f\n"                                                                                               \
-    "110:\n\t"                                                                                                           \
-    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                   \
-    "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                            \
-    "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                            \
-    "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                    \
-    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */   \
-    "v_readlane_b32 %[nw], %[h0], 62\n\t"                                                                                \
-    "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                          \
-    "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                             \
-    "s_bcnt1_i32_b64 %[p], vcc\n\t"                                       /* rank = keys at a smaller distance */       \
-    "s_cmp_lg_u64 %[um0], 0\n\t"                                                                                         \
-    "s_cbranch_scc1 14f\n"                                                /* members of W at this very distance */      \
-    "11:\n\t"                                                                                                            \
+// ---- one slot (ef <= 64): no cascade; the same steps as the two-slot loop's upper slot --------------------------------
+#define HNSW_INSERT_LOOP1                                                                                                   \
+    "10:\n\t"                                                                                                               \
+    "s_cmp_eq_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 19f\n"                                                                                                  \
+    "110:\n\t"                                                                                                              \
+    "s_ff1_i32_b64 %[i], %[fresh]\n\t"                                                                                      \
+    "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"                                                                               \
+    "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                               \
+    "v_readlane_b32 %[nw], %[h0], 62\n\t"                                                                                   \
+    "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                             \
+    "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                                \
+    "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */      \
+    "s_cmp_lg_u64 %[um0], 0\n\t"                                                                                            \
+    "s_cbranch_scc1 14f\n\t"                                              /* members of W at this very distance */          \
+    "s_bcnt1_i32_b64 %[p], vcc\n"                                         /* rank = keys at a smaller distance */           \
+    "11:\n\t"                                                                                                               \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
-    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                    \
-    "s_cbranch_scc1 15f\n\t"                                              /* the entry falling off ties with it */      \
-    "s_mov_b32 %[oc], 0\n"                                                /* max(W).d dropped: the tie list is dead */   \
-    "12:\n\t"                                                                                                            \
-    HNSW_SHIFT_FROM("%[h0]", "%[l0]")                                                                                    \
-    "s_mov_b32 %[wmax], %[nw]\n"                                                                                         \
-    "18:\n\t"                                                                                                            \
-    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                   \
-    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 110b\n\t"                                             /* the next accepted candidate */              \
-    "s_branch 19f\n"                                                                                                     \
-    "14:\n\t"                                                                                                            \
-    "v_and_b32_e32 %[t0], 0x7fffffff, %[l0]\n\t"                                                                         \
-    "v_cmp_gt_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                            \
-    "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
-    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                      \
-    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                     \
-    "v_cmp_eq_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                            \
-    "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                     \
-    "s_cbranch_scc1 18b\n\t"                                              /* already in W */                             \
-    "s_branch 11b\n"                                                                                                     \
-    "15:\n\t"                                                                                                            \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                       \
-    "s_cbranch_scc1 12b\n\t"                                                                                             \
-    "v_readlane_b32 %[t], %[l0], 63\n\t"                                                                                 \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                         \
-    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                  \
-    "s_mov_b32 %[od], %[nw]\n\t"                                        /* the distance the list is at */              \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                         \
-    "s_cbranch_scc1 16f\n\t"                                                                                             \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                        \
-    "s_lshl_b32 %[tmp], %[oc], 2\n\t"                                                                                    \
-    "s_add_u32 %[tmp], %[tmp], %[cand]\n\t"                                                                              \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                    \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                      \
-    "s_mov_b64 exec, 1\n\t"                                                                                              \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                           \
-    "s_mov_b64 exec, -1\n\t"                                                                                             \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                      \
-    "s_branch 12b\n"                                                                                                     \
-    "16:\n\t"                                                                                                            \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 12b\n"                                                                                                     \
+    "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
+    "s_cbranch_scc1 15f\n"                                                /* the entry falling off ties with it */          \
+    "12:\n\t"                                                                                                               \
+    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "v_cndmask_b32_dpp %[h0], %[h0], %[h0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "v_cndmask_b32_dpp %[l0], %[l0], %[l0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
+    "v_writelane_b32 %[h0], %[kd], m0\n\t"                                                                                  \
+    "v_writelane_b32 %[l0], %[klo], m0\n\t"                                                                                 \
+    "s_mov_b32 %[wmax], %[nw]\n"                                                                                            \
+    "18:\n\t"                                                                                                               \
+    "s_bitset0_b64 %[fresh], %[i]\n\t"                                                                                      \
+    "s_cmp_lg_u64 %[fresh], 0\n\t"                                                                                          \
+    "s_cbranch_scc1 110b\n"                                               /* the next accepted candidate */                 \
     "19:\n\t"
+
+#define HNSW_INSERT_RARE1                                                                                                   \
+    "14:\n\t"                                                                                                               \
+    "s_bcnt1_i32_b64 %[p], vcc\n\t"                                                                                         \
+    "v_and_b32_e32 %[t0], 0x7fffffff, %[l0]\n\t"                                                                            \
+    "v_cmp_gt_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                               \
+    "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                        \
+    "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                                                         \
+    "s_add_u32 %[p], %[p], %[t]\n\t"                                                                                        \
+    "v_cmp_eq_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                               \
+    "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                        \
+    "s_cbranch_scc1 18b\n\t"                                              /* already in W */                                \
+    "s_branch 11b\n"                                                                                                        \
+    "15:\n\t"                                                                                                               \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 12b\n\t"                                              /* W still holds dummies: nothing real falls off */ \
+    "v_readlane_b32 %[t], %[l0], 63\n\t"                                                                                    \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
+    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                     \
+    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
+    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
+    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
+    "s_cbranch_scc1 16f\n\t"                                                                                                \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
+    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
+    "s_mov_b64 exec, 1\n\t"                                                                                                 \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n\t"                                                                                                \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
+    "s_branch 12b\n"                                                                                                        \
+    "16:\n\t"                                                                                                               \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch 12b\n"
 
 __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv, WList<1> &w, const WaveCtx &cx,
                                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
@@ -1017,6 +1187,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
         HNSW_HOP_NEXT_ROUND
         HNSW_HOP_ADJACENCY_MISS
         HNSW_HOP_ROUNDS_RARE
+        HNSW_INSERT_RARE1
         HNSW_HOP_TAIL
         // back to the flag-in-bit-0 form
         "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
