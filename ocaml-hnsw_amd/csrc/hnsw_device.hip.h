@@ -749,10 +749,24 @@ __device__ __forceinline__ int eval_round(const IndexView &iv, const float4 (&qv
 // repeat until no change.  No visited set (argument ignored, :493).  Same row evaluation as the layer
 // search (keys stay in registers: lane order = row order, so the first lane holding the minimum is the
 // first neighbour in row order that attains it); the upper-row lookup is one 8-byte load.
+#if HNSW_ASM_LOOP
+// the same descent instruction by instruction for C2's shape (hnsw_hop_asm.hip.h)
+__device__ __forceinline__ void greedy_descend_bytes_l2_asm(const IndexView &iv, int from, int to, int &cur, uint32_t &cur_key,
+                                                            const WaveCtx &cx, uint32_t &n_dist);
+#endif
 template <int NCH, int RB, int METRIC, int ROWS = -1>
 __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4 (&qv)[NCH], int from,
                                                int to, int &cur, uint32_t &cur_key, const WaveCtx &cx,
                                                uint32_t &n_dist) {
+#if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING)
+    if constexpr (NCH == 2 && METRIC == 0 && ROWS == 2) {
+        // upper rows of at most 16 neighbours (M <= 16), a byte-valued query, tables the 32-bit offsets reach
+        if (cx.qint && iv.SU <= 16 && (uint64_t)iv.n * (uint64_t)iv.SU < (1ull << 28)) {
+            greedy_descend_bytes_l2_asm(iv, from, to, cur, cur_key, cx, n_dist);
+            return;
+        }
+    }
+#endif
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
     for (int layer = from; layer >= to; --layer) {
         for (;;) {

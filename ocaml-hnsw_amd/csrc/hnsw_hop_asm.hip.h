@@ -1212,4 +1212,152 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
     n_dist = nd; n_hops = nh; status = st;
 }
 
+
+// =====================================================================================================================
+// The descent through the upper layers (greedy_descend; Ohnsw.search_one, lib/ohnsw.ml:492-508) for the same shape:
+// byte rows of 65..128 dimensions, byte-valued query, L2, upper rows of at most 16 neighbours.  One hop = the node's
+// {row offset, level} by two scalar loads, its row (one dword per lane), the 16 vectors as ONE round of four batches --
+// no compaction: candidate j is lane j of the row, a hole or padding (-1) is evaluated on row 0 and masked out -- then
+// the nearest of the candidates strictly below the current key, the first in row order among equals (:502).  n_dist
+// counts the valid neighbours of every row read, as the C++ loop does.  C2's 10 k batch: ordering pre-pass 52 -> 45 us,
+// of which the descent below the top layer is 20 us, two launches and the sort the rest.  (Fetching every candidate's
+// {row offset, level} together with its vector -- two dependent loads per hop instead of three -- measured no different.)
+// =====================================================================================================================
+#define HNSW_DESCENT_ROUND16 \
+        "v_lshl_add_u32 %[t0], %[r4], 2, %[cand]\n\t"                              \
+        "ds_read_b32 %[id0], %[t0]\n\t"                                            \
+        "ds_read_b32 %[id1], %[t0] offset:4\n\t"                                   \
+        "ds_read_b32 %[id2], %[t0] offset:8\n\t"                                   \
+        "ds_read_b32 %[id3], %[t0] offset:12\n\t"                                  \
+        "s_waitcnt lgkmcnt(3)\n\t"                                                 \
+        "v_max_i32_e32 %[t1], 0, %[id0]\n\t"                                       \
+        HNSW_ROW_LOAD("%[t1]", "%[ad0]", "%[d0]", "%[d1]")                         \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                 \
+        "v_max_i32_e32 %[t1], 0, %[id1]\n\t"                                       \
+        HNSW_ROW_LOAD("%[t1]", "%[ad1]", "%[d2]", "%[d3]")                         \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                 \
+        "v_max_i32_e32 %[t1], 0, %[id2]\n\t"                                       \
+        HNSW_ROW_LOAD("%[t1]", "%[ad0]", "%[d4]", "%[d5]")                         \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                 \
+        "v_max_i32_e32 %[t1], 0, %[id3]\n\t"                                       \
+        HNSW_ROW_LOAD("%[t1]", "%[ad1]", "%[d6]", "%[d7]")                         \
+        "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"                     \
+        "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"                     \
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"                     \
+        "s_waitcnt vmcnt(6)\n\t"                                                   \
+        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")                                       \
+        "s_waitcnt vmcnt(4)\n\t"                                                   \
+        HNSW_DOTS("%[d2]", "%[d3]", "%[tb]")                                       \
+        "s_waitcnt vmcnt(2)\n\t"                                                   \
+        HNSW_COMBINE("%[d0]", "%[ta]")                                             \
+        HNSW_DOTS("%[d4]", "%[d5]", "%[ta]")                                       \
+        "s_waitcnt vmcnt(0)\n\t"                                                   \
+        HNSW_COMBINE("%[d2]", "%[tb]")                                             \
+        HNSW_DOTS("%[d6]", "%[d7]", "%[tb]")                                       \
+        HNSW_COMBINE("%[d4]", "%[ta]")                                             \
+        "s_nop 2\n\t"                                                              \
+        HNSW_COMBINE("%[d6]", "%[tb]")                                             \
+        "v_cndmask_b32_e64 %[ta], %[d0], %[d4], %[b3m]\n\t"                        \
+        "v_cndmask_b32_e64 %[d1], %[d4], %[d0], %[b3m]\n\t"                        \
+        "v_cndmask_b32_e64 %[tb], %[d2], %[d6], %[b3m]\n\t"                        \
+        "v_cndmask_b32_e64 %[d3], %[d6], %[d2], %[b3m]\n\t"                        \
+        "v_add_u32_dpp %[ta], %[d1], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"           \
+        "s_nop 0\n\t"                                                              \
+        "v_add_u32_dpp %[tb], %[d3], %[tb] row_ror:8" HNSW_DPP_BC "\n\t"           \
+        "v_cndmask_b32_e64 %[d0], %[ta], %[tb], %[b2m]\n\t"                        \
+        "v_cndmask_b32_e64 %[d1], %[tb], %[ta], %[b2m]\n\t"                        \
+        "v_cmp_lt_i32_e64 %[um0], -1, %[cid]\n\t"          /* a real neighbour */  \
+        "v_cmp_gt_u32_sdwa %[um1], %[c16], %[co] src0_sel:DWORD src1_sel:BYTE_2\n\t"  /* a lane that holds a sum */ \
+        "v_add_u32_dpp %[d0], %[d1], %[d0] row_half_mirror" HNSW_DPP_BC "\n\t"     \
+        "s_nop 1\n\t"                                                              \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t" \
+        "s_nop 1\n\t"                                                              \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t" \
+        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"
+
+__device__ __forceinline__ void greedy_descend_bytes_l2_asm(const IndexView &iv, int from, int to, int &cur_io, uint32_t &cur_key,
+                                                            const WaveCtx &cx, uint32_t &n_dist) {
+    const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
+    const uint64_t nbrU = (uint64_t)(uintptr_t)iv.nbrU, uref = (uint64_t)(uintptr_t)iv.upper_ref;
+    const uint64_t rowm = iv.SU >= 64 ? ~0ull : ((1ull << iv.SU) - 1ull);
+    const uint32_t su4 = (uint32_t)iv.SU * 4u, st8 = (uint32_t)iv.stride8, cand = lds_offset(cx.cand_id);
+    const uint32_t q2 = (uint32_t)uniform(cx.q2), c16 = 16u;
+    uint32_t cur = (uint32_t)uniform(cur_io), kcur = (uint32_t)uniform((int)cur_key), nd = (uint32_t)uniform((int)n_dist);
+    uint32_t layer = (uint32_t)uniform(from), lto = (uint32_t)uniform(to);
+    uint32_t nb, r4, co, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
+    uint64_t ad0, ad1;
+    uint64_t um0, um1, fresh, b3m, b2m;
+    uint32_t lm1, o8, off, lvl, cnt, i, kd, best, bi;
+    asm volatile(
+        HNSW_HOP_CONSTANTS
+        "s_cmp_lt_i32 %[layer], %[lto]\n\t"
+        "s_cbranch_scc1 9f\n"
+        // ---- one layer
+        "1:\n\t"
+        "s_sub_u32 %[lm1], %[layer], 1\n"
+        // ---- one hop: the node's rows start at off, it has lvl of them
+        "2:\n\t"
+        "s_lshl_b32 %[o8], %[cur], 3\n\t"
+        "s_load_dword %[off], %[uref], %[o8]\n\t"
+        "s_add_u32 %[o8], %[o8], 4\n\t"
+        "s_load_dword %[lvl], %[uref], %[o8]\n\t"
+        "v_mov_b32_e32 %[nb], -1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_cmp_gt_i32 %[layer], %[lvl]\n\t"                               // not on this layer (never in a consistent graph): an empty row
+        "s_cbranch_scc1 8f\n\t"
+        "s_add_u32 %[off], %[off], %[lm1]\n\t"
+        "s_mul_i32 %[off], %[off], %[su4]\n\t"                            // byte offset of the row (the caller checked the table's size)
+        "v_lshl_add_u32 %[t0], %[lane], 2, %[off]\n\t"
+        "s_mov_b64 exec, %[rowm]\n\t"
+        "global_load_dword %[nb], %[t0], %[nbrU]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_lshl_add_u32 %[t1], %[lane], 2, %[cand]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "ds_write_b32 %[t1], %[nb]\n\t"                                   // candidate j = lane j of the row
+        "v_cmp_lt_i32_e32 vcc, -1, %[nb]\n\t"
+        "s_bcnt1_i32_b64 %[cnt], vcc\n\t"
+        "s_cbranch_scc0 8f\n\t"                                           // no neighbour at all
+        "s_add_u32 %[nd], %[nd], %[cnt]\n\t"
+        HNSW_DESCENT_ROUND16
+        "v_cmp_gt_u32_e32 vcc, %[kcur], %[ckey]\n\t"                      // strictly closer than the current node (:502)
+        "s_and_b64 %[um0], %[um0], %[um1]\n\t"
+        "s_and_b64 %[fresh], %[um0], vcc\n\t"
+        "s_cbranch_scc0 8f\n\t"                                           // none: this layer is done
+        "s_mov_b32 %[best], %[kcur]\n"
+        "3:\n\t"                                                          // the nearest of them, the first in row order among equals
+        "s_ff1_i32_b64 %[i], %[fresh]\n\t"
+        "v_readlane_b32 %[kd], %[ckey], %[i]\n\t"
+        "s_bitset0_b64 %[fresh], %[i]\n\t"
+        "s_cmp_lt_u32 %[kd], %[best]\n\t"
+        "s_cbranch_scc0 4f\n\t"
+        "s_mov_b32 %[best], %[kd]\n\t"
+        "s_mov_b32 %[bi], %[i]\n"
+        "4:\n\t"
+        "s_cmp_lg_u64 %[fresh], 0\n\t"
+        "s_cbranch_scc1 3b\n\t"
+        "v_readlane_b32 %[cur], %[cid], %[bi]\n\t"
+        "s_mov_b32 %[kcur], %[best]\n\t"
+        "s_branch 2b\n"
+        "8:\n\t"                                                          // next layer down
+        "s_sub_u32 %[layer], %[layer], 1\n\t"
+        "s_cmp_ge_i32 %[layer], %[lto]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "9:\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [cur] "+&s"(cur), [kcur] "+&s"(kcur), [nd] "+&s"(nd), [layer] "+&s"(layer),
+          [nb] "=&v"(nb), [r4] "=&v"(r4), [co] "=&v"(co), [q2v] "=&v"(q2v),
+          [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
+          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
+          [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1),
+          [um0] "=&s"(um0), [um1] "=&s"(um1), [fresh] "=&s"(fresh), [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
+          [lm1] "=&s"(lm1), [o8] "=&s"(o8), [off] "=&s"(off), [lvl] "=&s"(lvl), [cnt] "=&s"(cnt), [i] "=&s"(i), [kd] "=&s"(kd),
+          [best] "=&s"(best), [bi] "=&s"(bi)
+        : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
+          [nbrU] "s"(nbrU), [uref] "s"(uref), [rowm] "s"(rowm), [su4] "s"(su4), [st8] "s"(st8), [cand] "s"(cand), [q2] "s"(q2),
+          [c16] "s"(c16), [lto] "s"(lto)
+        : "vcc", "scc", "memory");
+    cur_io = (int)cur; cur_key = kcur; n_dist = nd;
+}
+
 } // namespace hnsw_dev
