@@ -138,13 +138,12 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
     "s_cbranch_scc1 15f\n"                                                /* the entry falling off ties with it */          \
     "12:\n\t"                                                                                                               \
-    "s_bcnt1_i32_b64 %[p], vcc\n\t"                                       /* upper-slot keys below: any -> the rank is there */ \
+    "s_bcnt1_i32_b64 m0, vcc\n\t"                                         /* upper-slot keys below: any -> the rank is there */ \
     "s_cbranch_scc0 13f\n"                                                                                                  \
     "120:\n\t"                                                            /* upper slot from lane p (bits 5:0) on */        \
-    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "s_bfm_b64 vcc, m0, 0\n\t"                                            /* lanes below m0 keep their keys */               \
     "v_cndmask_b32_dpp %[h1], %[h1], %[h1], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
     "v_cndmask_b32_dpp %[l1], %[l1], %[l1], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
-    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
     "v_writelane_b32 %[h1], %[kd], m0\n\t"                                                                                  \
     "v_writelane_b32 %[l1], %[klo], m0\n\t"                                                                                 \
     "s_mov_b32 %[wmax], %[nw]\n"                                                                                            \
@@ -156,20 +155,19 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 
 #define HNSW_INSERT_RARE                                                                                                    \
     "13:\n\t"                                                             /* no upper-slot key below: the rank is the lower slot's count */ \
-    "s_bcnt1_i32_b64 %[p], %[g0]\n\t"                                                                                       \
-    "s_bitcmp1_b32 %[p], 6\n\t"                                                                                             \
+    "s_bcnt1_i32_b64 m0, %[g0]\n\t"                                                                                         \
+    "s_bitcmp1_b32 m0, 6\n\t"                                                                                               \
     "s_cbranch_scc1 120b\n"                                               /* all 64 below: lane 0 of the upper slot (p & 63 = 0) */ \
     "130:\n\t"                                                            /* lower slot from lane p on; the upper slot moves whole */ \
     "v_readlane_b32 %[sx], %[h0], 63\n\t"                                                                                   \
     "v_readlane_b32 %[tmp], %[l0], 63\n\t"                                                                                  \
     "v_mov_b32_dpp %[h1], %[h1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
     "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
-    "s_bfm_b64 vcc, %[p], 0\n\t"                                                                                            \
+    "s_bfm_b64 vcc, m0, 0\n\t"                                                                                              \
     "v_cndmask_b32_dpp %[h0], %[h0], %[h0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
     "v_cndmask_b32_dpp %[l0], %[l0], %[l0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
     "v_writelane_b32 %[h1], %[sx], 0\n\t"                                                                                   \
     "v_writelane_b32 %[l1], %[tmp], 0\n\t"                                                                                  \
-    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
     "v_writelane_b32 %[h0], %[kd], m0\n\t"                                                                                  \
     "v_writelane_b32 %[l0], %[klo], m0\n\t"                                                                                 \
     "s_mov_b32 %[wmax], %[nw]\n\t"                                                                                          \
@@ -205,6 +203,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
     "s_cbranch_scc1 151f\n"                                                                                                 \
     "141:\n\t"                                                                                                              \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
     "s_cmp_lt_u32 %[p], 64\n\t"                                                                                             \
     "s_cbranch_scc1 130b\n\t"                                                                                               \
     "s_branch 120b\n"                                                                                                       \
@@ -275,19 +274,19 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_HOP_ADJACENCY \
         "4:\n\t"                            \
         "s_add_u32 %[nh], %[nh], 1\n\t"     \
-        "s_cmp_lg_u32 %[klo], %[pref]\n\t"  \
+        "s_cmp_lg_u32 %[kd], %[pref]\n\t"   \
         "s_cbranch_scc1 44f\n\t"            \
         HNSW_ASM_COUNT_HIT                  \
         "s_waitcnt vmcnt(0)\n\t"            \
         "v_mov_b32_e32 %[nb], %[pnb]\n"
 #define HNSW_HOP_ADJACENCY_MISS \
         "44:\n\t"                                                                                                             \
-        "s_mul_i32 %[tmp], %[klo], %[rowb]\n\t"  /* byte offset of the row (the caller checked that the table is < 4 GiB) */  \
+        "s_mul_i32 %[tmp], %[kd], %[rowb]\n\t"   /* (id + 1) rows: the base is one row early; the caller checked the table's size */ \
         "v_lshl_add_u32 %[t0], %[lane], 2, %[tmp]\n\t"                                                                        \
         "s_waitcnt vmcnt(0)\n\t"  /* a wrong guess still in flight is drained first (its target is pnb) */                    \
         "v_mov_b32_e32 %[nb], -1\n\t"                                                                                         \
         "s_mov_b64 exec, %[rowm]\n\t"                                                                                         \
-        "global_load_dword %[nb], %[t0], %[nbr]\n\t"                                                                          \
+        "global_load_dword %[nb], %[t0], %[nbrm]\n\t"                                                                          \
         "s_mov_b64 exec, -1\n\t"                                                                                              \
         "s_waitcnt vmcnt(0)\n\t"                                                                                              \
         "s_branch 6b\n"
@@ -322,8 +321,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "ds_write_b32 %[t0], %[nb]\n\t"                                                \
         "s_mov_b64 exec, -1\n\t"                                                       \
         "s_add_u32 %[nd], %[nd], %[cnt]\n\t"                                           \
-        "s_lshl2_add_u32 %[lastad], %[cnt], %[cand]\n\t"                               \
-        "s_sub_u32 %[lastad], %[lastad], 4\n\t"                                        \
+        "s_lshl2_add_u32 %[lastad], %[cnt], %[candm4]\n\t"                             \
         "s_mov_b32 %[sx], %[cand]\n"                                                   
 
 // a list longer than one round (rare): the next candidate's address from what is left, then the next round
@@ -459,7 +457,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                           \
         "ds_read_b32 %[t0], %[t0] offset:768\n\t"                                   \
         "s_waitcnt lgkmcnt(0)\n\t"                                                  \
-        "v_readfirstlane_b32 %[klo], %[t0]\n\t"                                     \
+        "v_readfirstlane_b32 %[kd], %[t0]\n\t"                                      \
+        "s_add_u32 %[kd], %[kd], 1\n\t"  /* the list holds node ids */                \
         "s_mov_b64 %[um0], 0\n\t"                                                   \
         "s_mov_b64 %[um1], 0\n\t"                                                   \
         "s_branch 4b\n"                                                             \
@@ -502,12 +501,11 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 // requested into pnb beside this hop's vectors
 #define HNSW_HOP_PREFETCH_LOAD \
         "8:\n\t"                                                  \
-        "s_sub_u32 %[pref], %[pref], 1\n\t"                       \
         "s_mul_i32 %[tmp], %[pref], %[rowb]\n\t"                  \
         "v_lshl_add_u32 %[t1], %[lane], 2, %[tmp]\n\t"            \
         "v_mov_b32_e32 %[pnb], -1\n\t"                            \
         "s_mov_b64 exec, %[rowm]\n\t"                             \
-        "global_load_dword %[pnb], %[t1], %[nbr]\n\t"             \
+        "global_load_dword %[pnb], %[t1], %[nbrm]\n\t"             \
         "s_mov_b64 exec, -1\n"                                    \
         "9:\n\t"
 
@@ -515,7 +513,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, WList<2> &w, const WaveCtx &cx,
                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status, uint32_t maxhops = 0xFFFFFFFFu) {
     const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
-    const uint64_t nbr = (uint64_t)(uintptr_t)iv.nbr0;
+    const uint64_t nbrm = (uint64_t)(uintptr_t)iv.nbr0 - 4ull * (uint64_t)iv.S0;   // one row before the table: rows are addressed by id + 1
     const uint64_t rowm = iv.S0 >= 64 ? ~0ull : ((1ull << iv.S0) - 1ull);
     const uint32_t rowb = (uint32_t)iv.S0 * 4u, st8 = (uint32_t)iv.stride8;
     const uint32_t vtb = lds_offset(cx.vt), cand = lds_offset(cx.cand_id);
@@ -527,7 +525,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     uint32_t nb, pnb, vw, va, tag, r4, co, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
     uint64_t ad0, ad1;    // row addresses, alternating by batch (a load has long read its address when the register's next turn comes)
     uint64_t um0, um1, g0, fresh, b3m, b2m;   // um0 / um1 double as the insertion's equality masks, fresh as the round's accept mask
-    uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;   // klo doubles as the hop's node, sx / tmp as the shift's carries
+    uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;   // kd doubles as the hop's node (its low key half, id + 1), sx / tmp as the shift's carries
     asm volatile(
         // low key halves inside the loop: id + 1 with the expanded flag in bit 31 (a rotation of the (id + 1) << 1 | flag the
         // rest of the kernel keeps): the unexpanded members are the non-negative ones, a node id is one subtraction away
@@ -555,8 +553,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
         "s_mov_b32 m0, %[i]\n\t"
         "s_or_b32 %[t], %[kd], 0x80000000\n\t"
         "v_writelane_b32 %[l0], %[t], m0\n"
-        "3:\n\t"
-        "s_sub_u32 %[klo], %[kd], 1\n"                                       // node id
+        "3:\n"                                                              // kd = the node's low key half, id + 1
         HNSW_HOP_ADJACENCY
         HNSW_HOP_FILTER_ISSUE
         HNSW_PROBE(1)
@@ -620,8 +617,8 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
           [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t),
           [nw] "=&s"(nw), [tmp] "=&s"(tmp)
         : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
-          [nbr] "s"(nbr), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
-          [cand] "s"(cand), [q2] "s"(q2)
+          [nbrm] "s"(nbrm), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
+          [cand] "s"(cand), [candm4] "s"(cand - 4u), [q2] "s"(q2)
 #ifdef HNSW_ASM_DEBUG
           , [maxh] "s"(maxhops)
 #endif
@@ -716,15 +713,14 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_cmp_gt_u32_e64 %[um0], %[kd], %[h3]\n\t"                                                                             \
     "s_cmp_lg_u64 vcc, 0\n\t"                                                                                               \
     "s_cbranch_scc1 14f\n\t"                                              /* a member of W at this very distance */         \
-    "s_bcnt1_i32_b64 %[p], %[um0]\n"                                      /* rank inside the slot */                        \
+    "s_bcnt1_i32_b64 m0, %[um0]\n"                                        /* rank inside the slot */                        \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
     "s_cbranch_scc1 153f\n"                                               /* the entry falling off ties with it */          \
     "831:\n\t"                                                                                                              \
-    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "s_bfm_b64 vcc, m0, 0\n\t"                                            /* lanes below m0 keep their keys */               \
     "v_cndmask_b32_dpp %[h3], %[h3], %[h3], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
     "v_cndmask_b32_dpp %[l3], %[l3], %[l3], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
-    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
     "v_writelane_b32 %[h3], %[kd], m0\n\t"                                                                                  \
     "v_writelane_b32 %[l3], %[klo], m0\n\t"                                                                                 \
     "s_mov_b32 %[wmax], %[nw]\n"                                                                                            \
@@ -742,7 +738,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_cmp_gt_u32_e64 %[um0], %[kd], %[h2]\n\t"                                                                             \
     "s_cmp_lg_u64 vcc, 0\n\t"                                                                                               \
     "s_cbranch_scc1 14f\n\t"                                              /* a member of W at this very distance */         \
-    "s_bcnt1_i32_b64 %[p], %[um0]\n"                                      /* rank inside the slot */                        \
+    "s_bcnt1_i32_b64 m0, %[um0]\n"                                        /* rank inside the slot */                        \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
     "s_cbranch_scc1 152f\n"                                               /* the entry falling off ties with it */          \
@@ -753,10 +749,9 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_mov_b32_dpp %[l3], %[l3] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
     "v_writelane_b32 %[h3], %[sx], 0\n\t"                                                                                   \
     "v_writelane_b32 %[l3], %[tmp], 0\n\t"                                                                                  \
-    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "s_bfm_b64 vcc, m0, 0\n\t"                                            /* lanes below m0 keep their keys */               \
     "v_cndmask_b32_dpp %[h2], %[h2], %[h2], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
     "v_cndmask_b32_dpp %[l2], %[l2], %[l2], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
-    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
     "v_writelane_b32 %[h2], %[kd], m0\n\t"                                                                                  \
     "v_writelane_b32 %[l2], %[klo], m0\n\t"                                                                                 \
     "v_readlane_b32 %[mx2], %[h2], 63\n\t"                                                                                  \
@@ -772,7 +767,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_cmp_gt_u32_e64 %[um0], %[kd], %[h1]\n\t"                                                                             \
     "s_cmp_lg_u64 vcc, 0\n\t"                                                                                               \
     "s_cbranch_scc1 14f\n\t"                                              /* a member of W at this very distance */         \
-    "s_bcnt1_i32_b64 %[p], %[um0]\n"                                      /* rank inside the slot */                        \
+    "s_bcnt1_i32_b64 m0, %[um0]\n"                                        /* rank inside the slot */                        \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
     "s_cbranch_scc1 151f\n"                                               /* the entry falling off ties with it */          \
@@ -789,10 +784,9 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_mov_b32_dpp %[l2], %[l2] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
     "v_writelane_b32 %[h2], %[sx], 0\n\t"                                                                                   \
     "v_writelane_b32 %[l2], %[tmp], 0\n\t"                                                                                  \
-    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "s_bfm_b64 vcc, m0, 0\n\t"                                            /* lanes below m0 keep their keys */               \
     "v_cndmask_b32_dpp %[h1], %[h1], %[h1], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
     "v_cndmask_b32_dpp %[l1], %[l1], %[l1], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
-    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
     "v_writelane_b32 %[h1], %[kd], m0\n\t"                                                                                  \
     "v_writelane_b32 %[l1], %[klo], m0\n\t"                                                                                 \
     "v_readlane_b32 %[mx1], %[h1], 63\n\t"                                                                                  \
@@ -807,7 +801,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_cmp_gt_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                             \
     "s_cmp_lg_u64 vcc, 0\n\t"                                                                                               \
     "s_cbranch_scc1 14f\n\t"                                              /* a member of W at this very distance */         \
-    "s_bcnt1_i32_b64 %[p], %[um0]\n"                                      /* rank inside the slot */                        \
+    "s_bcnt1_i32_b64 m0, %[um0]\n"                                        /* rank inside the slot */                        \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
     "s_cbranch_scc1 150f\n"                                               /* the entry falling off ties with it */          \
@@ -830,10 +824,9 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "v_mov_b32_dpp %[l1], %[l1] wave_shr:1" HNSW_DPP_ALL "\n\t"                                                             \
     "v_writelane_b32 %[h1], %[sx], 0\n\t"                                                                                   \
     "v_writelane_b32 %[l1], %[tmp], 0\n\t"                                                                                  \
-    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "s_bfm_b64 vcc, m0, 0\n\t"                                            /* lanes below m0 keep their keys */               \
     "v_cndmask_b32_dpp %[h0], %[h0], %[h0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
     "v_cndmask_b32_dpp %[l0], %[l0], %[l0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
-    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
     "v_writelane_b32 %[h0], %[kd], m0\n\t"                                                                                  \
     "v_writelane_b32 %[l0], %[klo], m0\n\t"                                                                                 \
     "v_readlane_b32 %[mx0], %[h0], 63\n\t"                                                                                  \
@@ -858,7 +851,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
     "s_cbranch_scc1 154f\n"                                                                                                 \
     "141:\n\t"                                                                                                              \
-    "s_and_b32 %[p], %[P], 63\n\t"                                                                                          \
+    "s_and_b32 m0, %[P], 63\n\t"                                                                                            \
     "s_cmp_ge_u32 %[P], 192\n\t"                                                                                            \
     "s_cbranch_scc1 831b\n\t"                                                                                               \
     "s_cmp_ge_u32 %[P], 128\n\t"                                                                                            \
@@ -986,7 +979,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
 __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv, WList<4> &w, const WaveCtx &cx,
                                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
     const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
-    const uint64_t nbr = (uint64_t)(uintptr_t)iv.nbr0;
+    const uint64_t nbrm = (uint64_t)(uintptr_t)iv.nbr0 - 4ull * (uint64_t)iv.S0;   // one row before the table: rows are addressed by id + 1
     const uint64_t rowm = iv.S0 >= 64 ? ~0ull : ((1ull << iv.S0) - 1ull);
     const uint32_t rowb = (uint32_t)iv.S0 * 4u, st8 = (uint32_t)iv.stride8;
     const uint32_t vtb = lds_offset(cx.vt), cand = lds_offset(cx.cand_id);
@@ -997,7 +990,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     uint32_t nb, pnb, vw, va, tag, r4, co, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
     uint64_t ad0, ad1;    // row addresses, alternating by batch (a load has long read its address when the register's next turn comes)
     uint64_t um0, um1, um2, um3, fresh, b3m, b2m;
-    uint32_t pref, cnt, sx, lastad, i, kd, klo, p, P, t, nw, tmp, mx0, mx1, mx2;
+    uint32_t pref, cnt, sx, lastad, i, kd, klo, P, t, nw, tmp, mx0, mx1, mx2;
     asm volatile(
         // low key halves inside the loop: id + 1 with the expanded flag in bit 31 (a rotation of the (id + 1) << 1 | flag the
         // rest of the kernel keeps): the unexpanded members are the non-negative ones, a node id is one subtraction away
@@ -1018,8 +1011,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
         "v_cmp_lt_i32_e64 %[um2], -1, %[l2]\n\t"
         "v_cmp_lt_i32_e64 %[um3], -1, %[l3]\n"
         HNSW_POP_SLOT0("%[um0]", "%[l0]", "61f")
-        "3:\n\t"
-        "s_sub_u32 %[klo], %[kd], 1\n"                                   // node id
+        "3:\n"                                                          // kd = the node's low key half, id + 1
         HNSW_HOP_ADJACENCY
         HNSW_HOP_FILTER_ISSUE
 #if HNSW_ASM_PREFETCH
@@ -1064,11 +1056,11 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
           [um0] "=&s"(um0), [um1] "=&s"(um1), [um2] "=&s"(um2), [um3] "=&s"(um3), [fresh] "=&s"(fresh),
           [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
           [pref] "=&s"(pref), [cnt] "=&s"(cnt),
-          [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [P] "=&s"(P), [t] "=&s"(t),
+          [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [P] "=&s"(P), [t] "=&s"(t),
           [nw] "=&s"(nw), [tmp] "=&s"(tmp), [mx0] "=&s"(mx0), [mx1] "=&s"(mx1), [mx2] "=&s"(mx2)
         : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
-          [nbr] "s"(nbr), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
-          [cand] "s"(cand), [q2] "s"(q2)
+          [nbrm] "s"(nbrm), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
+          [cand] "s"(cand), [candm4] "s"(cand - 4u), [q2] "s"(q2)
         : "vcc", "scc", "m0", "memory");
     w.wmax = wmax; w.ovf_cnt = od == wmax ? (int)oc : 0;
     n_dist = nd; n_hops = nh; status = st;
@@ -1090,16 +1082,15 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */      \
     "s_cmp_lg_u64 %[um0], 0\n\t"                                                                                            \
     "s_cbranch_scc1 14f\n\t"                                              /* members of W at this very distance */          \
-    "s_bcnt1_i32_b64 %[p], vcc\n"                                         /* rank = keys at a smaller distance */           \
+    "s_bcnt1_i32_b64 m0, vcc\n"                                           /* rank = keys at a smaller distance */           \
     "11:\n\t"                                                                                                               \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
     "s_cmp_eq_u32 %[nw], %[wmax]\n\t"                                                                                       \
     "s_cbranch_scc1 15f\n"                                                /* the entry falling off ties with it */          \
     "12:\n\t"                                                                                                               \
-    "s_bfm_b64 vcc, %[p], 0\n\t"                                          /* lanes below p keep their keys */               \
+    "s_bfm_b64 vcc, m0, 0\n\t"                                            /* lanes below m0 keep their keys */               \
     "v_cndmask_b32_dpp %[h0], %[h0], %[h0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
     "v_cndmask_b32_dpp %[l0], %[l0], %[l0], vcc wave_shr:1" HNSW_DPP_ALL "\n\t"                                             \
-    "s_mov_b32 m0, %[p]\n\t"                                                                                                \
     "v_writelane_b32 %[h0], %[kd], m0\n\t"                                                                                  \
     "v_writelane_b32 %[l0], %[klo], m0\n\t"                                                                                 \
     "s_mov_b32 %[wmax], %[nw]\n"                                                                                            \
@@ -1120,6 +1111,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "v_cmp_eq_u32_e32 vcc, %[klo], %[t0]\n\t"                                                                               \
     "s_and_b64 vcc, vcc, %[um0]\n\t"                                                                                        \
     "s_cbranch_scc1 18b\n\t"                                              /* already in W */                                \
+    "s_mov_b32 m0, %[p]\n\t"                                                                                               \
     "s_branch 11b\n"                                                                                                        \
     "15:\n\t"                                                                                                               \
     "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
@@ -1148,7 +1140,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
 __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv, WList<1> &w, const WaveCtx &cx,
                                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
     const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
-    const uint64_t nbr = (uint64_t)(uintptr_t)iv.nbr0;
+    const uint64_t nbrm = (uint64_t)(uintptr_t)iv.nbr0 - 4ull * (uint64_t)iv.S0;   // one row before the table: rows are addressed by id + 1
     const uint64_t rowm = iv.S0 >= 64 ? ~0ull : ((1ull << iv.S0) - 1ull);
     const uint32_t rowb = (uint32_t)iv.S0 * 4u, st8 = (uint32_t)iv.stride8;
     const uint32_t vtb = lds_offset(cx.vt), cand = lds_offset(cx.cand_id);
@@ -1169,8 +1161,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
         "1:\n\t"
         "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n"
         HNSW_POP_SLOT0("%[um0]", "%[l0]", "90f")
-        "3:\n\t"
-        "s_sub_u32 %[klo], %[kd], 1\n"                                   // node id
+        "3:\n"                                                          // kd = the node's low key half, id + 1
         HNSW_HOP_ADJACENCY
         HNSW_HOP_FILTER_ISSUE
 #if HNSW_ASM_PREFETCH
@@ -1205,8 +1196,8 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
           [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t),
           [nw] "=&s"(nw), [tmp] "=&s"(tmp)
         : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
-          [nbr] "s"(nbr), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
-          [cand] "s"(cand), [q2] "s"(q2)
+          [nbrm] "s"(nbrm), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
+          [cand] "s"(cand), [candm4] "s"(cand - 4u), [q2] "s"(q2)
         : "vcc", "scc", "m0", "memory");
     w.wmax = wmax; w.ovf_cnt = od == wmax ? (int)oc : 0;
     n_dist = nd; n_hops = nh; status = st;
