@@ -832,9 +832,14 @@ def main():
         if "SQ_INSTS_VALU" in c_ and c_.get("SQ_BUSY_CYCLES"):
             cyc = c_["SQ_BUSY_CYCLES"] / 32.0            # summed over the chip's 32 shader engines
             tot = c_["SQ_INSTS_VALU"] + c_["SQ_INSTS_SALU"] + c_.get("SQ_INSTS_LDS", 0) + c_.get("SQ_INSTS_VMEM_RD", 0)
-            issue_ = {"valu": round(c_["SQ_INSTS_VALU"] * 4.0 / (1024 * cyc), 4), "salu": round(c_["SQ_INSTS_SALU"] / (256 * cyc), 4),
-                      "what": "share of the issue slots the launch had: vector = wave-instructions x 4 cycles / (1024 SIMDs x kernel cycles); "
-                              "scalar = instructions / (256 CUs x kernel cycles) (one scalar unit per CU, shared by its four SIMDs)",
+            # capacities measured with tools/issue_latency.hip at 8 waves per SIMD on every CU (profiles/r03_issue_latency.txt):
+            # a SIMD issues one simple vector wave-instruction per ~2.4 cycles (v_dot4 / v_mad_u64 per ~4.3), a CU one scalar
+            # instruction per cycle for its four SIMDs; a wave alone issues at most one instruction of any kind per 4 cycles
+            issue_ = {"valu": round(c_["SQ_INSTS_VALU"] * 2.4 / (1024 * cyc), 4), "salu": round(c_["SQ_INSTS_SALU"] / (256 * cyc), 4),
+                      "what": "share of the issue capacity the launch had, from measured capacities (tools/issue_latency.hip): vector = "
+                              "wave-instructions x 2.4 cycles / (1024 SIMDs x kernel cycles) (a lower bound: dot products and 64-bit "
+                              "multiply-adds take 4.3); scalar = instructions / (256 CUs x kernel cycles) (one scalar issue per cycle "
+                              "per CU, shared by its four SIMDs)",
                       "SQ_INSTS_VALU": c_["SQ_INSTS_VALU"], "SQ_INSTS_SALU": c_["SQ_INSTS_SALU"], "SQ_INSTS_LDS": c_.get("SQ_INSTS_LDS"),
                       "SQ_INSTS_VMEM_RD": c_.get("SQ_INSTS_VMEM_RD"), "kernel_cycles": round(cyc, 1),
                       "clock_GHz": round(cyc / (kernel_ms_ * 1e6), 3) if kernel_ms_ else None,

@@ -1,19 +1,22 @@
-// hnsw_hop_asm.hip.h -- the layer-0 loop of Ohnsw.search_k (lib/ohnsw.ml:543-588) for the headline shape, written
-// instruction by instruction for gfx950.
+// hnsw_hop_asm.hip.h -- the layer-0 loop of Ohnsw.search_k (lib/ohnsw.ml:543-588) and the descent above it
+// (Ohnsw.search_one, :492-508) for the headline shape, written instruction by instruction for gfx950.
 //
 // Shape: byte rows of at most 128 bytes (d <= 128: NCH = 2), a byte-valued query (exact integer arithmetic, see
-// hop_round), L2, the Ohnsw accept rule, ef in 65..128 (W in two key registers per lane).  Everything else takes
-// search_layer's C++ loop; this block computes exactly what that loop computes (same pops, same evaluations, same
-// insertions, same counters), so the two are interchangeable and tests/ compare both against the oracle.
+// hop_round), L2, the Ohnsw accept rule, ef <= 64 / 65..128 / 129..256 (W in one / two / four key registers per lane).
+// Everything else takes search_layer's C++ loop; the blocks compute exactly what that loop computes (same pops, same
+// evaluations, same insertions, same counters), so the two are interchangeable and tests/ compare both against the oracle.
 //
-// Why by hand: in a loaded launch a CU issues at most one vector and one scalar instruction per cycle for its 32 waves
-// (the scalar unit is shared by the four SIMDs), and hipcc's hop is ~125 vector + ~115 scalar instructions, a third of
-// them glue (loop-carried register copies, boolean flags materialised in mask registers and re-tested, skip branches
-// around single instructions); a lone wave at the end of a launch additionally pays for every taken branch.  Here a
-// hop is one basic-block chain: pop (s_ff1 + v_readlane + v_writelane for the flag), adjacency row (or the row
-// fetched speculatively during the previous hop), visited filter, compaction through LDS, one round of 4 / 8 / 16 rows
-// with every load issued before the first is consumed, integer dot products, ONE transposing reduction for the
-// round's sums, accept ballot, and the insertion loop of insert_island2.
+// Why by hand (numbers: tools/issue_latency.hip -> profiles/r03_issue_latency.txt): a CU issues ONE scalar instruction per
+// cycle for its four SIMDs and a SIMD one vector wave-instruction per ~2.4 cycles, so in a loaded launch scalar
+// instructions are the dearest, and hipcc's hop was ~125 vector + ~115 scalar instructions, a third of them glue
+// (loop-carried register copies, boolean flags materialised in mask registers and re-tested, skip branches around single
+// instructions).  A wave that runs alone -- the longest walk and the late starters are what a 10 k launch ends with --
+// issues one instruction per 4 cycles, waits 16 more whenever a scalar instruction reads what a vector one has just
+// written, and pays ~20 for every taken branch.  Here a hop is one fall-through chain: pop (s_ff1 + v_readlane +
+// v_writelane for the flag), adjacency row (or the row fetched speculatively during the previous hop), visited filter,
+// compaction through LDS, one round of 4 / 8 / 16 rows with every load issued before the first is consumed, integer dot
+// products, ONE transposing reduction for the round's sums, accept ballot, and the insertion loop; what is seldom taken
+// sits behind the loop.
 #pragma once
 
 namespace hnsw_dev {
