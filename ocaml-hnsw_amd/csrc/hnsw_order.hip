@@ -56,17 +56,21 @@ order_bucket_kernel(const uint32_t *sortkey, int32_t n, int32_t *order) {
         for (int i = t; i < n; i += ORDER_THREADS) atomicAdd(&cnt[bucket(sortkey[i])], 1u);
     }
     __syncthreads();
-    // exclusive scan of the 2048 counters: two per thread, then a block scan of the pair sums
+    // exclusive scan of the 2048 counters: two per thread, a scan of the pair sums inside each wave (no barriers), then the
+    // 16 wave totals (one barrier where the step-by-step block scan had twenty)
     const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
-    part[t] = c0 + c1;
-    __syncthreads();
-    for (int o = 1; o < ORDER_THREADS; o <<= 1) {
-        const uint32_t v = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    uint32_t incl = c0 + c1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if ((t & 63) >= o) incl += v;
     }
-    const uint32_t base = part[t] - (c0 + c1);
+    if ((t & 63) == 63) part[t >> 6] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+#pragma unroll
+    for (int w = 0; w < ORDER_THREADS / 64; ++w) wave_base += w < (t >> 6) ? part[w] : 0u;
+    const uint32_t base = wave_base + incl - (c0 + c1);
     cnt[2 * t] = base; cnt[2 * t + 1] = base + c0;
     __syncthreads();
     if (PER > 0) {
