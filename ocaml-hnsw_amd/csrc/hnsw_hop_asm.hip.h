@@ -63,15 +63,23 @@ namespace hnsw_dev {
 #else
 #define HNSW_ASM_COUNT_HIT
 #endif
-// Where the two-slot hop loop starts relative to a 64-byte instruction line: k dwords past one.  A lone wave's query time
-// moves by +-2 % with k (which branch targets sit at the end of a fetch window): 0.1410 .. 0.1469 ms over k = 0..8 on C2,
-// k = 7, 8 best; pinned so that code added in front of the loop does not move it.  (tools/mkvariant.sh -DHNSW_ASM_ALIGN_PAD=k)
+// Where a hop loop starts relative to a 64-byte instruction line: k dwords past one.  A lone wave's query time moves by
+// up to 4 % with k, with a period of 8 dwords (which branch targets end a 32-byte fetch window): two-slot loop on C2 0.1369 ms
+// at k = 2 or 10, 0.141 at 4 / 12, 0.1425-0.1435 at 0 / 6 / 8 / 14; the loaded launches follow by ~1 %.  Pinned per loop so
+// that code added in front of a loop does not move it.  (tools/mkvariant.sh -DHNSW_ASM_ALIGN_PAD[1|4]=k)
 #ifndef HNSW_ASM_ALIGN_PAD
-#define HNSW_ASM_ALIGN_PAD 8
+#define HNSW_ASM_ALIGN_PAD 2
+#endif
+#ifndef HNSW_ASM_ALIGN_PAD4
+#define HNSW_ASM_ALIGN_PAD4 6        // four-slot loop, ef 192: 0.2116 ms at 6, 0.214 at 0 / 4, 0.221 at 2
+#endif
+#ifndef HNSW_ASM_ALIGN_PAD1
+#define HNSW_ASM_ALIGN_PAD1 0        // one-slot loop, ef 64: within 1.5 % over k
 #endif
 #define HNSW_STR2(x) #x
 #define HNSW_STR(x) HNSW_STR2(x)
-#define HNSW_ASM_ALIGN ".p2align 6\n\t.rept " HNSW_STR(HNSW_ASM_ALIGN_PAD) "\n\ts_nop 0\n\t.endr\n"
+#define HNSW_ASM_ALIGN_K(K) ".p2align 6\n\t.rept " HNSW_STR(K) "\n\ts_nop 0\n\t.endr\n"
+#define HNSW_ASM_ALIGN HNSW_ASM_ALIGN_K(HNSW_ASM_ALIGN_PAD)
 #ifndef HNSW_ASM_PREFETCH
 #define HNSW_ASM_PREFETCH 1
 #endif
@@ -1006,6 +1014,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
         "v_readlane_b32 %[mx1], %[h1], 63\n\t"
         "v_readlane_b32 %[mx2], %[h2], 63\n\t"
         "s_mov_b32 %[pref], -1\n"
+        HNSW_ASM_ALIGN_K(HNSW_ASM_ALIGN_PAD4)
         // ================================ one hop ================================
         "1:\n\t"
         // pop: the first unexpanded member of W (pop_min, :565) and its flag
@@ -1161,6 +1170,7 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv,
         "v_alignbit_b32 %[l0], %[l0], %[l0], 1\n\t"
         HNSW_HOP_CONSTANTS
         "s_mov_b32 %[pref], -1\n"
+        HNSW_ASM_ALIGN_K(HNSW_ASM_ALIGN_PAD1)
         "1:\n\t"
         "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n"
         HNSW_POP_SLOT0("%[um0]", "%[l0]", "90f")
