@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""A lone 64-query batch on the C2 index against ef (host wall time around one device call, synchronised): the fixed cost
+(launch + descent) at ef = 1 and the layer-0 walk growing with ef.  Run on the GPU box."""
 import os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ocaml_hnsw_amd as H
 import bench
