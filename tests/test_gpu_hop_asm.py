@@ -145,3 +145,32 @@ def test_random_configurations_of_the_loop_shapes(H, oracle):
         g = oracle.build_ohnsw(sp, M, 40, seed=trial)
         hg = _hgraph(H, X, g, M)
         _check(H, oracle, hg, g, sp, Q, ef, k, "trial %d: n %d d %d M %d levels %d ef %d k %d" % (trial, n, d, M, levels, ef, k))
+
+
+def test_issue_priorities_and_ordering_change_nothing(H, oracle, monkeypatch):
+    """An ordered launch runs its first blocks and its late starters at raised issue priority (launch_priorities,
+    csrc/hnsw_capi.hip; HNSW_PRIO="head,tail" overrides the bounds), and its descent runs in the pre-pass kernel: ids,
+    distance bits, hop and evaluation counts per query must be those of the plain launch, whatever the bounds."""
+    rng = np.random.default_rng(5)
+    n, d = 4000, 128
+    X = rng.integers(0, 200, size=(n, d)).astype(np.float32)
+    Q = rng.integers(0, 200, size=(3000, d)).astype(np.float32)
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 16, 60, seed=9)
+    hg = _hgraph(H, X, g, 16)
+    for ef, k in ((40, 10), (128, 10), (200, 20)):
+        hg.set_option("order_queries", 0)
+        monkeypatch.delenv("HNSW_PRIO", raising=False)
+        plain = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True)
+        hg.set_option("order_queries", 1)
+        for prio in (None, "0,2000000000", "3000,0", "100,2900", "1,1"):
+            if prio is None:
+                monkeypatch.delenv("HNSW_PRIO", raising=False)
+            else:
+                monkeypatch.setenv("HNSW_PRIO", prio)
+            got = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True)
+            for a, b in zip(plain, got):
+                np.testing.assert_array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32), err_msg="ef %d HNSW_PRIO %s" % (ef, prio))
+    monkeypatch.delenv("HNSW_PRIO", raising=False)
+    oi, od, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q[:200], k=10, ef=128, ties=oracle.TIES_CANONICAL, counters=True)
+    np.testing.assert_array_equal(H.Ohnsw.knn_batch_bigarray(hg, 10, Q[:200], ef=128)[0], oi)
