@@ -125,6 +125,11 @@ typedef struct hnsw_search_params {
     int32_t semantics; /* HNSW_SEM_*                                                         */
 } hnsw_search_params;
 
+enum { HNSW_ROWS_F32 = 0,   /* the float32 rows as handed over                                              */
+       HNSW_ROWS_BYTES = 2, /* lossless byte copy (every value an integer in 0..255)                         */
+       HNSW_ROWS_SPLIT = 3 };/* float32 rows whose last 16 / 32 bytes past a 128-byte line are stored beside the
+                               neighbour in the layer-0 adjacency (option "split_rows")                      */
+
 typedef struct hnsw_index_info {
     int64_t n;
     int32_t d, metric, id_base, max_degree0, max_degree, max_layer;
@@ -132,7 +137,7 @@ typedef struct hnsw_index_info {
     int64_t device_bytes;      /* HBM held by the index                                       */
     int64_t row_stride_bytes;  /* padded vector row on the device                             */
     int32_t device;
-    int32_t reserved;
+    int32_t row_format;        /* HNSW_ROWS_*: what the knn searches read right now (options "byte_rows", "split_rows") */
 } hnsw_index_info;
 
 int32_t hnsw_abi_version(void);
@@ -160,7 +165,15 @@ int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info);
  *                   searches read that one: each byte is converted back to the float it came from and
  *                   the arithmetic is unchanged, so distances are bit-identical for a quarter of the
  *                   bytes gathered.  1 = use the copy where it exists (default), 0 = read the float32
- *                   rows.  (Environment HNSW_BYTE_ROWS=0 at creation: do not build the copy.) */
+ *                   rows.  (Environment HNSW_BYTE_ROWS=0 at creation: do not build the copy.)
+ *   "split_rows"    a float32 row that ends 1..32 bytes past a 128-byte line (4d mod 128 in 1..32, e.g. d = 100: 400
+ *                   bytes) costs one more 128-byte request per evaluation for those last bytes.  For such shapes
+ *                   (when there are no byte rows) the index keeps the whole lines of every row in a table of its own
+ *                   and the 16 / 32 remaining bytes of node nbr0[c][j] beside slot (c, j) of the layer-0 adjacency,
+ *                   where one hop finds all its candidates' tails in a few contiguous lines; the knn searches read
+ *                   those on layer 0 (same lanes, operands and order of arithmetic: bit-identical results).
+ *                   1 = use the copy where it exists (default), 0 = read the plain rows.  (Environment
+ *                   HNSW_SPLIT_ROWS=0 at creation: do not build it.) */
 int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value);
 /* Bytes of one vector as the knn searches read it: d for byte rows, 4 * d for float32 rows. */
 int32_t hnsw_index_row_bytes(const hnsw_index *idx, int64_t *row_bytes);

@@ -82,7 +82,7 @@ class IndexInfo(_C.Structure):
     _fields_ = [("n", _C.c_int64), ("d", _C.c_int32), ("metric", _C.c_int32), ("id_base", _C.c_int32),
                 ("max_degree0", _C.c_int32), ("max_degree", _C.c_int32), ("max_layer", _C.c_int32),
                 ("entry_point", _C.c_int64), ("device_bytes", _C.c_int64),
-                ("row_stride_bytes", _C.c_int64), ("device", _C.c_int32), ("reserved", _C.c_int32)]
+                ("row_stride_bytes", _C.c_int64), ("device", _C.c_int32), ("row_format", _C.c_int32)]
 
 
 _lib = None

@@ -64,24 +64,28 @@ int upload_upper_ref(const int32_t *off, const uint8_t *lvl, int64_t n, void **d
     hipError_t search_launch_##m##_##s##_##f(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st); \
     int search_occupancy_##m##_##s##_##f(int nch, int nslot, size_t lds);                                    \
     }
-HNSW_DECL_VARIANT(0, 0, 0) HNSW_DECL_VARIANT(0, 0, 1) HNSW_DECL_VARIANT(0, 0, 2) HNSW_DECL_VARIANT(0, 1, 0) HNSW_DECL_VARIANT(0, 1, 1) HNSW_DECL_VARIANT(0, 1, 2)
-HNSW_DECL_VARIANT(1, 0, 0) HNSW_DECL_VARIANT(1, 0, 1) HNSW_DECL_VARIANT(1, 0, 2) HNSW_DECL_VARIANT(1, 1, 0) HNSW_DECL_VARIANT(1, 1, 1) HNSW_DECL_VARIANT(1, 1, 2)
+HNSW_DECL_VARIANT(0, 0, 0) HNSW_DECL_VARIANT(0, 0, 1) HNSW_DECL_VARIANT(0, 0, 2) HNSW_DECL_VARIANT(0, 0, 3)
+HNSW_DECL_VARIANT(0, 1, 0) HNSW_DECL_VARIANT(0, 1, 1) HNSW_DECL_VARIANT(0, 1, 2) HNSW_DECL_VARIANT(0, 1, 3)
+HNSW_DECL_VARIANT(1, 0, 0) HNSW_DECL_VARIANT(1, 0, 1) HNSW_DECL_VARIANT(1, 0, 2) HNSW_DECL_VARIANT(1, 0, 3)
+HNSW_DECL_VARIANT(1, 1, 0) HNSW_DECL_VARIANT(1, 1, 1) HNSW_DECL_VARIANT(1, 1, 2) HNSW_DECL_VARIANT(1, 1, 3)
 #undef HNSW_DECL_VARIANT
 
 namespace {
 
 typedef hipError_t (*search_launch_fn)(int, int, const IndexView &, const SearchArgs &, hipStream_t);
 typedef int (*search_occupancy_fn)(int, int, size_t);
-const search_launch_fn k_launch[2][2][3] = {
-    {{search_launch_0_0_0, search_launch_0_0_1, search_launch_0_0_2}, {search_launch_0_1_0, search_launch_0_1_1, search_launch_0_1_2}},
-    {{search_launch_1_0_0, search_launch_1_0_1, search_launch_1_0_2}, {search_launch_1_1_0, search_launch_1_1_1, search_launch_1_1_2}}};
-const search_occupancy_fn k_occupancy[2][2][3] = {
-    {{search_occupancy_0_0_0, search_occupancy_0_0_1, search_occupancy_0_0_2}, {search_occupancy_0_1_0, search_occupancy_0_1_1, search_occupancy_0_1_2}},
-    {{search_occupancy_1_0_0, search_occupancy_1_0_1, search_occupancy_1_0_2}, {search_occupancy_1_1_0, search_occupancy_1_1_1, search_occupancy_1_1_2}}};
+const search_launch_fn k_launch[2][2][4] = {
+    {{search_launch_0_0_0, search_launch_0_0_1, search_launch_0_0_2, search_launch_0_0_3}, {search_launch_0_1_0, search_launch_0_1_1, search_launch_0_1_2, search_launch_0_1_3}},
+    {{search_launch_1_0_0, search_launch_1_0_1, search_launch_1_0_2, search_launch_1_0_3}, {search_launch_1_1_0, search_launch_1_1_1, search_launch_1_1_2, search_launch_1_1_3}}};
+const search_occupancy_fn k_occupancy[2][2][4] = {
+    {{search_occupancy_0_0_0, search_occupancy_0_0_1, search_occupancy_0_0_2, search_occupancy_0_0_3}, {search_occupancy_0_1_0, search_occupancy_0_1_1, search_occupancy_0_1_2, search_occupancy_0_1_3}},
+    {{search_occupancy_1_0_0, search_occupancy_1_0_1, search_occupancy_1_0_2, search_occupancy_1_0_3}, {search_occupancy_1_1_0, search_occupancy_1_1_1, search_occupancy_1_1_2, search_occupancy_1_1_3}}};
 
-// the knn kernel's row format: 2 = byte rows (hnsw_rows8.hip), else fp32 rows, 1 = every chunk of the lane grid inside the row
+// the knn kernel's row format: 2 = byte rows (hnsw_rows8.hip), 3 = split fp32 rows (hnsw_rows_split.hip), else plain fp32
+// rows, 1 = every chunk of the lane grid inside the row
 inline int variant_full(const hnsw_index *idx) {
     if (idx->iv.X8) return 2;
+    if (idx->iv.Xm) return 3;
     return idx->iv.nchunks == 16 * pick_nch(idx->iv.nchunks) ? 1 : 0;
 }
 
@@ -316,6 +320,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
     inf.device_bytes = (int64_t)(xbytes + nbr0.size() * 4 + nbrU.size() * 4 + off.size() * 12 + lvl.size());
     inf.row_stride_bytes = stride * 4; inf.device = device;
     { int rc8 = make_byte_rows(idx); if (rc8) return bail(rc8); }
+    { int rcs = make_split_rows(idx); if (rcs) return bail(rcs); }
     *out = idx;
     return HNSW_OK;
 }
@@ -323,7 +328,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
 int32_t hnsw_index_destroy(hnsw_index *idx) {
     if (!idx) return HNSW_OK;
     if (idx->device >= 0) (void)hipSetDevice(idx->device);
-    for (void *p : {idx->dX, idx->dX8, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl, idx->dRef}) if (p) (void)hipFree(p);
+    for (void *p : {idx->dX, idx->dX8, idx->dXm, idx->dTail0, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl, idx->dRef}) if (p) (void)hipFree(p);
     idx->sQ.release(); idx->sIds.release(); idx->sDist.release(); idx->sNd.release(); idx->sNh.release(); idx->sSt.release(); idx->sFlag.release();
     (void)hipDeviceSynchronize();                      // requests never waited for
     for (hnsw_request *r : idx->all_requests) {
@@ -340,6 +345,7 @@ int32_t hnsw_index_destroy(hnsw_index *idx) {
 int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info) {
     if (!idx || !info) return fail(HNSW_ERR_BAD_ARG, "null argument");
     *info = idx->info;
+    info->row_format = idx->iv.X8 ? HNSW_ROWS_BYTES : idx->iv.Xm ? HNSW_ROWS_SPLIT : HNSW_ROWS_F32;
     return HNSW_OK;
 }
 
@@ -355,6 +361,10 @@ int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) 
     if (!strcmp(name, "lds_pad")) { idx->lds_pad = value < 0 ? -1 : (int)std::min<int64_t>(value, 32768); return HNSW_OK; }
     if (!strcmp(name, "byte_rows")) {     // 0: search the fp32 rows even where a byte copy exists; otherwise: use it where it exists
         idx->iv.X8 = value != 0 ? (const uint8_t *)idx->dX8 : nullptr;
+        return HNSW_OK;
+    }
+    if (!strcmp(name, "split_rows")) {    // 0: search the plain fp32 rows even where a split copy exists; otherwise: use it where it exists
+        idx->iv.Xm = value != 0 ? (const float *)idx->dXm : nullptr;
         return HNSW_OK;
     }
     if (!strcmp(name, "time_kernels")) { idx->time_kernels = value != 0; return HNSW_OK; }

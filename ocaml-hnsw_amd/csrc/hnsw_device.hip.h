@@ -59,6 +59,16 @@ struct IndexView {
     // 64*NCH bytes, zero padded; chunk c of a row (dims 4c..4c+3) is one dword.  nullptr = not available / switched off
     const uint8_t *X8;
     int32_t stride8;         // bytes per byte row
+    // optional split copy of X for rows that end a little past a 128-byte line (4d mod 128 in 1..32, e.g. d = 100: 400 B =
+    // three lines + 16 B; hnsw_rows_split.hip): the first main_chunks float4 chunks of every row in a table of 128-byte
+    // multiples (a row costs exactly main_chunks / 8 lines), and the remaining tail_chunks chunks stored beside the
+    // neighbour in layer 0's adjacency: tail0[c][j] = the tail of node nbr0[c][j], so the tails of a hop's candidates
+    // share the S0 * 16 * tail_chunks contiguous bytes of the expanded node.  nullptr = not available / switched off
+    const float *Xm;
+    const float *tail0;      // [n][S0][4 * tail_chunks]
+    int32_t stride_m;        // bytes per main row = 16 * main_chunks
+    int32_t main_chunks;     // multiple of 8
+    int32_t tail_chunks;     // 1 or 2; main_chunks + tail_chunks == nchunks
 };
 
 struct SearchArgs {
@@ -590,10 +600,15 @@ __device__ __forceinline__ int adj_entry(const IndexView &iv, int layer, int c, 
 // the row; 2 = byte rows (IndexView::X8): one dword per chunk, converted to the same four floats the fp32 row holds, so
 // the arithmetic and its result are those of the fp32 row bit for bit, for a quarter of the bytes.  (The zero padding
 // of a byte row meets the zero padding of the query: it adds exact zeros.)
+// 3 = split fp32 rows (IndexView::Xm / tail0; layer-0 hops only): the lane grid and the arithmetic are those of ROWS = 0 --
+// chunk c of a row is still evaluated by lane c % 16 in its (c / 16)-th step -- but the lanes whose chunk lies in the
+// tail take it from the expanded node's tail row (`tail_row`, at the candidate's position in that node's adjacency row,
+// which the compaction left in cand_key[]) instead of from a fourth 128-byte line of the vector's own row.
 template <int NCH, int NB, int METRIC, int ROWS>
 __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv)[NCH], const WaveCtx &cx,
-                                          int base, int cnt, uint32_t &out_key, uint32_t &out_id) {
-    constexpr bool FULL = ROWS != 0;
+                                          int base, int cnt, uint32_t &out_key, uint32_t &out_id,
+                                          const char *tail_row = nullptr) {
+    constexpr bool FULL = ROWS == 1 || ROWS == 2;
     const int r = cx.r, l16 = cx.l16;
     const uint32_t stride_b = ROWS == 2 ? (uint32_t)iv.stride8 : (uint32_t)iv.stride * 4u;
     const int mine = base + NB * r;
@@ -620,6 +635,32 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
             const float4 *row = reinterpret_cast<const float4 *>(xlane + (uint64_t)id[b] * stride_b);
 #pragma unroll
             for (int i = 0; i < NCH; ++i) v[b][i] = row[i * 16];
+        }
+    } else if constexpr (ROWS == 3) {
+        // per lane and step: base address and multiplier of whichever table the lane's chunk lives in (lanes past the
+        // row end re-read chunk 0 of the main row and are dropped below, as in the ragged path)
+        const char *lbase[NCH];
+        uint32_t lmul[NCH];
+        bool ltail[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 16 + l16;
+            ltail[i] = c >= iv.main_chunks && c < iv.nchunks;
+            lbase[i] = ltail[i] ? tail_row + 16 * (c - iv.main_chunks)
+                                : reinterpret_cast<const char *>(iv.Xm) + (c < iv.main_chunks ? 16 * c : 0);
+            lmul[i] = ltail[i] ? 16u * (uint32_t)iv.tail_chunks : (uint32_t)iv.stride_m;
+        }
+        uint32_t pj[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int ci = (mine + b < cnt) ? mine + b : base + b;
+            pj[b] = cx.cand_key[ci];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+                v[b][i] = *reinterpret_cast<const float4 *>(lbase[i] + (uint64_t)(ltail[i] ? pj[b] : id[b]) * lmul[i]);
         }
     } else {
         uint32_t coff[NCH];   // lanes past the row end re-read chunk 0 (coalesced) and are zeroed below
@@ -734,13 +775,13 @@ __device__ __forceinline__ void hop_round(const IndexView &iv, const float4 (&qv
 // one round with as many 4-row batches as the list still needs (at most RB): returns the candidates consumed
 template <int NCH, int RB, int METRIC, int ROWS>
 __device__ __forceinline__ int eval_round(const IndexView &iv, const float4 (&qv)[NCH], const WaveCtx &cx,
-                                          int base, int cnt, uint32_t &ckey, uint32_t &cid) {
+                                          int base, int cnt, uint32_t &ckey, uint32_t &cid, const char *tail_row = nullptr) {
     const int nbb = (cnt - base + 3) >> 2;   // wave-uniform
-    if (RB >= 8 && nbb >= 8) { hop_round<NCH, (RB >= 8 ? 8 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid); return 32; }
-    if (RB >= 4 && nbb >= 4) { hop_round<NCH, (RB >= 4 ? 4 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid); return 16; }
-    if (RB >= 3 && nbb >= 3) { hop_round<NCH, (RB >= 3 ? 3 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid); return 12; }
-    if (RB >= 2 && nbb >= 2) { hop_round<NCH, (RB >= 2 ? 2 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid); return 8; }
-    hop_round<NCH, 1, METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid);
+    if (RB >= 8 && nbb >= 8) { hop_round<NCH, (RB >= 8 ? 8 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid, tail_row); return 32; }
+    if (RB >= 4 && nbb >= 4) { hop_round<NCH, (RB >= 4 ? 4 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid, tail_row); return 16; }
+    if (RB >= 3 && nbb >= 3) { hop_round<NCH, (RB >= 3 ? 3 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid, tail_row); return 12; }
+    if (RB >= 2 && nbb >= 2) { hop_round<NCH, (RB >= 2 ? 2 : 1), METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid, tail_row); return 8; }
+    hop_round<NCH, 1, METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid, tail_row);
     return 4;
 }
 
@@ -767,7 +808,7 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
         }
     }
 #endif
-    const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
+    const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;   // (split rows, ROWS = 3, serve layer-0 hops only: the descent reads X)
     for (int layer = from; layer >= to; --layer) {
         for (;;) {
             const int nb = adj_entry(iv, layer, cur, cx.lane);
@@ -908,11 +949,12 @@ struct PhaseClock {};
 
 template <int NCH, int RB, int NSLOT, int METRIC, int SEM, int ROWS>
 __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)[NCH], WList<NSLOT> &w,
-                                         const WaveCtx &cx, int cnt, uint32_t &status, PhaseClock &pc) {
+                                         const WaveCtx &cx, int cnt, uint32_t &status, PhaseClock &pc,
+                                         const char *tail_row = nullptr) {
     const int lane = cx.lane;
     for (int base = 0; base < cnt;) {
         uint32_t ckey, cid;
-        base += eval_round<NCH, RB, METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid);
+        base += eval_round<NCH, RB, METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid, tail_row);
         uint64_t pass = ballot(SEM ? ckey <= w.wmax : ckey < w.wmax);
 #ifdef HNSW_PHASE_TIMING
         asm volatile("" :: "s"(pass));
@@ -1073,11 +1115,15 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             if (fresh) {                                                 // Visited.add, :572
                 cx.vt[(uint32_t)nb & cx.set_mask] = (vword << 16) | ((uint32_t)nb >> cx.set_bits);
                 cx.cand_id[pos] = nb;
+                if (ROWS == 3) cx.cand_key[pos] = (uint32_t)lane;        // split rows: where in c's row (= in its tail row) the candidate sits
             }
             __syncthreads();
             n_dist += cnt;
             HNSW_PHASE(pc, 1);                                           // prefetch issue + compaction through LDS
-            if (ROWS == 2) hop_eval<NCH, RB, NSLOT, METRIC, SEM, 2>(iv, qv, w, cx, cnt, status, pc);                                  // :573-577
+            if (ROWS == 3)      // layer 0 only (the knn kernel): the tails of c's neighbours lie beside its adjacency row
+                hop_eval<NCH, RB, NSLOT, METRIC, SEM, 3>(iv, qv, w, cx, cnt, status, pc,
+                                                         reinterpret_cast<const char *>(iv.tail0) + (uint64_t)(uint32_t)c * (uint32_t)(iv.S0 * 16 * iv.tail_chunks));
+            else if (ROWS == 2) hop_eval<NCH, RB, NSLOT, METRIC, SEM, 2>(iv, qv, w, cx, cnt, status, pc);                                  // :573-577
             else if (ROWS == 1 || (ROWS < 0 && full_rows)) hop_eval<NCH, RB, NSLOT, METRIC, SEM, 1>(iv, qv, w, cx, cnt, status, pc);
             else hop_eval<NCH, RB, NSLOT, METRIC, SEM, 0>(iv, qv, w, cx, cnt, status, pc);
         }
@@ -1153,7 +1199,7 @@ __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv,
     (((NCH) <= 2 && (NSLOT) <= 2 && (METRIC) == 0 && (ROWS) == 1) ? 7 : \
      (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) <= 4 && (METRIC) == 0 && (ROWS) == 2 && (SEMF) == 0) ? 8 : 1)
 #endif
-// SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); ROWS: 0 | 1 | 2, see hop_round
+// SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); ROWS: 0 | 1 | 2 | 3, see hop_round
 template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, int ROWS>
 __global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS, SEMF))
 hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
@@ -1180,20 +1226,21 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     visited_clear(cx);
 
     uint32_t n_dist = 0, n_hops = 0, status = 0;
+    constexpr int DROWS = ROWS == 3 ? 0 : ROWS;   // split rows serve the layer-0 hops; the entry point and the upper layers read X
 
     int cur;
     uint32_t cur_key;
     if (a.pre_entry) {                       // descent already done (hnsw_descent_kernel)
         cur = a.pre_entry[q]; cur_key = a.pre_key[q]; n_dist = a.pre_nd[q];
-        if (a.pre_layer > 1) greedy_descend<NCH, RB, METRIC, ROWS>(iv, qv, a.pre_layer - 1, 1, cur, cur_key, cx, n_dist);
+        if (a.pre_layer > 1) greedy_descend<NCH, RB, METRIC, DROWS>(iv, qv, a.pre_layer - 1, 1, cur, cur_key, cx, n_dist);
     } else {
         // entry point
         cur = iv.entry_point;
         if (lane == 0) cx.cand_id[0] = cur;
         __syncthreads();
-        { uint32_t ck, ci; hop_round<NCH, 1, METRIC, ROWS>(iv, qv, cx, 0, 1, ck, ci); cur_key = rdlane(ck, 0); }
+        { uint32_t ck, ci; hop_round<NCH, 1, METRIC, DROWS>(iv, qv, cx, 0, 1, ck, ci); cur_key = rdlane(ck, 0); }
         n_dist += 1;
-        greedy_descend<NCH, RB, METRIC, ROWS>(iv, qv, iv.max_layer, 1, cur, cur_key, cx, n_dist);   // :865-867
+        greedy_descend<NCH, RB, METRIC, DROWS>(iv, qv, iv.max_layer, 1, cur, cur_key, cx, n_dist);   // :865-867
     }
 
     WList<NSLOT> w;

@@ -80,6 +80,7 @@ struct hnsw_index {
     hnsw_dev::IndexView iv{};
     hnsw_index_info info{};
     void *dX8 = nullptr;                 // byte rows (hnsw_rows8.hip), nullptr when the data does not qualify
+    void *dXm = nullptr, *dTail0 = nullptr; // split rows (hnsw_rows_split.hip), nullptr when the row shape does not qualify
     void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr, *dRef = nullptr;
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt, sFlag; // scratch for the host-buffer entry points (sFlag: the launch's "any query flagged" word)
@@ -108,6 +109,9 @@ namespace hnsw_host {
 
 // hnsw_rows8.hip: if every value of idx->dX is an integer in 0..255, build the byte copy (idx->dX8, iv.X8, iv.stride8)
 int make_byte_rows(::hnsw_index *idx);
+// hnsw_rows_split.hip: if a row ends 1..32 bytes past a 128-byte line (and there are no byte rows), build the split copy
+// (idx->dXm / dTail0, iv.Xm / tail0 / stride_m / main_chunks / tail_chunks); call after make_byte_rows, graph in place
+int make_split_rows(::hnsw_index *idx);
 
 // Longest-first ordering of a large batch (hnsw_order.hip): runs the descent kernel and a radix sort
 // on `st`; on success *block points to the handle's scratch for that stream (nothing to release)

@@ -8,7 +8,7 @@
 #include "hnsw_internal.h"
 
 #ifndef HNSW_V_METRIC
-#error "compile with -DHNSW_V_METRIC=0|1 -DHNSW_V_SEMF=0|1 -DHNSW_V_FULL=0|1|2 (rows: ragged fp32, full fp32, bytes)"
+#error "compile with -DHNSW_V_METRIC=0|1 -DHNSW_V_SEMF=0|1 -DHNSW_V_FULL=0|1|2|3 (rows: ragged fp32, full fp32, bytes, split fp32)"
 #endif
 
 using hnsw_dev::IndexView;

@@ -162,7 +162,7 @@ let ii_entry_point = field index_info "entry_point" int64_t
 let ii_device_bytes = field index_info "device_bytes" int64_t
 let ii_row_stride_bytes = field index_info "row_stride_bytes" int64_t
 let ii_device = field index_info "device" int32_t
-let ii_reserved = field index_info "reserved" int32_t
+let ii_row_format = field index_info "row_format" int32_t
 let () = seal index_info
 let hnsw_index_get_info = foreign ~from:lib "hnsw_index_get_info" (index @-> ptr index_info @-> returning int32_t)
 (* the flattened graph of a device index (built there by hnsw_build, or loaded from a file) back to the host *)

@@ -222,6 +222,43 @@ int32_t og_graph_adjacent(const og_graph *g, int32_t layer, int64_t node, int32_
 }
 
 /* ======================================================================================== */
+/* Hgraph.Stats: lib/hnsw.ml:353-375.  min_max_connectivity (:361-368) folds the layer's      */
+/* `connections` map in ascending key order from (1000000, -1, 0, 0., []): min / max of the    */
+/* neighbour-list lengths, their mean as a float sum over a float count, and the nodes with    */
+/* no neighbour consed onto `isolated` as they are met -- so the list holds them in DESCENDING */
+/* id order.  compute (:370-375): layer_sizes = Map.length of the layer's connections.  The   */
+/* keys of a layer are the nodes inserted at that level or above (layer 0: every node).        */
+/* ======================================================================================== */
+int64_t og_layer_stats(const og_graph *g, int32_t layer, int64_t *num_nodes, int32_t *min_degree,
+                       int32_t *max_degree, double *mean_degree, int64_t *isolated, int64_t isolated_cap) {
+    int32_t mi = 1000000, ma = -1;
+    int64_t cnt = 0, n_iso = 0;
+    double sum = 0.0;
+    const int64_t n = g->view.n;
+    if (layer < 0 || layer > g->max_layer) return -1;
+    for (int64_t key = 0; key < n; ++key) {              /* Map.fold: ascending keys */
+        if (layer > 0 && g->slot_of[layer - 1][key] < 0) continue;   /* not a key of this layer's map */
+        int32_t len; (void)g->view.adj(&g->view, layer, key, &len);  /* Neighbours.length */
+        if (!(len > 0)) n_iso++;                          /* key :: isolated (stored below, newest first) */
+        mi = len < mi ? len : mi; ma = len > ma ? len : ma;
+        cnt++; sum += (double)len;
+    }
+    if (isolated) {                                       /* the consed list, head first = descending ids */
+        int64_t w = 0;
+        for (int64_t key = n - 1; key >= 0 && w < isolated_cap; --key) {
+            if (layer > 0 && g->slot_of[layer - 1][key] < 0) continue;
+            int32_t len; (void)g->view.adj(&g->view, layer, key, &len);
+            if (!(len > 0)) isolated[w++] = key;
+        }
+    }
+    if (num_nodes) *num_nodes = cnt;
+    if (min_degree) *min_degree = mi;
+    if (max_degree) *max_degree = ma;
+    if (mean_degree) *mean_degree = sum / (double)cnt;    /* 0. /. 0. = nan on an empty layer, as in OCaml */
+    return n_iso;
+}
+
+/* ======================================================================================== */
 /* Visited: lib/ohnsw.ml:256-268 (epoch array; clear = epoch++ with reset on overflow).     */
 /* The functor copy (lib/hnsw.ml:105-121) is the same minus the overflow reset.             */
 /* ======================================================================================== */

@@ -73,6 +73,13 @@ int64_t og_graph_entry_point(const og_graph *g);
 /* returns degree, writes up to cap neighbour ids */
 int32_t og_graph_adjacent(const og_graph *g, int32_t layer, int64_t node, int32_t *out, int32_t cap);
 
+/* Hgraph.Stats.compute for one layer (lib/hnsw.ml:353-375): layer size, min / max / mean of the neighbour-list lengths
+ * and the isolated nodes in the reference's list order (descending id: consed during an ascending fold).  Returns the
+ * number of isolated nodes (-1: no such layer); at most isolated_cap ids are written.  An empty layer yields
+ * min 1000000, max -1, mean nan, as the OCaml fold does. */
+int64_t og_layer_stats(const og_graph *g, int32_t layer, int64_t *num_nodes, int32_t *min_degree,
+                       int32_t *max_degree, double *mean_degree, int64_t *isolated, int64_t isolated_cap);
+
 /* ---- tie modes --------------------------------------------------------------------------- */
 enum { OG_TIES_HEAP = 0,       /* heap-implementation-defined (pairing heap of hnsw_algo.ml:17-66) */
        OG_TIES_CANONICAL = 1 };/* total order (distance, id) in both heaps                         */

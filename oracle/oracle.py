@@ -59,6 +59,8 @@ def lib():
     L.og_graph_create.restype = vp
     L.og_graph_create.argtypes = [i64, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]
     L.og_graph_destroy.argtypes = [vp]
+    L.og_layer_stats.restype = i64
+    L.og_layer_stats.argtypes = [vp, i32, vp, vp, vp, vp, vp, i64]
     L.og_ohnsw_search_one.restype = i64
     L.og_ohnsw_search_one.argtypes = [vp, i32, vp, i64, vp, i32]
     L.og_ohnsw_search_k.restype = i32
@@ -256,6 +258,26 @@ class Graph:
 
 def _ctr():
     return _Counters()
+
+
+class Stats:
+    """Hgraph.Stats (lib/hnsw.ml:353-375)"""
+
+    @staticmethod
+    def compute(graph):
+        """Stats.compute hgraph -> {num_nodes, layer_sizes {layer: size}, layer_connectivity {layer: mima}} with
+        mima = {min, max, mean, isolated}; `isolated` is the reference's list (node ids, descending: consed during the
+        ascending Map.fold of min_max_connectivity, :361-368)."""
+        out = {"num_nodes": graph.n, "layer_sizes": {}, "layer_connectivity": {}}
+        for layer in range(graph.max_layer + 1):
+            nn, mi, ma, mean = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+            iso = np.empty(max(graph.n, 1), np.int64)
+            c = lib().og_layer_stats(graph._h, layer, C.byref(nn), C.byref(mi), C.byref(ma), C.byref(mean), _ptr(iso), graph.n)
+            assert c >= 0
+            out["layer_sizes"][layer] = int(nn.value)
+            out["layer_connectivity"][layer] = {"min": int(mi.value), "max": int(ma.value), "mean": float(mean.value),
+                                                "isolated": iso[:c].tolist()}
+        return out
 
 
 class Ohnsw:

@@ -44,6 +44,9 @@ else:
     if cache:
         t = time.time(); hg.save(cache); print("index saved to %s in %.2fs" % (cache, time.time() - t), flush=True)
 stream = torch.cuda.current_stream()
+for kv in filter(None, os.environ.get("OPTS", "").split(",")):      # OPTS="split_rows=0,order_queries=1": hnsw_index_set_option
+    hg.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+print("row format %d, %d B of index" % (hg.info().row_format, hg.info().device_bytes), flush=True)
 
 # hooks called after every run(); registered by a wrapper that executes this file (the oracle is test
 # infrastructure and is only touched from tests/)
