@@ -11,12 +11,15 @@ all-gathered over RCCL (weak scaling: per-GPU work fixed).
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-`value` is measured on the device-pointer entry point (hnsw_search_batch_device: queries resident in HBM,
-results left in HBM -- the line says so in `protocol`).  The same run also reports, as extra objects:
-`drop_in` (the synchronous host-buffer call hnsw_search_batch = what Ohnsw.knn_batch_bigarray becomes:
-H2D + ordering pre-pass + kernel + D2H, as benchmark/benchmark.ml:89-96 times it, and the
-submit/wait form with two requests in flight), `secondary` (a harder SIFT-like set), and for N > 1
-`strong` (C4 as BASELINE.json words it: ONE 10 k batch split over the N GPUs).
+`value` is measured the way the reference's benchmark times knn_batch (benchmark/benchmark.ml:89-96) and SURVEY 8d
+prescribes: host matrices in, host results out, one synchronous call per batch -- hnsw_search_batch, the body of
+Ohnsw.knn_batch_bigarray (H2D of the queries + ordering pre-pass + search kernel + D2H of the results; the caller's
+matrices registered once with hnsw_host_register, as a benchmark loop that reuses its Bigarrays would).  Named beside it:
+`device_resident` (hnsw_search_batch_device: queries already in HBM, results left there), `float32_rows` (the same
+batch through the general-format kernel), `harder_set_at_recall_gate`, `drop_in` (pageable matrices; two requests in
+flight), `secondary` (a harder SIFT-like set), `others` (C3, C5), and for N > 1 `strong` (C4 as BASELINE.json words it:
+ONE 10 k batch split over the N GPUs).  `roofline` is the search kernel's: its duration comes from HIP events the
+library records around its own launches inside the timed region.
 
 Prints ONE JSON line on rank 0.  The oracle (oracle/) is used only as the checker and as the
 `cpu_baseline` leg (a single-thread C restatement of the reference's OCaml CPU path).
@@ -91,6 +94,27 @@ def brute_force_topk(X, Q, k):
 
 def recall_ids(got, gt):
     return float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got.tolist(), gt.tolist())]))
+
+
+def search_kernel_name(d, ef, metric, semf, rows=-1):
+    """The hnsw_search_kernel<NCH, RB, NSLOT, METRIC, SEMF, ROWS> instance the library launches for this shape
+    (csrc/hnsw_internal.h: pick_nch / pick_nslot; csrc/hnsw_search_variants.hip: RB per NCH).  rows: 2 = byte rows,
+    3 = split rows, -1 = plain float32 rows (1 when every chunk of the lane grid lies inside the row, else 0)."""
+    nchunks = (d + 3) // 4
+    per_lane = (nchunks + 15) // 16
+    nch = next(c for c in (1, 2, 4, 8, 16) if per_lane <= c)
+    nslot = next(s_ for s_ in (1, 2, 4, 8, 16) if ef <= 64 * s_)
+    if rows < 0:
+        rows = 1 if nchunks == 16 * nch else 0
+    rb = {1: 8, 2: 4, 4: 4, 8: 2, 16: 1}[nch] if rows == 2 else {1: 8, 2: 4, 4: 2, 8: 1, 16: 1}[nch]
+    return "hnsw_search_kernel<%d,%d,%d,%d,%d,%d>" % (nch, rb, nslot, metric, semf, rows)
+
+
+def kernel_rows_of(name):
+    """ROWS template argument of a (demangled) hnsw_search_kernel name, or None"""
+    import re
+    m = re.search(r"hnsw_search_kernel<([^>]*)>", name.replace(" ", ""))
+    return int(m.group(1).split(",")[-1]) if m else None
 
 
 def _stdout_to_stderr():
@@ -251,7 +275,7 @@ def main():
     byte_rows = row_bytes == d
 
     def kernel_name(bytes_):
-        return "hnsw_search_kernel<2,4,2,0,0,2>" if bytes_ else "hnsw_search_kernel<2,4,2,0,0,1>"
+        return search_kernel_name(d, ef, 0, 0, 2 if bytes_ else -1)
 
     def search(ef_, counters=False, slot=0):
         H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(),
@@ -285,6 +309,7 @@ def main():
         torch.cuda.synchronize()
 
     def timed(ef_, steps, warmup):
+        """device-resident steps (hnsw_search_batch_device: queries already in HBM, results left there)"""
         run_steps(ef_, warmup)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         sync()
@@ -305,29 +330,87 @@ def main():
             wall = float(w[0])
         return wall, kern_ms
 
+    # ---- the headline protocol (benchmark/benchmark.ml:89-96): host matrices in, host results out, one
+    #      synchronous call per batch.  N = 1: hnsw_search_batch itself (= the body of Ohnsw.knn_batch_bigarray) on the
+    #      caller's registered matrices.  N > 1 (one process per GPU): the same sequence per rank with the exchange in it
+    #      -- H2D of the rank's query shard, search, all-gather of the per-shard results over RCCL (the full table ends
+    #      up resident on every GPU), D2H of the rank's own shard, stream synchronisation. ----
+    if not multi:
+        Qh = Qd.cpu().numpy()
+        host_i = np.empty((nq, k), np.int32)
+        host_d = np.empty((nq, k), np.float32)
+        for a_ in (Qh, host_i, host_d):
+            H.pin(a_)                                     # hnsw_host_register: the caller's matrices, registered once
+    else:
+        Qh_t = Qd.cpu().pin_memory()
+        host_res = torch.empty(2 * nres, dtype=torch.int32).pin_memory()
+
+    def host_step(ef_, slot=0):
+        if not multi:
+            H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef_, out=(host_i, host_d))
+            return
+        with torch.cuda.stream(stream):
+            Qd.copy_(Qh_t, non_blocking=True)
+            search(ef_, slot=slot)
+            gather(slot).wait()                           # the current stream waits for the collective
+            host_res.copy_(res[slot], non_blocking=True)
+        stream.synchronize()
+
+    def timed_host(ef_, steps, warmup):
+        for i in range(warmup):
+            host_step(ef_, i & 1)
+        sync()
+        hg.set_option("time_kernels", 1)
+        hg.kernel_times()
+        ts = []
+        t = time.perf_counter()
+        for i in range(steps):
+            t1 = time.perf_counter()
+            host_step(ef_, i & 1)
+            ts.append(1e3 * (time.perf_counter() - t1))
+        sync()
+        wall = time.perf_counter() - t
+        lt = dict(zip(("search_ms", "prepass_ms", "calls"), hg.kernel_times()))
+        hg.set_option("time_kernels", 0)
+        ts.sort()
+        if multi:
+            w = torch.tensor([wall], dtype=torch.float64, device=cdev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            wall = float(w[0])
+        return wall, {"median": round(ts[len(ts) // 2], 4), "min": round(ts[0], 4), "max": round(ts[-1], 4)}, lt
+
     lib_times = {}
     step_stats = {}
-    wall, kern_ms = timed(ef, args.steps, args.warmup)
-    headline_steps = dict(step_stats)
+    wall, host_stats, host_lib = timed_host(ef, args.steps, args.warmup)
     qps = world * nq * args.steps / wall
-    search_ms, prepass_ms = lib_times["search_ms"], lib_times["prepass_ms"]
-    log("ef=%d: %.0f q/s, %.3f ms/step; per step: ordering pre-pass %.3f ms + search kernel %.3f ms (device call %.3f ms)%s" %
-        (ef, qps, 1e3 * wall / args.steps, prepass_ms, search_ms, kern_ms, " [byte rows]" if byte_rows else ""))
+    search_ms, prepass_ms = host_lib["search_ms"], host_lib["prepass_ms"]
+    log("ef=%d, host matrices in and out: %.0f q/s, %.3f ms/step (median %.3f); per step: ordering pre-pass %.3f ms + search kernel %.3f ms%s" %
+        (ef, qps, 1e3 * wall / args.steps, host_stats["median"], prepass_ms, search_ms, " [byte rows]" if byte_rows else ""))
+    # ---- the same steps with the queries already resident in HBM and the results left there (hnsw_search_batch_device) ----
+    wall_dev, kern_ms = timed(ef, args.steps, args.warmup)
+    headline_steps = dict(step_stats)
+    dev_lib = dict(lib_times)
+    qps_dev = world * nq * args.steps / wall_dev
+    log("ef=%d, device-resident: %.0f q/s, %.3f ms/step; pre-pass %.3f ms + search kernel %.3f ms (device call %.3f ms)" %
+        (ef, qps_dev, 1e3 * wall_dev / args.steps, dev_lib["prepass_ms"], dev_lib["search_ms"], kern_ms))
     # ---- the same steps through the float32 rows (never `value`): the general-format kernel, the one the HBM
     #      roofline bounds (a byte row is a quarter of the bytes and leaves that regime) ----
     fp32_leg = None
     if byte_rows and world == 1:
         hg.set_option("byte_rows", 0)
-        lt_keep = dict(lib_times)
+        wall_fh, stats_fh, _ = timed_host(ef, args.steps, args.warmup)
         wall_f, kern_f = timed(ef, args.steps, args.warmup)
-        fp32_leg = {"wall": wall_f, "kern_ms": kern_f, "search_ms": lib_times["search_ms"], "prepass_ms": lib_times["prepass_ms"]}
-        lib_times.clear(); lib_times.update(lt_keep)
+        fp32_leg = {"wall": wall_f, "kern_ms": kern_f, "search_ms": lib_times["search_ms"], "prepass_ms": lib_times["prepass_ms"],
+                    "host_wall": wall_fh, "host_stats": stats_fh}
+        lib_times.clear(); lib_times.update(dev_lib)
         search(ef, counters=True)
         torch.cuda.synchronize()
         fp32_leg["ids"], fp32_leg["dist"] = ids_d.cpu().numpy().copy(), dist_d.cpu().numpy().copy()
         hg.set_option("byte_rows", 1)
-        log("float32 rows: %.0f q/s, %.3f ms/step; pre-pass %.3f ms + search kernel %.3f ms" %
-            (nq * args.steps / wall_f, 1e3 * wall_f / args.steps, fp32_leg["prepass_ms"], fp32_leg["search_ms"]))
+        log("float32 rows: host protocol %.0f q/s; device-resident %.0f q/s, %.3f ms/step; pre-pass %.3f ms + search kernel %.3f ms" %
+            (nq * args.steps / wall_fh, nq * args.steps / wall_f, 1e3 * wall_f / args.steps, fp32_leg["prepass_ms"], fp32_leg["search_ms"]))
+    if not multi:
+        host_last = (host_i.copy(), host_d.copy())
 
     # ---- extra (--pipelined, N = 1, not `value`): the same steps alternated over two HIP streams ----
     # A single 10 k-query launch ends with a drain phase (the last queries to start run on a nearly
@@ -429,10 +512,17 @@ def main():
     #      synchronous call per batch, benchmark/benchmark.ml:89-96), PCIe copies included ----
     drop_in = None
     if world == 1 and rank == 0:
+        if not multi:
+            for a_ in (Qh, host_i, host_d):
+                H.unpin(a_)                    # the headline's matrices are done with
         Qh = Qd.cpu().numpy()
         reps = max(5, min(args.steps, 10))
         hi_, hd_ = H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef)       # warm-up, and the exact result of every query
         checks["device_call_equals_drop_in"] = bool(np.array_equal(hi_, got) and np.array_equal(hd_.view(np.uint32), got_dist.view(np.uint32)))
+        # what the timed headline steps themselves left in the caller's matrices (float32-row leg last: same bits)
+        if not multi:
+            checks["headline_steps_results_equal_device_call"] = bool(np.array_equal(host_last[0], got) and
+                                                                      np.array_equal(host_last[1].view(np.uint32), got_dist.view(np.uint32)))
 
         def timed_calls(fn):
             ts = []
@@ -473,8 +563,9 @@ def main():
             inflight.pop(0).wait(out=(oi_, od_))
         for a_ in (Qh, oi_, od_):
             H.unpin(a_)
-        drop_in = {"synchronous": leg(*sync_r, "hnsw_search_batch, the caller's query / result matrices registered once (hnsw_host_register): H2D -> ordering "
-                                               "pre-pass + search kernel -> D2H, one blocking call per %d-query batch = the body of Ohnsw.knn_batch_bigarray" % nq),
+        drop_in = {"synchronous": leg(*sync_r, "the headline protocol again, as the median of %d single calls: hnsw_search_batch, the caller's query / result "
+                                               "matrices registered once (hnsw_host_register): H2D -> ordering pre-pass + search kernel -> D2H, one blocking "
+                                               "call per %d-query batch = the body of Ohnsw.knn_batch_bigarray" % (reps, nq)),
                    "synchronous_pageable": leg(*sync_p, "the same call on fresh pageable matrices (copies staged by the runtime)"),
                    "submit_wait_2_in_flight": leg(*sub, "hnsw_search_submit / hnsw_search_wait, two requests in flight, registered matrices"),
                    "batches_timed": reps, "statistic": "median of the per-call wall times (min / max beside it)"}
@@ -499,7 +590,7 @@ def main():
             torch.cuda.synchronize()
             r2 = recall_ids(ids_d.cpu().numpy()[:ns], gt)
             if r2 >= 0.95:
-                w2, _ = timed(ef2, max(3, args.steps // 2), 1)
+                w2, _, _ = timed_host(ef2, max(3, args.steps // 2), 1)       # the headline protocol at the ef that meets the gate
                 ef_ok, qps_ok = ef2, nq * max(3, args.steps // 2) / w2
                 checks["ef_for_recall_0.95"] = ef2
                 checks["recall_at_that_ef"] = round(r2, 4)
@@ -537,9 +628,23 @@ def main():
             hg2.set_option("time_kernels", 0)
             return w, sm, pm
 
+        Q2h = Q2d.cpu().numpy()
+        h2i, h2d = np.empty((nq, k), np.int32), np.empty((nq, k), np.float32)
+        for a_ in (Q2h, h2i, h2d):
+            H.pin(a_)
+
+        def timed2_host(ef_, steps):
+            """the headline protocol on this set: hnsw_search_batch, registered host matrices in and out"""
+            H.Ohnsw.knn_batch_bigarray(hg2, k, Q2h, ef=ef_, out=(h2i, h2d))
+            t = time.perf_counter()
+            for _ in range(steps):
+                H.Ohnsw.knn_batch_bigarray(hg2, k, Q2h, ef=ef_, out=(h2i, h2d))
+            return (time.perf_counter() - t) / steps
+
         ns2 = min(1000, nq)
         gt2 = brute_force_topk(X2d, Q2d[:ns2], k)
         steps2 = max(3, args.steps // 2)
+        w2h = timed2_host(ef, steps2)
         w2, sm2, pm2 = timed2(ef, steps2)
         search2(ef, counters=True)
         torch.cuda.synchronize()
@@ -574,6 +679,9 @@ def main():
         secondary = {"workload": "harder SIFT-like: n=%d d=%d clustered ints 0..218, 256 blobs, sigma 40; M=%d efConstruction=%d, ef=%d k=%d, %d queries"
                                  % (n, d, args.M, args.efc, ef, k, nq),
                      "value": round(nq / w2, 1), "unit": "queries/s", "ms_per_step": round(1e3 * w2, 4), "steps": steps2,
+                     "value_host_protocol": round(nq / w2h, 1), "ms_per_step_host_protocol": round(1e3 * w2h, 4),
+                     "protocols": "`value`: queries resident in HBM, results left there (hnsw_search_batch_device); `value_host_protocol`: the headline's "
+                                  "protocol (hnsw_search_batch, registered host matrices in and out)",
                      "roofline": {"bound": "hbm", "achieved": round(ach2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(ach2 / HBM_PEAK_GBS, 4), "kernel_ms": round(kms2, 4), "bytes_per_query": round(bq2, 1),
                                   "row_bytes": rb2,
@@ -592,12 +700,18 @@ def main():
                 torch.cuda.synchronize()
                 r2 = recall_ids(ids_v[0].cpu().numpy()[:ns2], gt2)
                 if r2 >= 0.95:
+                    w3h = timed2_host(ef2, steps2)
                     w3, _, _ = timed2(ef2, steps2)
-                    secondary["at_recall_0.95"] = {"ef": ef2, "recall_at_10": round(r2, 4), "value": round(nq / w3, 1),
-                                                   "unit": "queries/s", "ms_per_step": round(1e3 * w3, 4)}
+                    secondary["at_recall_0.95"] = {"ef": ef2, "recall_at_10": round(r2, 4), "value": round(nq / w3h, 1),
+                                                   "unit": "queries/s", "ms_per_step": round(1e3 * w3h, 4),
+                                                   "device_resident_value": round(nq / w3, 1), "device_resident_ms_per_step": round(1e3 * w3, 4),
+                                                   "what": "`value`: the headline's protocol (host matrices in and out) at the smallest ef of the "
+                                                           "ladder that reaches recall@10 >= 0.95 on this set"}
                     break
         log("secondary (256 blobs, sigma 40): %.0f q/s at ef=%d, recall@10 %.4f, %.0f evaluations/query, frac %.3f (%.1fs)" %
             (nq / w2, ef, rec2, nd2, ach2 / HBM_PEAK_GBS, time.time() - t0))
+        for a_ in (Q2h, h2i, h2d):
+            H.unpin(a_)
         hg2.release()
         del hg2
         # Is the batched device builder the reason this set misses the gate at ef 128?  The same recipe at n = 100 000,
@@ -644,7 +758,7 @@ def main():
                 out_[s_:s_ + m_] = (x_ / x_.norm(dim=1, keepdim=True)).cpu().numpy()
             return out_
 
-        def other_config(tag, n_, d_, metric_, M_, efc_, ef_, k_, seed_, n_sample, kern):
+        def other_config(tag, n_, d_, metric_, M_, efc_, ef_, k_, seed_, n_sample, ceiling):
             t0_ = time.time()
             Xo = unit_vectors(n_, d_, seed_)
             Qo = unit_vectors(nq, d_, seed_ + 100)
@@ -694,6 +808,8 @@ def main():
                 del spo, go_
             So = 2 * M_
             rbo = hgo.row_bytes()
+            fmt_ = int(hgo.info().row_format)
+            kern = search_kernel_name(d_, ef_, metric_, 0, fmt_ if fmt_ else -1)
             ordered_ = pm_ > 0
             l0 = ordered_ and nu_ is not None
             bq_ = (nd_ - (nu_ if l0 else 0.0)) * (rbo + 4) + nh_ * 4 * So + 4 * d_ + 8 * k_ + (16 if l0 else 0)
@@ -705,6 +821,9 @@ def main():
                     "ms_min": round(ts_[0], 4), "ms_max": round(ts_[-1], 4), "steps": steps_, "statistic": "median",
                     "roofline": {"bound": "hbm", "achieved": round(ach_, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(ach_ / HBM_PEAK_GBS, 4), "kernel": kern, "kernel_ms": round(kms_, 4),
+                                 "row_format": {0: "float32 rows", 2: "byte rows", 3: "split rows: whole 128-byte lines per row + the last 16 / 32 bytes beside the "
+                                                "neighbour in the layer-0 adjacency (hnsw_rows_split.hip)"}.get(fmt_),
+                                 "measured_gather_ceiling": dict(ceiling, frac_of_it=round(ach_ / (1e3 * ceiling["TBps"]), 4)),
                                  "prepass_ms": round(pm_, 4), "bytes_per_query": round(bq_, 1), "row_bytes": rbo,
                                  "n_dist_per_query": round(nd_, 1), "n_hops_per_query": round(nh_, 1), "counters": src_,
                                  "index_bytes": int(hgo.info().device_bytes) if hasattr(hgo, "info") else None},
@@ -716,14 +835,19 @@ def main():
             return res_
 
         try:
-            others["C3"] = other_config("C3 GloVe-1.2M shape", 1_183_514, 100, 1, 32, 200, 256, 100, 2, 200, "hnsw_search_kernel<2,4,4,1,0,0>")
+            others["C3"] = other_config("C3 GloVe-1.2M shape", 1_183_514, 100, 1, 32, 200, 256, 100, 2, 200,
+                                        {"TBps": 6.84, "what": "random whole 384-byte rows (the split layout's main rows) from a 1.07 GB table, independent "
+                                                                "requests, 4-8 waves/SIMD: tools/gather_ceiling.hip, profiles/r04_gather_ceiling.txt (6.22 from 4.3 GB; "
+                                                                "this index is 2.5 GB)"})
         except Exception as e:   # never lose the headline line to a secondary leg
             others["C3"] = {"skipped": "failed: %r" % (e,)}
         if free_gb is not None and free_gb < 24:
             others["C5"] = {"skipped": "needs about 12 GB of host memory for the vectors and the exported graph; %.1f GB free" % free_gb}
         else:
             try:
-                others["C5"] = other_config("C5 DEEP10M shape", 10_000_000, 96, 0, 32, 200, 512, 10, 3, 100, "hnsw_search_kernel<2,4,8,0,0,0>")
+                others["C5"] = other_config("C5 DEEP10M shape", 10_000_000, 96, 0, 32, 200, 512, 10, 3, 100,
+                                            {"TBps": 6.44, "what": "random whole 384-byte rows from a 6.4 GB table, independent requests, the same at 4, 5 and 8 "
+                                                                    "waves/SIMD and 1-8 batches in flight: tools/gather_ceiling.hip, profiles/r04_gather_ceiling.txt"})
             except Exception as e:
                 others["C5"] = {"skipped": "failed: %r" % (e,)}
 
@@ -810,7 +934,7 @@ def main():
                             kn = row.get("Kernel_Name", "")
                             if "hnsw_search_kernel" not in kn:
                                 continue
-                            key_ = "bytes" if kn.replace(" ", "").startswith(("voidhnsw_dev::hnsw_search_kernel<2,4,2,0,0,2>", "hnsw_dev::hnsw_search_kernel<2,4,2,0,0,2>")) or "<2,4,2,0,0,2>" in kn.replace(" ", "") else "float32"
+                            key_ = "bytes" if kernel_rows_of(kn) == 2 else "float32"      # the ROWS template argument, whatever d and ef are
                             a_ = pmc.setdefault(key_, {}).setdefault(row["Counter_Name"], [0.0, 0])
                             a_[0] += float(row["Counter_Value"]); a_[1] += 1
                 for key_ in ("bytes", "float32"):
@@ -829,13 +953,15 @@ def main():
             return None, None
         traffic_ = int(2 * c_["FETCH_SIZE"] * 1024) if "FETCH_SIZE" in c_ else None     # gfx950: FETCH_SIZE (KB) counts 128-B requests at 64 B
         issue_ = None
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count          # 256 on MI355X
+        n_simd, n_se = 4 * n_cu, max(1, n_cu // 8)                                   # four SIMDs per CU; shader engines of 8 CUs (32)
         if "SQ_INSTS_VALU" in c_ and c_.get("SQ_BUSY_CYCLES"):
-            cyc = c_["SQ_BUSY_CYCLES"] / 32.0            # summed over the chip's 32 shader engines
+            cyc = c_["SQ_BUSY_CYCLES"] / float(n_se)     # summed over the chip's shader engines
             tot = c_["SQ_INSTS_VALU"] + c_["SQ_INSTS_SALU"] + c_.get("SQ_INSTS_LDS", 0) + c_.get("SQ_INSTS_VMEM_RD", 0)
             # capacities measured with tools/issue_latency.hip at 8 waves per SIMD on every CU (profiles/r03_issue_latency.txt):
             # a SIMD issues one simple vector wave-instruction per ~2.4 cycles (v_dot4 / v_mad_u64 per ~4.3), a CU one scalar
             # instruction per cycle for its four SIMDs; a wave alone issues at most one instruction of any kind per 4 cycles
-            issue_ = {"valu": round(c_["SQ_INSTS_VALU"] * 2.4 / (1024 * cyc), 4), "salu": round(c_["SQ_INSTS_SALU"] / (256 * cyc), 4),
+            issue_ = {"valu": round(c_["SQ_INSTS_VALU"] * 2.4 / (n_simd * cyc), 4), "salu": round(c_["SQ_INSTS_SALU"] / (n_cu * cyc), 4),
                       "what": "share of the issue capacity the launch had, from measured capacities (tools/issue_latency.hip): vector = "
                               "wave-instructions x 2.4 cycles / (1024 SIMDs x kernel cycles) (a lower bound: dot products and 64-bit "
                               "multiply-adds take 4.3); scalar = instructions / (256 CUs x kernel cycles) (one scalar issue per cycle "
@@ -843,7 +969,7 @@ def main():
                       "SQ_INSTS_VALU": c_["SQ_INSTS_VALU"], "SQ_INSTS_SALU": c_["SQ_INSTS_SALU"], "SQ_INSTS_LDS": c_.get("SQ_INSTS_LDS"),
                       "SQ_INSTS_VMEM_RD": c_.get("SQ_INSTS_VMEM_RD"), "kernel_cycles": round(cyc, 1),
                       "clock_GHz": round(cyc / (kernel_ms_ * 1e6), 3) if kernel_ms_ else None,
-                      "instructions_per_hop": None, "wave_occupancy": round(c_["SQ_WAVE_CYCLES"] * 4.0 / (8192 * cyc), 4) if c_.get("SQ_WAVE_CYCLES") else None,
+                      "instructions_per_hop": None, "wave_occupancy": round(c_["SQ_WAVE_CYCLES"] * 4.0 / (8 * n_simd * cyc), 4) if c_.get("SQ_WAVE_CYCLES") else None,
                       "instructions_per_dispatch": tot,
                       "source": "rocprofv3 --pmc pass of this run (a child process on the same index and batch, 5 dispatches)"}
         return traffic_, issue_
@@ -937,7 +1063,11 @@ def main():
                     "kernel": kname, "kernel_ms": round(kernel_ms, 4), "row_bytes": row_bytes,
                     "bytes_per_query": round(bq, 1), "n_dist_per_query": round(n_dist_mean, 1),
                     "n_hops_per_query": round(n_hops_mean, 1), "counters": src,
-                    "step": {"device_call_ms": round(kern_ms, 4), "device_call_ms_stats": headline_steps, "prepass_ms": round(prepass_ms, 4),
+                    "kernel_ms_source": "HIP events the library records on its launch stream around its own launches (option "
+                                        "time_kernels), mean over the %d timed steps of `value`" % args.steps,
+                    "step": {"host_call_ms": round(1e3 * wall / args.steps, 4), "host_call_ms_stats": host_stats,
+                             "device_call_ms": round(kern_ms, 4), "device_call_ms_stats": headline_steps, "prepass_ms": round(prepass_ms, 4),
+                             "kernel_ms_in_device_resident_steps": round(dev_lib["search_ms"], 4),
                              "prepass": "hnsw_descent_kernel + radix sort (longest-first ordering)" if ordered else None,
                              "bytes_per_query_whole_path": round(bq_total, 1),
                              "n_dist_before_layer0_per_query": None if n_upper_mean is None else round(n_upper_mean, 1),
@@ -962,30 +1092,64 @@ def main():
                                         "what": "option byte_rows = 0: the same index, batch and steps through the float32 rows"}
 
     if rank == 0:
+        gate_ok = checks.get("recall_at_10", 0) >= 0.95
+        harder_gate = None
+        if secondary:
+            harder_gate = ({"ef": ef, "recall_at_10": secondary["checks"]["recall_at_10"], "value": secondary.get("value_host_protocol"),
+                            "device_resident_value": secondary["value"], "unit": "queries/s"}
+                           if secondary["checks"]["recall_at_10"] >= 0.95 else secondary.get("at_recall_0.95"))
+        fl = roofline.get("float32_rows") if roofline else None
+        # which synthetic set is the closer stand-in for SIFT1M (about 2.5-3 k evaluations per query at ef 128)
+        nd_head = roofline["n_dist_per_query"] if roofline else None
+        nd_hard = secondary["roofline"]["n_dist_per_query"] if secondary else None
         out = {
             "metric": "queries/sec at recall@10>=0.95, SIFT1M d=128 ef=128 k=10",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # the arithmetic of the timed kernel, not a precision claim: byte rows are gathered as uint8 and summed with
+            # v_dot4_u32_u8 (exact: every partial sum < 2^24, the float32 result bit for bit); float data computes in f32
+            "dtype": "u8 rows, u32 dot products (exact) -> f32 distances" if byte_rows else "f32",
             "data": ("file:" + os.path.basename(os.path.normpath(args.dataset))) if args.dataset else "synthetic",
             "config": {"workload": "C2: %s (n=%d d=%d), M=%d efConstruction=%d "
-                                   "(graph built on the GPU), ef=%d k=%d, %d queries per GPU per step, replicated index%s"
+                                   "(graph built on the GPU), ef=%d k=%d, %d queries per GPU per step, replicated index%s; this set is the one SURVEY 8d "
+                                   "prescribes and is EASIER than SIFT1M (%s evaluations per query where SIFT1M needs about 2.5-3 k at ef 128): "
+                                   "the harder set of `secondary` (%s evaluations per query) is the closer stand-in, see `harder_set_at_recall_gate`"
                                    % ("vectors from " + args.dataset if args.dataset else "SIFT1M-shaped synthetic, clustered ints 0..218 stored as float32",
                                       n, d, args.M, args.efc, ef, k, nq,
-                                      ", RCCL all-gather of results" if world > 1 else ""),
+                                      ", RCCL all-gather of results" if world > 1 else "", nd_head, nd_hard),
                        "n": n, "d": d, "M": args.M, "ef_construction": args.efc, "ef": ef, "k": k,
                        "queries_per_gpu": nq, "global_batch": world * nq, "parallelism": "replica x%d" % world,
-                       "rows": "bytes (lossless copy of integer-valued float32 data)" if byte_rows else "float32"},
-            "protocol": "hnsw_search_batch_device: queries resident in HBM before the timed region, results left in HBM "
-                        "(the host-buffer drop-in call is timed in `drop_in`)",
+                       "rows": "bytes (lossless copy of integer-valued float32 data)" if byte_rows else "float32",
+                       "headline_set": {"n_dist_per_query": nd_head, "recall_at_10": checks.get("recall_at_10"), "ef": ef},
+                       "harder_set": (None if not secondary else
+                                      {"n_dist_per_query": nd_hard, "recall_at_10": secondary["checks"]["recall_at_10"], "ef": ef,
+                                       "ef_at_recall_gate": (ef if secondary["checks"]["recall_at_10"] >= 0.95 else (secondary.get("at_recall_0.95") or {}).get("ef")),
+                                       "closer_to_SIFT1M": True})},
+            "protocol": ("one synchronous call per %d-query batch with HOST matrices in and out, as benchmark/benchmark.ml:89-96 times knn_batch "
+                         "and SURVEY 8d prescribes: " % nq) +
+                        ("hnsw_search_batch (H2D of the queries, ordering pre-pass, search kernel, D2H of the results; the caller's matrices "
+                         "registered once with hnsw_host_register)" if world == 1 else
+                         "per rank H2D of its query shard (pinned), search, RCCL all-gather of the per-shard results (the full table resident on every "
+                         "GPU), D2H of the rank's own shard, stream synchronisation") +
+                        "; the rate with the queries already resident in HBM and the results left there is `device_resident`",
+            "device_resident": {"value": round(qps_dev, 1), "unit": "queries/s", "ms_per_step": round(1e3 * wall_dev / args.steps, 4),
+                                "ms_per_step_stats": headline_steps, "kernel_ms": round(dev_lib["search_ms"], 4), "prepass_ms": round(dev_lib["prepass_ms"], 4),
+                                "what": "hnsw_search_batch_device: the same %d steps with the queries resident in HBM before the timed region and the "
+                                        "results left in HBM%s" % (args.steps, " (search of step i+1 overlapped with the all-gather of step i)" if world > 1 else "")},
+            "float32_rows": (None if not fl else
+                             {"value": round(nq * args.steps / fp32_leg["host_wall"], 1), "unit": "queries/s",
+                              "ms_per_step": round(1e3 * fp32_leg["host_wall"] / args.steps, 4), "ms_per_step_stats": fp32_leg["host_stats"],
+                              "device_resident_value": fl["value"], "frac": fl["frac"], "kernel": fl["kernel"], "kernel_ms": fl["kernel_ms"],
+                              "what": "option byte_rows = 0: the same index, batch and protocol through the float32 rows (the general-format kernel, "
+                                      "what data that is not byte-valued takes); details in roofline.float32_rows"}),
+            "harder_set_at_recall_gate": harder_gate,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "drop_in": drop_in, "secondary": secondary,
             "recall_gate": {"threshold": 0.95, "metric": "id-set recall@10 against exact brute force",
-                            "headline_set": {"ef": ef if checks.get("recall_at_10", 0) >= 0.95 else checks.get("ef_for_recall_0.95"),
-                                             "recall_at_10": checks.get("recall_at_10") if checks.get("recall_at_10", 0) >= 0.95 else checks.get("recall_at_that_ef"),
-                                             "value": round(qps, 1) if checks.get("recall_at_10", 0) >= 0.95 else checks.get("qps_at_that_ef")},
-                            "harder_set": (None if not secondary else
-                                           ({"ef": ef, "recall_at_10": secondary["checks"]["recall_at_10"], "value": secondary["value"]}
-                                            if secondary["checks"]["recall_at_10"] >= 0.95 else secondary.get("at_recall_0.95")))} if rank == 0 and world == 1 else None,
+                            "headline_set": {"ef": ef if gate_ok else checks.get("ef_for_recall_0.95"),
+                                             "recall_at_10": checks.get("recall_at_10") if gate_ok else checks.get("recall_at_that_ef"),
+                                             "value": round(qps, 1) if gate_ok else checks.get("qps_at_that_ef")},
+                            "harder_set": harder_gate} if rank == 0 and world == 1 else None,
             "others": others, "bench_dist": bench_dist, "strong": strong, "pipelined": pipelined, "checks": checks,
         }
         _restore_stdout(saved_stdout)

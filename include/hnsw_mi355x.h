@@ -276,8 +276,9 @@ int32_t hnsw_search_one_batch(hnsw_index *idx, int32_t layer, const float *targe
  * exactness fallback for tie-list overflow runs per shard before the exchange.
  * RCCL is bound at first use (dlopen librccl.so.1).  A device may be listed more than once (several
  * replicas on one GPU: a test arrangement); RCCL refuses that, the exchange is then device-to-device
- * copies.  The caller's host arrays are pinned (hipHostRegister) on first sight and stay pinned until
- * hnsw_multi_destroy.  (One process PER GPU, each with its own RCCL rank, is the other deployment:
+ * copies.  The library pins nothing of the caller's: the shard uploads run at PCIe speed when the caller registered its
+ * query matrix with hnsw_host_register (its lifetime, not the library's) and are staged by the runtime otherwise.
+ * (One process PER GPU, each with its own RCCL rank, is the other deployment:
  * ocaml-hnsw_amd/sharding.py and bench.py.) */
 typedef struct hnsw_multi hnsw_multi;
 int32_t hnsw_multi_create(const hnsw_index_desc *desc, const int32_t *devices, int32_t n_devices,
@@ -297,6 +298,10 @@ int32_t hnsw_multi_search_batch(hnsw_multi *m, const float *queries, int64_t nq,
  * NULL). */
 int32_t hnsw_multi_search_batch_device(hnsw_multi *m, const float *queries, int64_t nq, int64_t q_stride,
                                        const hnsw_search_params *params, int32_t **d_ids, float **d_dist);
+/* What the exchanges of this handle were made of so far (tests, debugging): out4 = { ncclAllGather calls, ncclBroadcast
+ * calls (unequal shards, and the re-send of a repaired shard), device-to-device copies (replicas sharing a device),
+ * shards searched again by the exactness fallback }, each summed over the devices. */
+int32_t hnsw_multi_debug_counters(const hnsw_multi *m, int64_t *out4);
 /* device g's copy of the last device-resident result, copied to host arrays [nq][k] (tests, debugging) */
 int32_t hnsw_multi_copy_result(hnsw_multi *m, int32_t g, int32_t *out_ids, float *out_dist);
 
@@ -340,7 +345,10 @@ int32_t hnsw_index_export_upper(const hnsw_index *idx, int32_t layer, int64_t *n
                                 int32_t *nbr);
 
 /* Per-layer degree statistics: Hgraph.Stats.compute (lib/hnsw.ml:353-375; printed by
- * benchmark/benchmark.ml:70-71): layer size and min / max / mean / isolated of the degrees. */
+ * benchmark/benchmark.ml:70-71): layer size (layer_sizes) and the layer's mima record -- min / max / mean of the
+ * neighbour-list lengths, the nodes without a neighbour.  Computed on the device from the resident tables.  The keys of
+ * layer l >= 1 are the nodes inserted at level >= l.  A layer without nodes yields what the reference's fold yields:
+ * min 1000000, max -1, mean nan. */
 typedef struct hnsw_layer_stats {
     int64_t num_nodes;     /* layer_sizes */
     int32_t min_degree, max_degree;
@@ -348,6 +356,10 @@ typedef struct hnsw_layer_stats {
     int64_t num_isolated;  /* length of mima.isolated */
 } hnsw_layer_stats;
 int32_t hnsw_index_layer_stats(const hnsw_index *idx, int32_t layer, hnsw_layer_stats *out);
+/* mima.isolated of that layer: the node ids (id_base-based) in the reference's list order -- min_max_connectivity
+ * conses a key onto the list as the ascending Map.fold meets it (lib/hnsw.ml:364-366), so the list is DESCENDING.
+ * *count = length of the list; the first min(cap, *count) ids are written (cap = 0, ids = NULL: count only). */
+int32_t hnsw_index_layer_isolated(const hnsw_index *idx, int32_t layer, int64_t *ids, int64_t cap, int64_t *count);
 
 /* Flattened-index file (new: the reference has no persistence; its types derive sexp but values
  * are sexp_opaque and nothing reads one back, lib/hnsw.ml:348, lib/ohnsw.ml:312).  Little-endian

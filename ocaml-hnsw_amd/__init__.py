@@ -33,11 +33,11 @@ ABI_SYMBOLS = [
     "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_index_row_bytes", "hnsw_search_batch",
     "hnsw_search_batch_device", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
-    "hnsw_index_layer_stats", "hnsw_index_save", "hnsw_index_load",
+    "hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_save", "hnsw_index_load",
     "hnsw_search_layer_batch", "hnsw_search_one_batch",
     "hnsw_search_submit", "hnsw_search_wait", "hnsw_index_kernel_times",
     "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
-    "hnsw_multi_search_batch_device", "hnsw_multi_copy_result",
+    "hnsw_multi_search_batch_device", "hnsw_multi_copy_result", "hnsw_multi_debug_counters",
     "hnsw_host_register", "hnsw_host_unregister",
 ]
 
@@ -116,9 +116,10 @@ def load():
     L.hnsw_select_neighbours_batch.argtypes = [vp, vp, i64, i64, vp, vp, i32, i32, i32, vp, vp, vp]
     L.hnsw_select_neighbours_batch.restype = i32
     L.hnsw_index_layer_stats.argtypes = [vp, i32, vp]
+    L.hnsw_index_layer_isolated.argtypes = [vp, i32, vp, i64, vp]
     L.hnsw_index_save.argtypes = [vp, _C.c_char_p]
     L.hnsw_index_load.argtypes = [_C.c_char_p, i32, vp]
-    for f in ("hnsw_index_layer_stats", "hnsw_index_save", "hnsw_index_load"):
+    for f in ("hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_save", "hnsw_index_load"):
         getattr(L, f).restype = i32
     L.hnsw_index_export_layer0.argtypes = [vp, vp, vp]
     L.hnsw_index_export_upper_count.argtypes = [vp, i32, vp]
@@ -144,13 +145,14 @@ def load():
     L.hnsw_multi_search_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp]
     L.hnsw_multi_search_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp]
     L.hnsw_multi_copy_result.argtypes = [vp, i32, vp, vp]
+    L.hnsw_multi_debug_counters.argtypes = [vp, vp]
     if hasattr(L, "hnsw_host_register"):      # (an older build of the library, loaded by tools/ab.py for comparison, lacks them)
         L.hnsw_host_register.argtypes = [vp, i64]
         L.hnsw_host_unregister.argtypes = [vp]
         L.hnsw_host_register.restype = L.hnsw_host_unregister.restype = i32
     for f in ("hnsw_search_layer_batch", "hnsw_search_one_batch", "hnsw_multi_create", "hnsw_multi_destroy",
               "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
-              "hnsw_multi_search_batch_device", "hnsw_multi_copy_result"):
+              "hnsw_multi_search_batch_device", "hnsw_multi_copy_result", "hnsw_multi_debug_counters"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -255,14 +257,19 @@ class Hgraph:
         return self
 
     def stats(self):
-        """Hgraph.Stats.compute (lib/hnsw.ml:353-375): {num_nodes, layer_sizes, layer_connectivity}."""
+        """Hgraph.Stats.compute (lib/hnsw.ml:353-375): {num_nodes, layer_sizes, layer_connectivity}; a layer's
+        connectivity is the reference's mima record {min, max, mean, isolated}, `isolated` the list of node ids
+        (descending, as the reference's fold conses it)."""
         out = {"num_nodes": self.n, "layer_sizes": {}, "layer_connectivity": {}}
         for l in range(self.max_layer + 1):
             st = LayerStats()
             _check(load().hnsw_index_layer_stats(self.handle, l, _C.byref(st)))
+            iso = _np.empty(max(int(st.num_isolated), 1), _np.int64)
+            c = _C.c_int64(0)
+            _check(load().hnsw_index_layer_isolated(self.handle, l, _ptr(iso), int(st.num_isolated), _C.byref(c)))
             out["layer_sizes"][l] = int(st.num_nodes)
             out["layer_connectivity"][l] = {"min": st.min_degree, "max": st.max_degree,
-                                            "mean": st.mean_degree, "isolated": int(st.num_isolated)}
+                                            "mean": st.mean_degree, "isolated": iso[:min(c.value, int(st.num_isolated))].tolist()}
         return out
 
     def save(self, path):
@@ -406,8 +413,9 @@ class Request:
             raise InvalidArgument("request already waited for")
         if out is not None:
             ids, dist = out
-            if ids.shape != (self.nq, self.k) or dist.shape != (self.nq, self.k) or ids.dtype != _np.int32 or dist.dtype != _np.float32:
-                raise InvalidArgument("out must be (int32 [nq][k], float32 [nq][k])")
+            if (ids.shape != (self.nq, self.k) or dist.shape != (self.nq, self.k) or ids.dtype != _np.int32 or dist.dtype != _np.float32
+                    or not ids.flags["C_CONTIGUOUS"] or not dist.flags["C_CONTIGUOUS"]):   # the library writes nq * k contiguous words
+                raise InvalidArgument("out must be (int32 [nq][k], float32 [nq][k]), C-contiguous")
         else:
             ids = _np.empty((self.nq, self.k), _np.int32)
             dist = _np.empty((self.nq, self.k), _np.float32)
@@ -625,6 +633,12 @@ class MultiHgraph:
         _check(load().hnsw_multi_search_batch_device(self._h, _ptr(Q), Q.shape[0], max(qs, self.hgraph.d), _C.byref(p), pi, pd))
         self._last = (Q.shape[0], k)
         return [int(x or 0) for x in pi], [int(x or 0) for x in pd]
+
+    def debug_counters(self):
+        """hnsw_multi_debug_counters -> {allgather, broadcast, peer_copies, repaired_shards}"""
+        out = (_C.c_int64 * 4)()
+        _check(load().hnsw_multi_debug_counters(self._h, out))
+        return dict(zip(("allgather", "broadcast", "peer_copies", "repaired_shards"), [int(x) for x in out]))
 
     def copy_result(self, g):
         """device g's copy of the last search_device result -> (ids, dist) host arrays"""

@@ -59,17 +59,35 @@ def build(force=False, verbose=False, resource_log=None):
     jobs = max(1, int(os.environ.get("HNSW_BUILD_JOBS", os.cpu_count() or 4)))
     pending = list(units)
     running, objs, logs = [], [], []
+    headers = [os.path.join(CSRC, h) for h in DEPS if isinstance(h, str) and h.endswith(".h") and not os.path.isabs(h)]
+    headers += [h for h in DEPS if os.path.isabs(h)]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+
+    def fresh(obj, src, cmd):
+        """an object is kept when it is newer than its source and every header and was made by the same command"""
+        try:
+            return (not force and not resource_log and os.path.getmtime(obj) >= max(newest_header, os.path.getmtime(src))
+                    and open(obj + ".cmd").read() == " ".join(cmd))
+        except OSError:
+            return False
     while pending or running:   # one hipcc per translation unit, at most `jobs` at a time
         while pending and len(running) < jobs:
             name, src, defs = pending.pop(0)
             obj = os.path.join(objdir, name + ".o")
             cmd = base + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if fresh(obj, os.path.join(CSRC, src), cmd):
+                objs.append(obj)
+                continue
+            if os.path.exists(obj + ".cmd"):
+                os.remove(obj + ".cmd")
             if verbose:
                 print(" ".join(cmd), flush=True)
             log = open(resource_log + "." + name, "w") if resource_log else None
             if log:
                 logs.append(resource_log + "." + name)
             running.append((subprocess.Popen(cmd, stderr=log), obj, cmd, log))
+        if not running:
+            continue
         pr, obj, cmd, log = running.pop(0)
         rc = pr.wait()
         if log:
@@ -78,6 +96,8 @@ def build(force=False, verbose=False, resource_log=None):
             for other in running:
                 other[0].kill()
             raise subprocess.CalledProcessError(rc, cmd)
+        with open(obj + ".cmd", "w") as f:
+            f.write(" ".join(cmd))
         objs.append(obj)
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_out]
     if verbose:

@@ -176,7 +176,7 @@ static int32_t build_attempt(const float *vectors, int64_t n, int32_t d, int64_t
     HIP_TRY_B(hipMalloc(&idx->dLvl, (size_t)n));
     HIP_TRY_B(hipMemcpy(idx->dLvl, lvl.data(), (size_t)n, hipMemcpyHostToDevice));
     if ((rc = upload_upper_ref(off.data(), lvl.data(), n, &idx->dRef))) goto done;
-    idx->rowsU = rowsU;
+    idx->rowsU = rowsU; idx->iv.rowsU = rowsU;
     {
         IndexView &iv = idx->iv;
         iv.X = (const float *)idx->dX; iv.stride = stride; iv.n = n; iv.d = d; iv.nchunks = nchunks;
@@ -450,33 +450,84 @@ int32_t hnsw_index_export_upper(const hnsw_index *idx, int32_t layer, int64_t *n
 
 
 // ---- per-layer degree statistics: Hgraph.Stats (lib/hnsw.ml:353-375) -----------------------------
-int32_t hnsw_index_layer_stats(const hnsw_index *idx, int32_t layer, hnsw_layer_stats *out) {
-    if (!idx || !out) return fail(HNSW_ERR_BAD_ARG, "null argument");
+// min_max_connectivity (:361-368) folds the layer's connections map from (1000000, -1, 0, 0., []): min / max / mean of
+// the neighbour-list lengths and the list of nodes without a neighbour.  One thread per node over the device-resident
+// tables; the keys of layer l >= 1 are the nodes whose level reaches l (upper_ref), of layer 0 every node.
+namespace {
+struct StatsAcc { unsigned long long cnt, sum, iso; int mi, ma; };
+
+__global__ void __launch_bounds__(256)
+layer_stats_kernel(const int32_t *nbr0, int32_t S0, const int32_t *nbrU, int32_t SU, const int2 *upper_ref, int64_t n,
+                   int32_t layer, StatsAcc *acc, int64_t *iso_ids, unsigned long long iso_cap) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *row; int w;
+    if (layer == 0) { row = nbr0 + i * S0; w = S0; }
+    else {
+        const int2 ref = upper_ref[i];
+        if (ref.y < layer) return;                                   // not a key of this layer
+        row = nbrU + ((int64_t)ref.x + (layer - 1)) * SU; w = SU;
+    }
+    int dg = 0;
+    for (int j = 0; j < w; ++j) dg += row[j] >= 0;                   // Neighbours.length
+    atomicAdd(&acc->cnt, 1ull); atomicAdd(&acc->sum, (unsigned long long)dg);
+    atomicMin(&acc->mi, dg); atomicMax(&acc->ma, dg);
+    if (dg == 0) {
+        const unsigned long long at = atomicAdd(&acc->iso, 1ull);
+        if (at < iso_cap) iso_ids[at] = i;
+    }
+}
+
+// runs the kernel once; with iso != nullptr also collects the isolated nodes (0-based, unordered)
+int layer_stats_device(const hnsw_index *idx, int32_t layer, StatsAcc *out, std::vector<int64_t> *iso) {
     if (layer < 0 || layer > idx->iv.max_layer) return fail(HNSW_ERR_BAD_ARG, "layer %d out of range", layer);
     HIP_TRY(hipSetDevice(idx->device));
     const int64_t n = idx->iv.n;
-    int64_t cnt = 0, isolated = 0, sum = 0;
-    int mi = 1000000, ma = -1;
-    auto add = [&](const int32_t *row, int w) {
-        int dg = 0;
-        for (int j = 0; j < w; ++j) dg += row[j] >= 0;
-        mi = std::min(mi, dg); ma = std::max(ma, dg); sum += dg; cnt++; isolated += dg == 0;
-    };
-    if (layer == 0) {
-        std::vector<int32_t> rows((size_t)std::max<int64_t>(n, 1) * idx->iv.S0);
-        HIP_TRY(hipMemcpy(rows.data(), idx->dNbr0, (size_t)n * idx->iv.S0 * 4, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; ++i) add(&rows[(size_t)i * idx->iv.S0], idx->iv.S0);
-    } else {
-        std::vector<uint8_t> lvl((size_t)std::max<int64_t>(n, 1));
-        std::vector<int32_t> off((size_t)std::max<int64_t>(n, 1)), rows((size_t)std::max<int64_t>(idx->rowsU, 1) * idx->iv.SU);
-        HIP_TRY(hipMemcpy(lvl.data(), idx->dLvl, (size_t)n, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(off.data(), idx->dOff, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(rows.data(), idx->dNbrU, rows.size() * 4, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; ++i)
-            if (lvl[(size_t)i] >= layer) add(&rows[((size_t)off[(size_t)i] + (layer - 1)) * idx->iv.SU], idx->iv.SU);
+    StatsAcc h{0, 0, 0, 1000000, -1};
+    if (n == 0) { *out = h; if (iso) iso->clear(); return HNSW_OK; }
+    DevBuf dAcc, dIso;
+    struct Guard { DevBuf &a, &b; ~Guard() { a.release(); b.release(); } } guard{dAcc, dIso};
+    int rc;
+    if ((rc = dAcc.ensure(sizeof(StatsAcc)))) return rc;
+    unsigned long long cap = 0;
+    for (int pass = 0; pass < 2; ++pass) {                          // second pass only when there are isolated nodes to list
+        HIP_TRY(hipMemcpy(dAcc.p, &h, sizeof h, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(layer_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, idx->iv.nbr0, idx->iv.S0,
+                           idx->iv.nbrU, idx->iv.SU, idx->iv.upper_ref, n, layer, (StatsAcc *)dAcc.p, (int64_t *)dIso.p, cap);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out, dAcc.p, sizeof *out, hipMemcpyDeviceToHost));
+        if (!iso || out->iso == 0 || pass == 1) break;
+        cap = out->iso;
+        if ((rc = dIso.ensure((size_t)cap * 8))) return rc;
     }
-    out->num_nodes = cnt; out->min_degree = cnt ? mi : 0; out->max_degree = cnt ? ma : 0;
-    out->mean_degree = cnt ? (double)sum / (double)cnt : 0.0; out->num_isolated = isolated;
+    if (iso) {
+        iso->resize((size_t)out->iso);
+        if (out->iso) HIP_TRY(hipMemcpy(iso->data(), dIso.p, (size_t)out->iso * 8, hipMemcpyDeviceToHost));
+    }
+    return HNSW_OK;
+}
+} // namespace
+
+int32_t hnsw_index_layer_stats(const hnsw_index *idx, int32_t layer, hnsw_layer_stats *out) {
+    if (!idx || !out) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    StatsAcc a;
+    int rc = layer_stats_device(idx, layer, &a, nullptr);
+    if (rc) return rc;
+    out->num_nodes = (int64_t)a.cnt; out->min_degree = a.mi; out->max_degree = a.ma;       // empty layer: 1000000 / -1 / nan, as the fold's
+    out->mean_degree = (double)a.sum / (double)a.cnt;                                      // initial value leaves them (0. /. 0.)
+    out->num_isolated = (int64_t)a.iso;
+    return HNSW_OK;
+}
+
+int32_t hnsw_index_layer_isolated(const hnsw_index *idx, int32_t layer, int64_t *ids, int64_t cap, int64_t *count) {
+    if (!idx || !count || cap < 0 || (cap > 0 && !ids)) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    StatsAcc a;
+    std::vector<int64_t> iso;
+    int rc = layer_stats_device(idx, layer, &a, &iso);
+    if (rc) return rc;
+    std::sort(iso.begin(), iso.end(), [](int64_t x, int64_t y) { return x > y; });   // key :: isolated during an ascending fold: descending ids
+    *count = (int64_t)iso.size();
+    for (int64_t i = 0; i < std::min<int64_t>(cap, (int64_t)iso.size()); ++i) ids[i] = iso[(size_t)i] + idx->iv.id_base;
     return HNSW_OK;
 }
 

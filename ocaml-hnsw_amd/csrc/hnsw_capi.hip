@@ -312,7 +312,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
     iv.nbrU = (const int32_t *)idx->dNbrU; iv.upper_off = (const int32_t *)idx->dOff;
     iv.upper_lvl = (const uint8_t *)idx->dLvl;
     iv.max_layer = d->max_layer; iv.entry_point = (int32_t)ep; iv.id_base = base;
-    idx->rowsU = rowsU;
+    idx->rowsU = rowsU; iv.rowsU = rowsU;
 
     hnsw_index_info &inf = idx->info;
     inf.n = n; inf.d = d->d; inf.metric = d->metric; inf.id_base = base; inf.max_degree0 = S0;
@@ -338,6 +338,7 @@ int32_t hnsw_index_destroy(hnsw_index *idx) {
     for (hipStream_t st : idx->hs) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : idx->tev) (void)hipEventDestroy(e);
     for (auto &o : idx->order_scratch) if (o.p) (void)hipFree(o.p);
+    if (idx->hFlag) (void)hipHostFree(idx->hFlag);
     delete idx;
     return HNSW_OK;
 }
@@ -406,7 +407,8 @@ extern "C++" {
 namespace hnsw_host {
 int search_batch_device_flag(hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
                              const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
-                             uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, uint32_t *d_any_flag, void *stream);
+                             uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, uint32_t *d_any_flag, void *stream,
+                             float *d_stage);
 }
 }
 int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
@@ -416,7 +418,8 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
 }
 extern "C++" int hnsw_host::search_batch_device_flag(hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
                                  const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
-                                 uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, uint32_t *d_any_flag, void *stream) {
+                                 uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, uint32_t *d_any_flag, void *stream,
+                                 float *d_stage) {
     int rc = check_params(idx, params);
     if (rc) return rc;
     if (nq < 0 || nq > 0x7FFFFFFFLL) return fail(HNSW_ERR_BAD_ARG, "nq out of range");
@@ -448,8 +451,9 @@ extern "C++" int hnsw_host::search_batch_device_flag(hnsw_index *idx, const floa
     // dispatched first and spread over the CUs (C2, 7168 queries: 0.59 -> 0.45 ms byte rows, 0.68 -> 0.65 ms fp32);
     // below that the pre-pass costs more than it returns.
     if (mode != 0 && (mode == 1 || 2 * nq > resident_queries(idx, params->ef, params->semantics ? 1 : 0))) {
-        rc = order_longest_first(idx, d_queries, nq, q_stride, (hipStream_t)stream, &block, &a.qmap, &a.pre_entry, &a.pre_key, &a.pre_nd, &a.pre_layer);
+        rc = order_longest_first(idx, d_queries, nq, q_stride, d_stage, (hipStream_t)stream, &block, &a.qmap, &a.pre_entry, &a.pre_key, &a.pre_nd, &a.pre_layer);
         if (rc) return rc;
+        if (d_stage) a.Q = d_stage;        // the descent kernel left a device-resident copy of the (host-resident) queries
         a.q_limit = nq;
         a.lds_pad = balanced_lds_pad(idx, nq, params->ef, params->semantics ? 1 : 0);
         launch_priorities(idx, nq, params->ef, params->semantics ? 1 : 0, a);
@@ -501,44 +505,78 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
         (rc = idx->sNh.ensure((size_t)nq * 4)) || (rc = idx->sSt.ensure((size_t)nq * 4)) || (rc = idx->sFlag.ensure(16)))
         return rc;
     // Upload, search (ordered longest walk first when the batch is larger than the chip holds) and download on one
-    // of the handle's streams, ONE stream synchronisation at the end.  The copies run at PCIe speed when the caller
-    // registered its arrays (hnsw_host_register); from pageable memory the runtime stages them.  Whether any query
-    // needs the exactness fallback comes back as one word beside the results (the kernel sets it), not as a scan of
-    // nq status words.  (Splitting the batch into chunks on two streams to overlap the copies with the search was
-    // measured too: 1.08 ms against 1.06 ms for this.)
+    // of the handle's streams, ONE stream synchronisation at the end.
+    //
+    // Matrices the caller registered (hnsw_host_register) are not copied at all: the device reads the queries straight
+    // from the caller's matrix -- each query once, by the wave that searches it (the descent pre-pass keeps a device copy
+    // for the search kernel), so the 5 MB of a 10 k x 128 batch cross PCIe UNDER the descent instead of before it -- and
+    // the kernel writes each query's results straight into the caller's result matrices as the query finishes, so there is
+    // no download step behind the launch either.  Pageable matrices are staged through hipMemcpyAsync as before.  Whether
+    // any query needs the exactness fallback comes back as one word (pinned host memory, the kernel stores it), not as a
+    // scan of nq status words.  (Splitting the batch into chunks on two streams to overlap copies and search measured
+    // 1.08 against 1.06 ms in round 1.)  HNSW_ZERO_COPY=0 switches the direct access off.
     if (!idx->hs[0]) HIP_TRY(hipStreamCreateWithFlags(&idx->hs[0], hipStreamNonBlocking));
     hipStream_t st = idx->hs[0];
-    const float *dQ = (const float *)idx->sQ.p;
-    uint32_t flag = 0;
-    HIP_TRY(hipMemsetAsync(idx->sFlag.p, 0, 4, st));
-    HIP_TRY(hipMemcpyAsync(idx->sQ.p, queries, qbytes, hipMemcpyHostToDevice, st));
-    rc = search_batch_device_flag(idx, dQ, nq, q_stride, params, (int32_t *)idx->sIds.p, (float *)idx->sDist.p,
-                                  (uint32_t *)idx->sNd.p, (uint32_t *)idx->sNh.p, (uint32_t *)idx->sSt.p, (uint32_t *)idx->sFlag.p, st);
+    if (!idx->hFlag) {
+        HIP_TRY(hipHostMalloc((void **)&idx->hFlag, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&idx->hFlagDev, idx->hFlag, 0));
+    }
+    // device address of a registered host range (both ends checked), or nullptr
+    auto mapped = [&](const void *p, size_t bytes) -> void * {
+        static const int enabled = env_int("HNSW_ZERO_COPY", 1);
+        if (!enabled || !p || bytes == 0) return nullptr;
+        hipPointerAttribute_t a0{}, a1{};
+        if (hipPointerGetAttributes(&a0, p) != hipSuccess || hipPointerGetAttributes(&a1, (const char *)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost) return nullptr;
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, const_cast<void *>(p), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return dp;
+    };
+    const float *zq = (const float *)mapped(queries, qbytes);
+    int32_t *zi = (int32_t *)mapped(out_ids, (size_t)nq * k * 4);
+    float *zd = (float *)mapped(out_dist, (size_t)nq * k * 4);
+    uint32_t *znd = out_ndist ? (uint32_t *)mapped(out_ndist, (size_t)nq * 4) : nullptr;
+    uint32_t *znh = out_nhops ? (uint32_t *)mapped(out_nhops, (size_t)nq * 4) : nullptr;
+    if (!zi || !zd) zi = nullptr, zd = nullptr;                      // results: both matrices or neither
+    const float *dQ = zq ? zq : (const float *)idx->sQ.p;            // where the queries can be read from the device
+    int32_t *dI = zi ? zi : (int32_t *)idx->sIds.p;
+    float *dD = zi ? zd : (float *)idx->sDist.p;
+    uint32_t *dNd = znd ? znd : (uint32_t *)idx->sNd.p, *dNh = znh ? znh : (uint32_t *)idx->sNh.p;
+    *idx->hFlag = 0;
+    if (!zq) HIP_TRY(hipMemcpyAsync(idx->sQ.p, queries, qbytes, hipMemcpyHostToDevice, st));
+    rc = search_batch_device_flag(idx, dQ, nq, q_stride, params, dI, dD, dNd, dNh, (uint32_t *)idx->sSt.p, idx->hFlagDev, st,
+                                  zq ? (float *)idx->sQ.p : nullptr);
     if (rc) { (void)hipStreamSynchronize(st); return rc; }
     auto copy_out = [&](hipStream_t s_) -> int {
-        HIP_TRY(hipMemcpyAsync(out_ids, idx->sIds.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s_));
-        HIP_TRY(hipMemcpyAsync(out_dist, idx->sDist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s_));
-        if (out_ndist) HIP_TRY(hipMemcpyAsync(out_ndist, idx->sNd.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s_));
-        if (out_nhops) HIP_TRY(hipMemcpyAsync(out_nhops, idx->sNh.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s_));
+        if (!zi) {
+            HIP_TRY(hipMemcpyAsync(out_ids, idx->sIds.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s_));
+            HIP_TRY(hipMemcpyAsync(out_dist, idx->sDist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s_));
+        }
+        if (out_ndist && !znd) HIP_TRY(hipMemcpyAsync(out_ndist, idx->sNd.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s_));
+        if (out_nhops && !znh) HIP_TRY(hipMemcpyAsync(out_nhops, idx->sNh.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s_));
         return HNSW_OK;
     };
-    if ((rc = copy_out(st))) { (void)hipStreamSynchronize(st); return rc; }
-    HIP_TRY(hipMemcpyAsync(&flag, idx->sFlag.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (!(flag & 1u)) return HNSW_OK;
+    rc = copy_out(st);
+    {   // no return while a copy into the caller's arrays may still be queued
+        const hipError_t es = hipStreamSynchronize(st);
+        if (rc) return rc;
+        if (es != hipSuccess) return fail(HNSW_ERR_HIP, "search failed: %s", hipGetErrorString(es));
+    }
+    if (!(*idx->hFlag & 1u)) return HNSW_OK;
     // Exactness fallback for queries whose tie-overflow stack outgrew its LDS slots (rare: the rows
     // of the whole batch are then copied out again)
     int64_t n_rerun = 0;
     rc = rerun_overflowed(idx, nq, (const uint32_t *)idx->sSt.p,
                           [&](const int32_t *qmap, int64_t c, uint32_t *slab, int32_t cap) {
-                              return search_rerun_device(idx, dQ, nq, q_stride, params, (int32_t *)idx->sIds.p, (float *)idx->sDist.p,
-                                                         (uint32_t *)idx->sNd.p, (uint32_t *)idx->sNh.p, (uint32_t *)idx->sSt.p,
+                              return search_rerun_device(idx, dQ, nq, q_stride, params, dI, dD, dNd, dNh, (uint32_t *)idx->sSt.p,
                                                          qmap, c, slab, cap, nullptr);
                           }, &n_rerun);
     if (rc) return rc;
     if (n_rerun > 0) {
-        if ((rc = copy_out(nullptr))) return rc;
-        HIP_TRY(hipDeviceSynchronize());
+        rc = copy_out(nullptr);
+        const hipError_t es = hipDeviceSynchronize();
+        if (rc) return rc;
+        if (es != hipSuccess) return fail(HNSW_ERR_HIP, "result download failed: %s", hipGetErrorString(es));
     }
     return HNSW_OK;
 }
@@ -597,7 +635,10 @@ int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uin
         if (e0 == hipSuccess && out_ndist) e0 = hipMemcpyAsync(out_ndist, r->nd.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
         if (e0 == hipSuccess && out_nhops) e0 = hipMemcpyAsync(out_nhops, r->nh.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
         if (e0 == hipSuccess) e0 = hipMemcpyAsync(&flag, r->flag.p, 4, hipMemcpyDeviceToHost, st);
-        if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);
+        // synchronise whatever happened: copies already queued target the caller's arrays and `flag` (a stack word),
+        // and the request goes back to the pool only once its stream is idle
+        const hipError_t es = hipStreamSynchronize(st);
+        if (e0 == hipSuccess) e0 = es;
         if (e0 != hipSuccess) return done(fail(HNSW_ERR_HIP, "search failed: %s", hipGetErrorString(e0)));
     }
     if (!(flag & 1u)) return done(HNSW_OK);
@@ -612,7 +653,7 @@ int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uin
     if (e == hipSuccess) e = hipMemcpyAsync(out_dist, r->dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && out_ndist) e = hipMemcpyAsync(out_ndist, r->nd.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && out_nhops) e = hipMemcpyAsync(out_nhops, r->nh.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    { const hipError_t es = hipStreamSynchronize(st); if (e == hipSuccess) e = es; }
     if (e != hipSuccess) return done(fail(HNSW_ERR_HIP, "result download failed: %s", hipGetErrorString(e)));
     return done(HNSW_OK);
 }
@@ -620,8 +661,19 @@ int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uin
 int32_t hnsw_host_register(void *p, int64_t bytes) {
     if (!p || bytes <= 0) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_register: null buffer or bytes <= 0");
     hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
-    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return HNSW_OK; }
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); e = hipSuccess; }
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostRegister(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); }
+    // The runtime answers "success" (or "already registered") for a range that merely STARTS inside an existing
+    // registration and leaves the rest pageable (measured on ROCm 7.2: a 1 MB prefix registered, then the 4 MB array:
+    // success, last byte still unregistered).  The whole array is registered only if both of its ends are.
+    auto locked = [](const void *q) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    if (!locked(p) || !locked((const char *)p + bytes - 1))
+        return fail(HNSW_ERR_BAD_ARG, "hnsw_host_register: part of the %lld-byte array is registered already, its end is not "
+                    "(unregister the shorter range first)", (long long)bytes);
     return HNSW_OK;
 }
 

@@ -49,6 +49,7 @@ struct IndexView {
     int32_t S0;
     int32_t SU;
     const int32_t *nbrU;     // [rowsU][SU]
+    int64_t rowsU;           // rows of nbrU (what the 32-bit row offsets of the hand-scheduled descent must reach)
     const int32_t *upper_off;// [n] first upper row of the node (layer 1), -1 if none
     const uint8_t *upper_lvl;// [n] number of upper rows of the node
     const int2 *upper_ref;   // [n] {upper_off, upper_lvl} side by side: ONE dependent load per upper-layer hop instead of two
@@ -801,8 +802,9 @@ __device__ __forceinline__ void greedy_descend(const IndexView &iv, const float4
                                                uint32_t &n_dist) {
 #if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING)
     if constexpr (NCH == 2 && METRIC == 0 && ROWS == 2) {
-        // upper rows of at most 16 neighbours (M <= 16), a byte-valued query, tables the 32-bit offsets reach
-        if (cx.qint && iv.SU <= 16 && (uint64_t)iv.n * (uint64_t)iv.SU < (1ull << 28)) {
+        // upper rows of at most 16 neighbours (M <= 16), a byte-valued query, tables the 32-bit offsets reach: the last row
+        // ends at byte (rowsU * SU) * 4, and the block multiplies (row + layer - 1) by SU * 4 in 32 bits
+        if (cx.qint && iv.SU <= 16 && ((uint64_t)iv.rowsU + 1) * (uint64_t)iv.SU < (1ull << 28)) {
             greedy_descend_bytes_l2_asm(iv, from, to, cur, cur_key, cx, n_dist);
             return;
         }
@@ -1031,7 +1033,11 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     if constexpr (NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4) && METRIC == 0 && SEM == 0 && ROWS == 2) {
         // the headline shape (d <= 128 byte rows, byte query, L2, Ohnsw rule; ef <= 64 / 65..128 / 129..256): hand-scheduled
         // loop, same results
-        if (layer == 0 && cx.qint && cx.ovf.g == nullptr && (uint64_t)iv.n * (uint64_t)iv.S0 < (1ull << 30)) {
+        // (the block forms the byte offset (id + 1) * S0 * 4 + lane * 4 of a row in 32 bits, one row ahead of the node it
+        // fetches: the row AFTER the last node's must still be below 2^32 bytes whatever S0 is; and it restores EXEC with
+        // s_mov_b64 exec, -1: it is entered with all 64 lanes on -- the kernel runs one full wave per query and reaches this
+        // point through wave-uniform branches only)
+        if (layer == 0 && cx.qint && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30)) {
             if constexpr (NSLOT == 1) { search_layer0_bytes_l2_asm1(iv, w, cx, n_dist, n_hops, status); return; }
             if constexpr (NSLOT == 4) { search_layer0_bytes_l2_asm4(iv, w, cx, n_dist, n_hops, status); return; }
             if constexpr (NSLOT == 2) {
@@ -1151,6 +1157,19 @@ __device__ __forceinline__ void load_query(float4 (&qv)[NCH], const float *qp, i
         qv[i].y = (e0 + 1 < d) ? qp[e0 + 1] : 0.f;
         qv[i].z = (e0 + 2 < d) ? qp[e0 + 2] : 0.f;
         qv[i].w = (e0 + 3 < d) ? qp[e0 + 3] : 0.f;
+    }
+}
+// the query as loaded, written to a device-resident copy by one 16-lane group (the pre-pass of a batch whose queries are read
+// straight from the caller's registered host matrix: the search kernel then reads the copy, not the PCIe bus again)
+template <int NCH>
+__device__ __forceinline__ void store_query(const float4 (&qv)[NCH], float *qp, int d, int l16) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int e0 = 4 * (i * 16 + l16);
+        if (e0 + 0 < d) qp[e0 + 0] = qv[i].x;
+        if (e0 + 1 < d) qp[e0 + 1] = qv[i].y;
+        if (e0 + 2 < d) qp[e0 + 2] = qv[i].z;
+        if (e0 + 3 < d) qp[e0 + 3] = qv[i].w;
     }
 }
 // byte rows: is the query byte-valued too (SIFT queries are)?  Then hop_round may use exact integer arithmetic.
@@ -1279,7 +1298,9 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
 #endif
         if (a.out_status) a.out_status[q] = status;
 #ifndef HNSW_PHASE_TIMING
-        if ((status & 1u) && a.any_flag) atomicOr(a.any_flag, 1u);
+        // (a plain store: the word carries this one bit, and it may live in pinned host memory, where a device atomic would
+        // need PCIe atomics)
+        if ((status & 1u) && a.any_flag) *reinterpret_cast<volatile uint32_t *>(a.any_flag) = 1u;
 #endif
     }
 }
@@ -1295,7 +1316,7 @@ template <int NCH, int RB, int METRIC, int ROWS = -1>
 __global__ void __launch_bounds__(64)
 hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq, int32_t to_layer,
                     int32_t *out_entry, uint32_t *out_key, uint32_t *out_nd,
-                    uint32_t *out_sortkey, int32_t *out_index) {
+                    uint32_t *out_sortkey, int32_t *out_index, float *stage) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
     const int64_t q = blockIdx.x;
@@ -1303,6 +1324,7 @@ hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_
     WaveCtx cx = make_ctx(lds, 4, lane);
     float4 qv[NCH];
     load_query<NCH>(qv, Q + q * q_stride, iv.d, cx.l16);
+    if (stage && cx.r == 0) store_query<NCH>(qv, stage + q * q_stride, iv.d, cx.l16);   // Q may be host memory: keep a device copy
     if (ROWS == 2) query_bytes<NCH>(cx, qv, iv.d);
     int cur = iv.entry_point;
     if (lane == 0) cx.cand_id[0] = cur;

@@ -84,6 +84,7 @@ struct hnsw_index {
     void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr, *dRef = nullptr;
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt, sFlag; // scratch for the host-buffer entry points (sFlag: the launch's "any query flagged" word)
+    uint32_t *hFlag = nullptr, *hFlagDev = nullptr;          // the same word in pinned host memory (zero-copy calls) and its device address
     hipStream_t hs[4] = {nullptr, nullptr, nullptr, nullptr}; // streams of the chunked host-buffer search and of requests (lazy)
     std::vector<hnsw_request *> free_requests;               // finished requests keep their buffers for the next submit
     std::vector<hnsw_request *> all_requests;                // every request ever created (released with the index)
@@ -116,14 +117,18 @@ int make_split_rows(::hnsw_index *idx);
 // Longest-first ordering of a large batch (hnsw_order.hip): runs the descent kernel and a radix sort
 // on `st`; on success *block points to the handle's scratch for that stream (nothing to release)
 // whose parts are returned in the other pointers.
-int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, hipStream_t st,
+// d_stage (optional): d_queries is the caller's registered HOST matrix seen from the device (zero-copy); the descent kernel
+// then leaves a device-resident copy of every query there for the search kernel
+int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, float *d_stage, hipStream_t st,
                         void **block, const int32_t **qmap, const int32_t **pre_entry, const uint32_t **pre_key,
                         const uint32_t **pre_nd, int32_t *pre_layer);
 
 // hnsw_search_batch_device plus the optional device word that collects status bit 0 of the whole launch
+// d_stage (optional, [nq][q_stride] device floats): d_queries points into registered host memory (see order_longest_first)
 int search_batch_device_flag(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride,
                              const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
-                             uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, uint32_t *d_any_flag, void *stream);
+                             uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, uint32_t *d_any_flag, void *stream,
+                             float *d_stage = nullptr);
 // parameter / handle checks shared by every search entry point (HNSW_ERR_BAD_ARG, HNSW_ERR_EMPTY_INDEX, ...)
 int search_check(const ::hnsw_index *idx, const hnsw_search_params *p);
 // launch of the exactness fallback (see rerun_overflowed): `c` flagged queries, listed in qmap, searched again

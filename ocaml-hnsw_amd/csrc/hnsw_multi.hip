@@ -69,6 +69,8 @@ struct hnsw_multi {
     int64_t last_nq = 0; int last_k = 0;
     std::vector<DevBuf> dFlag;            // per device: the launch's "any query flagged" word (see hnsw_search_batch)
     uint32_t *hFlags = nullptr;           // [G] pinned host words the flags are copied into
+    // what the exchanges of this handle were made of (hnsw_multi_debug_counters): calls issued, summed over the devices
+    int64_t n_allgather = 0, n_broadcast = 0, n_peer_copies = 0, n_repaired_shards = 0;
 };
 
 namespace {
@@ -163,6 +165,7 @@ int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q
                     const size_t cnt = (size_t)(nq / G) * k;
                     r1 = m->rccl.AllGather(ids + (size_t)g * cnt, ids, cnt, ncclInt32, m->comms[(size_t)g], m->streams[(size_t)g]);
                     if (r1 == ncclSuccess) r1 = m->rccl.AllGather(dd + (size_t)g * cnt, dd, cnt, ncclFloat32, m->comms[(size_t)g], m->streams[(size_t)g]);
+                    if (r1 == ncclSuccess) m->n_allgather += 2;
                 } else {           // unequal shards: one in-place broadcast per shard (all-gather-v)
                     for (int r = 0; r < G && r1 == ncclSuccess; ++r) {
                         if (only_shard >= 0 && r != only_shard) continue;
@@ -170,6 +173,7 @@ int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q
                         if (hi <= lo) continue;
                         r1 = m->rccl.Broadcast(ids + lo * k, ids + lo * k, (size_t)(hi - lo) * k, ncclInt32, r, m->comms[(size_t)g], m->streams[(size_t)g]);
                         if (r1 == ncclSuccess) r1 = m->rccl.Broadcast(dd + lo * k, dd + lo * k, (size_t)(hi - lo) * k, ncclFloat32, r, m->comms[(size_t)g], m->streams[(size_t)g]);
+                        if (r1 == ncclSuccess) m->n_broadcast += 2;
                     }
                 }
                 if (r1 != ncclSuccess) err = fail(HNSW_ERR_HIP, "RCCL exchange failed: %s", m->rccl.GetErrorString(r1));
@@ -197,6 +201,7 @@ int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q
                                                m->devices[(size_t)r], (size_t)(hi - lo) * k * 4, m->streams[(size_t)g]));
                     HIP_TRY(hipMemcpyPeerAsync((float *)m->dDist[(size_t)g].p + lo * k, m->devices[(size_t)g], (float *)m->dDist[(size_t)r].p + lo * k,
                                                m->devices[(size_t)r], (size_t)(hi - lo) * k * 4, m->streams[(size_t)g]));
+                    m->n_peer_copies += 2;
                 }
             }
         }
@@ -226,6 +231,7 @@ int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q
                                                                  (uint32_t *)m->dSt[(size_t)g].p, qmap, c, slab, cap, nullptr);
                                   });
             if (rc) return rc;
+            m->n_repaired_shards++;
             if ((rc = exchange(g))) return rc;
         }
         if (out_ndist) HIP_TRY(hipMemcpyAsync(out_ndist + lo, m->dNd[(size_t)g].p, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, m->streams[(size_t)g]));
@@ -313,6 +319,12 @@ int32_t hnsw_multi_search_batch_device(hnsw_multi *m, const float *queries, int6
         if (d_ids) d_ids[g] = (int32_t *)m->dIds[g].p;
         if (d_dist) d_dist[g] = (float *)m->dDist[g].p;
     }
+    return HNSW_OK;
+}
+
+int32_t hnsw_multi_debug_counters(const hnsw_multi *m, int64_t *out4) {
+    if (!m || !out4) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    out4[0] = m->n_allgather; out4[1] = m->n_broadcast; out4[2] = m->n_peer_copies; out4[3] = m->n_repaired_shards;
     return HNSW_OK;
 }
 

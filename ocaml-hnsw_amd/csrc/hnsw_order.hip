@@ -83,30 +83,30 @@ order_bucket_kernel(const uint32_t *sortkey, int32_t n, int32_t *order) {
 
 template <int METRIC, int ROWS>
 hipError_t launch_descent_rows(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq, int32_t to_layer, int32_t *entry, uint32_t *key,
-                               uint32_t *nd, uint32_t *sortkey, int32_t *index, hipStream_t st) {
+                               uint32_t *nd, uint32_t *sortkey, int32_t *index, float *stage, hipStream_t st) {
     const size_t lds = hnsw_dev::wave_lds_words(4) * sizeof(uint32_t);
     dim3 grid((unsigned)nq), block(64);
     constexpr bool B = ROWS == 2;            // byte rows: a quarter of the registers per row in flight
     switch (nch) {
-    case 1: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<1, 8, METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
-    case 2: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<2, (B ? 8 : HNSW_RB_NCH2), METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
-    case 4: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<4, (B ? 4 : 2), METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
-    case 8: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<8, (B ? 2 : 1), METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
-    default: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<16, 1, METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index); break;
+    case 1: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<1, 8, METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, stage); break;
+    case 2: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<2, (B ? 8 : HNSW_RB_NCH2), METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, stage); break;
+    case 4: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<4, (B ? 4 : 2), METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, stage); break;
+    case 8: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<8, (B ? 2 : 1), METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, stage); break;
+    default: hipLaunchKernelGGL((hnsw_dev::hnsw_descent_kernel<16, 1, METRIC, ROWS>), grid, block, lds, st, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, stage); break;
     }
     return hipGetLastError();
 }
 template <int METRIC>
 hipError_t launch_descent(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq, int32_t to_layer, int32_t *entry, uint32_t *key,
-                          uint32_t *nd, uint32_t *sortkey, int32_t *index, hipStream_t st) {
-    return iv.X8 ? launch_descent_rows<METRIC, 2>(nch, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, st)
-                 : launch_descent_rows<METRIC, -1>(nch, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, st);
+                          uint32_t *nd, uint32_t *sortkey, int32_t *index, float *stage, hipStream_t st) {
+    return iv.X8 ? launch_descent_rows<METRIC, 2>(nch, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, stage, st)
+                 : launch_descent_rows<METRIC, -1>(nch, iv, Q, qs, nq, to_layer, entry, key, nd, sortkey, index, stage, st);
 }
 } // namespace
 
 namespace hnsw_host {
 
-int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, hipStream_t st,
+int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, float *d_stage, hipStream_t st,
                         void **block, const int32_t **qmap, const int32_t **pre_entry, const uint32_t **pre_key,
                         const uint32_t **pre_nd, int32_t *pre_layer) {
     // The pre-pass may stop above layer 1 and leave the rest of the descent to the search kernel: on C2
@@ -142,8 +142,8 @@ int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, i
     int32_t *index = (int32_t *)(base + 5 * slot), *order = (int32_t *)(base + 6 * slot);
     void *temp = base + 7 * slot;
     const int nch = pick_nch(idx->iv.nchunks);
-    e = idx->info.metric == HNSW_METRIC_L2 ? launch_descent<0>(nch, idx->iv, d_queries, q_stride, nq, to_layer, entry, key, nd, sortkey, index, st)
-                                           : launch_descent<1>(nch, idx->iv, d_queries, q_stride, nq, to_layer, entry, key, nd, sortkey, index, st);
+    e = idx->info.metric == HNSW_METRIC_L2 ? launch_descent<0>(nch, idx->iv, d_queries, q_stride, nq, to_layer, entry, key, nd, sortkey, index, d_stage, st)
+                                           : launch_descent<1>(nch, idx->iv, d_queries, q_stride, nq, to_layer, entry, key, nd, sortkey, index, d_stage, st);
     if (e == hipSuccess) {
         if (nq <= 16 * ORDER_THREADS && !env_int("HNSW_ORDER_FULL_SORT", 0)) {
             static_assert(ORDER_BUCKETS == 2 * ORDER_THREADS, "two counters per thread in the scan");

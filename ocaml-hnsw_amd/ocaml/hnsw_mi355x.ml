@@ -105,6 +105,8 @@ let hnsw_multi_search_batch_device =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_multi_search_batch_device"
     (multi @-> ptr float @-> int64_t @-> int64_t @-> ptr search_params @-> ptr (ptr int32_t) @-> ptr (ptr float)
      @-> returning int32_t)
+let hnsw_multi_debug_counters =
+  foreign ~from:lib "hnsw_multi_debug_counters" (multi @-> ptr int64_t @-> returning int32_t)
 let hnsw_multi_copy_result =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_multi_copy_result"
     (multi @-> int32_t @-> ptr int32_t @-> ptr float @-> returning int32_t)
@@ -147,6 +149,9 @@ let ls_num_isolated = field layer_stats "num_isolated" int64_t
 let () = seal layer_stats
 let hnsw_index_layer_stats =
   foreign ~from:lib "hnsw_index_layer_stats" (index @-> int32_t @-> ptr layer_stats @-> returning int32_t)
+let hnsw_index_layer_isolated =
+  foreign ~from:lib "hnsw_index_layer_isolated"
+    (index @-> int32_t @-> ptr int64_t @-> int64_t @-> ptr int64_t @-> returning int32_t)
 let hnsw_abi_version = foreign ~from:lib "hnsw_abi_version" (void @-> returning int32_t)
 let hnsw_device_count = foreign ~from:lib "hnsw_device_count" (ptr int32_t @-> returning int32_t)
 type index_info
@@ -685,6 +690,24 @@ let stats (t : t) ~layer : int * int * int * float * int =
   check (hnsw_index_layer_stats t.handle (Int32.of_int layer) (addr s));
   (Int64.to_int (getf s ls_num_nodes), Int32.to_int (getf s ls_min_degree), Int32.to_int (getf s ls_max_degree),
    getf s ls_mean_degree, Int64.to_int (getf s ls_num_isolated))
+
+(* mima.isolated of one layer (lib/hnsw.ml:357,364-366): the nodes without a neighbour, in the reference's list order
+   (descending: consed during the ascending Map.fold) *)
+let isolated (t : t) ~layer : int list =
+  let cnt = allocate int64_t 0L in
+  check (hnsw_index_layer_isolated t.handle (Int32.of_int layer) (from_voidp int64_t null) 0L cnt);
+  let c = Int64.to_int !@cnt in
+  if c = 0 then [] else begin
+    let ids = CArray.make int64_t c in
+    check (hnsw_index_layer_isolated t.handle (Int32.of_int layer) (CArray.start ids) (Int64.of_int c) cnt);
+    List.map Int64.to_int (CArray.to_list ids)
+  end
+
+(* Hgraph.Stats.compute (lib/hnsw.ml:370-375) as the reference's record: per layer (size, {min; max; mean; isolated}) *)
+let stats_compute (t : t) ~max_layer : (int * (int * int * float * int list)) list =
+  List.init (max_layer + 1) (fun layer ->
+      let (size, mi, ma, mean, _) = stats t ~layer in
+      (size, (mi, ma, mean, isolated t ~layer)))
 
 (* Page-lock a query or result matrix a benchmark loop passes again and again (benchmark/benchmark.ml:86-98): the
    copies of knn_batch* then run at PCIe speed.  The CALLER keeps the Bigarray reachable until [unpin] -- the library

@@ -1,0 +1,123 @@
+"""Static hazard check of the hand-scheduled gfx950 code (tools/check_asm_hazards.py).
+
+csrc/hnsw_hop_asm.hip.h (the layer-0 loops and the descent of the headline shape) and insert_island2 are inline assembly:
+nothing inserts the wait states gfx950 needs between, say, a v_dot4 and a different vector instruction that reads its
+result.  The checker re-derives them from the disassembly of the built code objects.  Here: its rules on hand-made
+listings, a clean pass over the objects of the in-tree build (hipcc cross-compiles without a GPU), and the mutation test --
+every single s_nop of the hand-scheduled kernels deleted in turn from a copy of the listing: the checker must notice."""
+import importlib.util
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("check_asm_hazards", os.path.join(ROOT, "tools", "check_asm_hazards.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _listing(lines):
+    """lines of assembly -> text in llvm-objdump's format (4-byte addresses are enough for the parser)"""
+    out = ["0000000000001000 <k>:"]
+    for i, ln in enumerate(lines):
+        out.append("\t%-60s// %012X: 00000000" % (ln, 0x1000 + 4 * i))
+    return "\n".join(out) + "\n"
+
+
+def _violations(hz, lines):
+    funcs = hz.parse(_listing(lines))
+    return hz.check(funcs["k"])
+
+
+def test_rules_on_hand_made_listings():
+    hz = _tool()
+    dot = "v_dot4_u32_u8 v1, v2, v3, 0"
+    # R1: a different VALU reads a dot result: 3 wait states
+    assert _violations(hz, [dot, "s_nop 1", "v_add_u32_e32 v4, v1, v5", "s_endpgm"])
+    assert not _violations(hz, [dot, "s_nop 2", "v_add_u32_e32 v4, v1, v5", "s_endpgm"])
+    assert not _violations(hz, [dot, "s_mov_b32 s0, 0", "s_mov_b32 s1, 0", "v_mov_b32_e32 v9, 0", "v_add_u32_e32 v4, v1, v5", "s_endpgm"])
+    # ... the same dot opcode taking it as its accumulator needs none, as a factor it needs 3
+    assert not _violations(hz, [dot, "v_dot4_u32_u8 v1, v6, v7, v1", "s_endpgm"])
+    assert _violations(hz, [dot, "v_dot4_u32_u8 v8, v1, v7, 0", "s_endpgm"])
+    # R2: overwritten by another VALU
+    assert _violations(hz, [dot, "s_nop 1", "v_mov_b32_e32 v1, 0", "s_endpgm"])
+    # R3 / R4: VALU-written SGPR or VCC read by VALU (2), used as lane select (4)
+    assert _violations(hz, ["v_cmp_lt_u32_e32 vcc, v1, v2", "s_nop 0", "v_cndmask_b32_e32 v3, v4, v5, vcc", "s_endpgm"])
+    assert not _violations(hz, ["v_cmp_lt_u32_e32 vcc, v1, v2", "s_nop 1", "v_cndmask_b32_e32 v3, v4, v5, vcc", "s_endpgm"])
+    assert _violations(hz, ["v_readlane_b32 s4, v1, 3", "s_nop 2", "v_writelane_b32 v2, s5, s4", "s_endpgm"])
+    assert not _violations(hz, ["v_readlane_b32 s4, v1, 3", "s_nop 3", "v_writelane_b32 v2, s5, s4", "s_endpgm"])
+    assert not _violations(hz, ["s_mov_b32 m0, s4", "v_writelane_b32 v2, s5, m0", "s_endpgm"])          # SALU write of m0: interlocked
+    # R5: DPP source written by VALU: 2
+    assert _violations(hz, ["v_add_u32_e32 v1, v2, v3", "s_nop 0", "v_mov_b32_dpp v4, v1 wave_shr:1 row_mask:0xf bank_mask:0xf", "s_endpgm"])
+    assert not _violations(hz, ["v_add_u32_e32 v1, v2, v3", "s_nop 1", "v_mov_b32_dpp v4, v1 wave_shr:1 row_mask:0xf bank_mask:0xf", "s_endpgm"])
+    # R8: v_readlane of a VGPR just written: 1
+    assert _violations(hz, ["v_add_u32_e32 v1, v2, v3", "v_readlane_b32 s0, v1, 5", "s_endpgm"])
+    # R9: VALU-written SGPR as the scalar base of a vector-memory instruction: 5
+    assert _violations(hz, ["v_readlane_b32 s4, v1, 3", "v_readlane_b32 s5, v1, 4", "s_nop 2", "global_load_dword v2, v3, s[4:5]", "s_endpgm"])
+    assert not _violations(hz, ["v_readlane_b32 s4, v1, 3", "v_readlane_b32 s5, v1, 4", "s_nop 4", "global_load_dword v2, v3, s[4:5]", "s_endpgm"])
+    # across a branch: the hazard is followed along the taken edge and along the fall-through
+    loop = [dot,                                              # 0x1000
+            "s_cbranch_scc1 3 <k+0x14>",                      # 0x1004 -> 0x1014
+            "s_nop 3",                                        # 0x1008
+            "s_branch 1 <k+0x14>",                            # 0x100c
+            "s_nop 0",                                        # 0x1010 (never executed)
+            "v_add_u32_e32 v4, v1, v5",                       # 0x1014: reached from 0x1004 with one state (the branch)
+            "s_endpgm"]
+    assert _violations(hz, loop)
+    loop[1] = "s_nop 0"
+    assert not _violations(hz, loop)
+
+
+@pytest.fixture(scope="module")
+def objects():
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") and not shutil.which("llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    hz = _tool()
+    paths = hz.default_objects()
+    if not all(os.path.exists(p) for p in paths):            # a tree that was never built here: build it (hipcc cross-compiles)
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g._load_build_module().build(force=True)
+    return hz, {os.path.basename(p): hz.parse(hz.disassemble(p)) for p in paths}
+
+
+def test_built_code_objects_have_no_unpadded_hazard(objects):
+    hz, objs = objects
+    for name, funcs in objs.items():
+        bad = [(k, v) for k, body in funcs.items() for v in hz.check(body)]
+        assert not bad, "%s: %d hazards, first: %s\n%s" % (name, len(bad), bad[0][0], bad[0][1])
+
+
+def _asm_kernels(objs):
+    """the kernels that contain hand-scheduled code: the three layer-0 loops (byte rows, W in 1 / 2 / 4 key registers), the
+    float32-row kernel with insert_island2, and the descent kernel with the hand-scheduled descent"""
+    want = [("hnsw_search_variants_0_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi0ELi2E" % s) for s in (1, 2, 4)]
+    want += [("hnsw_search_variants_0_0_1.o", "hnsw_search_kernelILi2ELi4ELi2ELi0ELi0ELi1E"), ("hnsw_order.hip.o", "hnsw_descent_kernelILi2ELi8ELi0ELi2E")]
+    out = []
+    for obj, frag in want:
+        hits = [(k, b) for k, b in objs[obj].items() if frag in k]
+        assert len(hits) == 1, (obj, frag, [k for k, _ in hits])
+        out.append((obj, hits[0][0], hits[0][1]))
+    return out
+
+
+def test_a_deleted_wait_state_is_noticed(objects):
+    """the deliberately broken copy: each s_nop of the hand-scheduled kernels deleted in turn from the parsed listing"""
+    hz, objs = objects
+    for obj, name, body in _asm_kernels(objs):
+        nops = [i for i in body if i.mn == "s_nop"]
+        caught = 0
+        for i in nops:
+            i.dead = True
+            if hz.check(body, report_limit=1):
+                caught += 1
+            i.dead = False
+        print("%s %s: %d instructions, %d of %d single s_nop deletions caught" % (obj, name[:60], len(body), caught, len(nops)))
+        assert nops and caught >= 0.7 * len(nops), (name, caught, len(nops))
+        assert not hz.check(body)                             # and the untouched listing is clean again

@@ -151,6 +151,58 @@ def test_save_load_stats_roundtrip(H, oracle, built, tmp_path):
         H.Hgraph.load(tmp_path / "bad.hnsw")
 
 
+def _same_stats(got, want):
+    assert got["num_nodes"] == want["num_nodes"]
+    assert got["layer_sizes"] == want["layer_sizes"]
+    assert sorted(got["layer_connectivity"]) == sorted(want["layer_connectivity"])
+    for layer, w in want["layer_connectivity"].items():
+        g = got["layer_connectivity"][layer]
+        assert (g["min"], g["max"]) == (w["min"], w["max"]), layer
+        assert g["mean"] == w["mean"] or (np.isnan(g["mean"]) and np.isnan(w["mean"])), layer    # same sum / count in double
+        assert g["isolated"] == w["isolated"], layer                                             # ids, the reference's list order
+
+
+def test_stats_equal_the_reference_fold_on_every_layer(H, oracle, built):
+    """Hgraph.Stats.compute (lib/hnsw.ml:353-375): layer sizes, min / max / mean and the isolated node LIST of every layer,
+    device (hnsw_index_layer_stats + hnsw_index_layer_isolated) against the oracle's restatement of the fold."""
+    # (1) a hand-made three-layer graph with isolated nodes on every layer, 1-based ids as Hnsw.Ba has them
+    n = 12
+    X = _uniform(n, 8, 3)
+    adj0 = {1: [2, 3], 2: [1], 3: [1], 4: [], 5: [6], 6: [5], 7: [], 8: [9], 9: [8], 10: [], 11: [12], 12: [11]}
+    deg0 = np.array([len(adj0[i + 1]) for i in range(n)], np.int32)
+    nbr0 = np.full((n, 4), 0, np.int32)                   # padding below id_base
+    for i in range(n):
+        nbr0[i, :deg0[i]] = adj0[i + 1]
+    up1 = (np.array([2, 5, 7, 9, 12], np.int64), np.array([1, 0, 0, 1, 0], np.int32),
+           np.array([[9, 0], [0, 0], [0, 0], [2, 0], [0, 0]], np.int32))
+    up2 = (np.array([7, 9], np.int64), np.array([0, 0], np.int32), np.zeros((2, 2), np.int32))
+    hg = H.Hgraph(X, deg0, nbr0, [up1, up2], entry_point=9, id_base=1, max_degree=2).to_device()
+    got = hg.stats()
+    assert got["layer_connectivity"][0] == {"min": 0, "max": 2, "mean": 10 / 12, "isolated": [10, 7, 4]}
+    assert got["layer_connectivity"][1] == {"min": 0, "max": 1, "mean": 2 / 5, "isolated": [12, 7, 5]}
+    assert got["layer_connectivity"][2] == {"min": 0, "max": 0, "mean": 0.0, "isolated": [9, 7]}
+    assert got["layer_sizes"] == {0: 12, 1: 5, 2: 2}
+    g = oracle.Graph(n, 8, deg0, np.where(nbr0 > 0, nbr0 - 1, -1),
+                     [(u[0] - 1, u[1], np.where(u[2] > 0, u[2] - 1, -1)) for u in (up1, up2)])
+    want = oracle.Stats.compute(g)
+    for lc in want["layer_connectivity"].values():
+        lc["isolated"] = [i + 1 for i in lc["isolated"]]  # the oracle is 0-based
+    _same_stats(got, want)
+    hg.release()
+    # (2) a graph built on the device (uniform data: a few nodes lose every link when their neighbours shrink them away)
+    X, hb = built
+    hb.export()
+    _same_stats(hb.stats(), oracle.Stats.compute(oracle.Graph(hb.n, hb.entry_point, hb.deg0, hb.nbr0, hb.upper)))
+    # (3) tie-heavy integer data, M = 4: many isolated nodes on layer 0
+    Xt = np.random.default_rng(4).integers(0, 3, size=(3000, 6)).astype(np.float32)
+    ht = H.Ohnsw.build_batch_bigarray(Xt, 4, 20, seed=2)
+    ht.export()
+    want = oracle.Stats.compute(oracle.Graph(ht.n, ht.entry_point, ht.deg0, ht.nbr0, ht.upper))
+    _same_stats(ht.stats(), want)
+    print("isolated nodes per layer (tie-heavy set):", [len(v["isolated"]) for v in want["layer_connectivity"].values()])
+    ht.release()
+
+
 def test_select_neighbours_functor_variant(H, oracle):
     """Hnsw_algo.SelectNeighbours.select_neighbours (lib/hnsw_algo.ml:572-609): the keep-all shortcut
     and ~do_not_isolate:true, against the oracle's restatement (canonical order)."""

@@ -62,7 +62,7 @@ def test_c2_whole_batch_properties(oracle, c2):
         np.testing.assert_array_equal(ids[short], oi)
         assert np.isnan(dist[short][ids[short] < 0]).all()             # lib/ohnsw.ml:880-881 fill
     iso = c2["hg"].stats()["layer_connectivity"][0]["isolated"]
-    assert iso < 1e-3 * N
+    assert len(iso) < 1e-3 * N
     full = np.setdiff1d(np.arange(NQ), short)
     assert (np.diff(dist[full], axis=1) >= 0).all()                    # ascending (lib/ohnsw.ml:886-893)
     assert all(len(set(r)) == K for r in ids[full[:2000]].tolist())    # no node twice

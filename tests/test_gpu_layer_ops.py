@@ -279,7 +279,26 @@ def test_multi_device_call_reuses_buffers_checks_parameters_and_repairs_flagged_
         gi, gd = two.copy_result(r)                                        # repaired on EVERY device
         np.testing.assert_array_equal(gi, want[0])
         np.testing.assert_array_equal(gd.view(np.uint32), want[1].view(np.uint32))
+    c2 = two.debug_counters()
+    assert c2["repaired_shards"] >= 2 and c2["peer_copies"] > 0 and c2["allgather"] == 0 and c2["broadcast"] == 0, c2
     two.release()
+    # the same batch through RCCL at communicator size 1 (devices [0]: every listed device distinct): the all-gather of the
+    # whole table, then -- the shard is flagged -- the exactness fallback and the re-send of the repaired shard, which is
+    # the ncclBroadcast branch of the exchange (the one unequal shards take on a multi-GPU node)
+    one = H.MultiHgraph(hgo, [0])
+    for nq_ in (5, 3):                                                     # 3: no flagged query left out, an odd count
+        Qn = Q[:nq_]
+        wn = oracle.Ohnsw.knn_batch_bigarray(go, spo, Qn, k=10, ef=128, ties=oracle.TIES_CANONICAL)
+        before = one.debug_counters()
+        one.search_device(Qn, 128, 10)
+        after = one.debug_counters()
+        gi, gd = one.copy_result(0)
+        np.testing.assert_array_equal(gi, wn[0])
+        np.testing.assert_array_equal(gd.view(np.uint32), wn[1].view(np.uint32))
+        assert after["allgather"] == before["allgather"] + 2, (before, after)            # ids + distances
+        assert after["broadcast"] == before["broadcast"] + 2, (before, after)            # the repaired shard, ids + distances
+        assert after["repaired_shards"] == before["repaired_shards"] + 1 and after["peer_copies"] == 0
+    one.release()
 
 
 def test_multi_device_errors(H, oracle, built):

@@ -548,3 +548,20 @@ def test_registered_host_arrays_and_caller_owned_results(H, oracle):
         H.unpin(ids)                             # not registered any more
     with pytest.raises(H.InvalidArgument):
         H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, out=(ids[:, :5], dist))
+    # a strided view or a Fortran-ordered matrix has the right shape and dtype but is not nq * k contiguous words
+    big_i, big_d = np.zeros((Q.shape[0], 2 * k), np.int32), np.zeros((Q.shape[0], 2 * k), np.float32)
+    for bad in ((big_i[:, :k], big_d[:, :k]), (np.asfortranarray(ids), dist)):
+        r = H.submit(hg, Q, ef, k)
+        with pytest.raises(H.InvalidArgument, match="contiguous"):
+            r.wait(out=bad)
+        r.wait(out=(ids, dist))                  # the request is still there to be waited for
+        np.testing.assert_array_equal(ids, want_i)
+    assert not big_i.any() and not big_d.any()
+    # an existing registration that covers only the head of the array does not make the whole array registered
+    whole = np.zeros(1 << 22, np.uint8)
+    H.pin(whole[:1 << 20])
+    try:
+        with pytest.raises(H.InvalidArgument, match="registered already"):
+            H.pin(whole)
+    finally:
+        H.unpin(whole[:1 << 20])

@@ -167,3 +167,23 @@ def test_functor_tie_with_max_w_is_inserted_but_w_keeps_the_incumbent(oracle):
         assert res == [(3, 0.5)]
     oi, od = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=1, ef=1, ties=oracle.TIES_CANONICAL)
     assert oi[0, 0] == 1 and od[0, 0] == 2.0
+
+
+def test_stats_restatement_follows_the_reference_fold(oracle):
+    """Hgraph.Stats.min_max_connectivity (lib/hnsw.ml:361-368), worked by hand: the fold starts from (1000000, -1, 0, 0., []),
+    takes min / max of Neighbours.length, sums as floats, and conses a node without neighbours onto `isolated` as the
+    ascending Map.fold meets it -- so the list is descending."""
+    g = oracle.Graph.from_lists([[1], [0, 2], [1], [], []], 0)
+    st = oracle.Stats.compute(g)
+    assert st == {"num_nodes": 5, "layer_sizes": {0: 5},
+                  "layer_connectivity": {0: {"min": 0, "max": 2, "mean": 4 / 5, "isolated": [4, 3]}}}
+    ring = oracle.Stats.compute(oracle.Graph.ring(5))      # Graph.Test.create_loop (lib/ohnsw.ml:205-212)
+    assert ring["layer_connectivity"][0] == {"min": 2, "max": 2, "mean": 2.0, "isolated": []}
+    # upper layers: the keys of layer l are the nodes present there; a present node with no neighbour is isolated
+    deg0 = np.array([1, 1, 0], np.int32)
+    nbr0 = np.array([[1], [0], [-1]], np.int32)
+    up1 = (np.array([0, 2], np.int64), np.array([0, 0], np.int32), np.full((2, 1), -1, np.int32))
+    st = oracle.Stats.compute(oracle.Graph(3, 0, deg0, nbr0, [up1]))
+    assert st["layer_sizes"] == {0: 3, 1: 2}
+    assert st["layer_connectivity"][0] == {"min": 0, "max": 1, "mean": 2 / 3, "isolated": [2]}
+    assert st["layer_connectivity"][1] == {"min": 0, "max": 0, "mean": 0.0, "isolated": [2, 0]}

@@ -31,10 +31,14 @@ def one(lib):
     sets = [("c2", 4096, 25.0)] + ([("hard", 256, 40.0)] if os.environ.get("AB_HARD") else [])
     stream = torch.cuda.current_stream()
     for name, centres, sigma in sets:
-        cache = "/tmp/ab_%s_%d.idx" % (name, n)
+        # the graph depends on the builder that made it: key the cached file on everything that decides it, the FIRST
+        # library's content included (variants meant to be exact search the same file and must print the same digest)
+        key = hashlib.md5(open(os.environ.get("AB_BUILDER_LIB", lib), "rb").read()).hexdigest()[:10]
+        cache = "/tmp/ab_%s_n%d_M%d_efc%d_seed1_%s.idx" % (name, n, M, efc, key)
         Xd = bench.make_sift_like(n, d, 1, dev, centres, sigma)
         if os.path.exists(cache):
             hg = H.Hgraph.load(cache)
+            print("  [%s] index loaded from %s" % (name, cache), flush=True)
         else:
             t = time.time()
             hg = H.Ohnsw.build_batch_bigarray(Xd.cpu().numpy(), M, efc, seed=1)
@@ -79,6 +83,7 @@ def main():
     if sys.argv[1] == "--one":
         one(sys.argv[2])
         return
+    os.environ.setdefault("AB_BUILDER_LIB", os.path.abspath(sys.argv[1]))     # every variant searches the first library's graph
     for lib in sys.argv[1:]:
         print("== %s" % lib, flush=True)
         rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--one", lib])

@@ -4,9 +4,7 @@ import numpy as np, torch
 import ocaml_hnsw_amd as H, bench
 dev = torch.device("cuda", 0)
 n, d, ef, k = 1000000, 128, 128, 10
-cache = "/tmp/ab_c2_%d.idx" % n
-hg = H.Hgraph.load(cache) if os.path.exists(cache) else H.Ohnsw.build_batch_bigarray(bench.make_sift_like(n, d, 1, dev).cpu().numpy(), 16, 200, seed=1)
-if not os.path.exists(cache): hg.save(cache)
+hg = H.Ohnsw.build_batch_bigarray(bench.make_sift_like(n, d, 1, dev).cpu().numpy(), 16, 200, seed=1)   # built by the library under test (1 s): no stale cache
 names = ["pop + adjacency row", "visited filter + speculative fetch + compaction", "round: ids, row loads, dot products, reduction, accept", "insertions"]
 for nq in (64, 10000):
     hg.set_option("order_queries", 0)
