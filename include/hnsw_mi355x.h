@@ -173,7 +173,13 @@ int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info);
  *                   where one hop finds all its candidates' tails in a few contiguous lines; the knn searches read
  *                   those on layer 0 (same lanes, operands and order of arithmetic: bit-identical results).
  *                   1 = use the copy where it exists (default), 0 = read the plain rows.  (Environment
- *                   HNSW_SPLIT_ROWS=0 at creation: do not build it.) */
+ *                   HNSW_SPLIT_ROWS=0 at creation: do not build it.)
+ * and one that buys exactness for the device-pointer entry point:
+ *   "device_fallback_slab_bytes"  the library allocates a slab of this many bytes (0 frees it); hnsw_search_batch_device
+ *                   then lists the queries its launch flagged (d_status bit 0: tie list outgrew its LDS slots) ON THE
+ *                   DEVICE and searches them again with the slab on the caller's stream -- no host round trip, two small
+ *                   extra launches per call.  One flagged query needs 4 n bytes (a slot per node), so a slab repairs
+ *                   bytes / (4 n) queries per call; those it could not take keep their flag.  Needs d_status. */
 int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value);
 /* Bytes of one vector as the knn searches read it: d for byte rows, 4 * d for float32 rows. */
 int32_t hnsw_index_row_bytes(const hnsw_index *idx, int64_t *row_bytes);
@@ -201,8 +207,8 @@ int32_t hnsw_host_unregister(void *p);
 
 /* Same, device buffers, asynchronous on `stream` (a hipStream_t; NULL = default stream).
  * d_status (optional, [nq] uint32): bit 0 set if the query's list of tied, still expandable
- * candidates outgrew its 64 LDS slots.  THIS ENTRY POINT HAS NO EXACTNESS FALLBACK: entries that did not
- * fit were not expanded, so a flagged query's result may MISS neighbours the reference would return
+ * candidates outgrew its 64 LDS slots.  WITHOUT THE OPTION "device_fallback_slab_bytes" THIS ENTRY POINT HAS NO EXACTNESS
+ * FALLBACK: entries that did not fit were not expanded, so a flagged query's result may MISS neighbours the reference would return
  * (tests/test_gpu_parity.py::test_tie_overflow_beyond_lds_stack builds such a case), not merely order
  * ties differently.  A caller that needs the reference's result passes d_status and re-runs the flagged
  * queries through hnsw_search_batch (host buffers; it searches them again with a global slab), as

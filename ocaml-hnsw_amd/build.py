@@ -37,6 +37,8 @@ def up_to_date():
 
 def build(force=False, verbose=False, resource_log=None):
     if not force and up_to_date() and not os.environ.get("HNSW_LIB_OUT"):
+        if verbose:
+            print("build_mode: reused %s (newer than every source; --force recompiles)" % LIB, flush=True)
         return LIB
     # -fno-slp-vectorize: the SLP vectorizer pairs the fp32 chains of two row batches into v_pk_fma_f32,
     # which costs extra register moves and is no faster than two v_fma_f32 on this SIMD
@@ -59,6 +61,7 @@ def build(force=False, verbose=False, resource_log=None):
     jobs = max(1, int(os.environ.get("HNSW_BUILD_JOBS", os.cpu_count() or 4)))
     pending = list(units)
     running, objs, logs = [], [], []
+    n_compiled = [0]
     headers = [os.path.join(CSRC, h) for h in DEPS if isinstance(h, str) and h.endswith(".h") and not os.path.isabs(h)]
     headers += [h for h in DEPS if os.path.isabs(h)]
     newest_header = max(os.path.getmtime(h) for h in headers)
@@ -80,6 +83,7 @@ def build(force=False, verbose=False, resource_log=None):
                 continue
             if os.path.exists(obj + ".cmd"):
                 os.remove(obj + ".cmd")
+            n_compiled[0] += 1
             if verbose:
                 print(" ".join(cmd), flush=True)
             log = open(resource_log + "." + name, "w") if resource_log else None
@@ -99,6 +103,8 @@ def build(force=False, verbose=False, resource_log=None):
         with open(obj + ".cmd", "w") as f:
             f.write(" ".join(cmd))
         objs.append(obj)
+    if verbose:
+        print("build_mode: compiled %d of %d translation units for gfx950 (the others were up to date), linking" % (n_compiled[0], len(units)), flush=True)
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_out]
     if verbose:
         print(" ".join(link), flush=True)

@@ -200,6 +200,20 @@ int check_params(const hnsw_index *idx, const hnsw_search_params *p) {
 
 } // namespace
 
+// The flagged queries of a launch (status bit 0), listed on the device: map[0 .. cap) = their indices, -1 beyond the count
+// (the re-run kernel's blocks with a -1 entry leave at once); map[cap] = how many there were.  One workgroup.
+__global__ void __launch_bounds__(1024)
+flagged_list_kernel(const uint32_t *status, int64_t nq, int32_t *map, int32_t cap) {
+    __shared__ int32_t count;
+    if (threadIdx.x == 0) count = 0;
+    for (int i = threadIdx.x; i < cap; i += blockDim.x) map[i] = -1;
+    __syncthreads();
+    for (int64_t q = threadIdx.x; q < nq; q += blockDim.x)
+        if (status[q] & 1u) { const int at = atomicAdd(&count, 1); if (at < cap) map[at] = (int32_t)q; }
+    __syncthreads();
+    if (threadIdx.x == 0) map[cap] = count;
+}
+
 // ---- ABI ---------------------------------------------------------------------------------------
 extern "C" {
 
@@ -329,6 +343,7 @@ int32_t hnsw_index_destroy(hnsw_index *idx) {
     if (!idx) return HNSW_OK;
     if (idx->device >= 0) (void)hipSetDevice(idx->device);
     for (void *p : {idx->dX, idx->dX8, idx->dXm, idx->dTail0, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl, idx->dRef}) if (p) (void)hipFree(p);
+    idx->dFbSlab.release(); idx->dFbMap.release();
     idx->sQ.release(); idx->sIds.release(); idx->sDist.release(); idx->sNd.release(); idx->sNh.release(); idx->sSt.release(); idx->sFlag.release();
     (void)hipDeviceSynchronize();                      // requests never waited for
     for (hnsw_request *r : idx->all_requests) {
@@ -369,6 +384,20 @@ int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) 
         return HNSW_OK;
     }
     if (!strcmp(name, "time_kernels")) { idx->time_kernels = value != 0; return HNSW_OK; }
+    if (!strcmp(name, "device_fallback_slab_bytes")) {
+        // room for the tie lists of value / (4 n) flagged queries per call (a flagged query may need a slot per node)
+        HIP_TRY(hipSetDevice(idx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        idx->dFbSlab.release(); idx->dFbMap.release(); idx->fb_queries = 0;
+        if (value <= 0) return HNSW_OK;
+        const int64_t per_query = std::max<int64_t>(idx->iv.n, 1) * 4;
+        const int64_t q = std::min<int64_t>(value / per_query, 65536);
+        if (q < 1) return fail(HNSW_ERR_BAD_ARG, "device_fallback_slab_bytes=%lld holds no query: one needs 4 n = %lld bytes", (long long)value, (long long)per_query);
+        int rc;
+        if ((rc = idx->dFbSlab.ensure((size_t)(q * per_query))) || (rc = idx->dFbMap.ensure((size_t)(q + 1) * 4))) { idx->dFbSlab.release(); idx->dFbMap.release(); return rc; }
+        idx->fb_queries = q;
+        return HNSW_OK;
+    }
     if (!strcmp(name, "order_queries")) { idx->order_mode = value < 0 ? -1 : (value ? 1 : 0); return HNSW_OK; }
     return fail(HNSW_ERR_BAD_ARG, "unknown option %s", name);
 }
@@ -460,6 +489,17 @@ extern "C++" int hnsw_host::search_batch_device_flag(hnsw_index *idx, const floa
     }
     if (ev) HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
     rc = launch_search_args(idx, a, (hipStream_t)stream);
+    if (!rc && idx->fb_queries > 0 && d_status && !d_any_flag) {
+        // opt-in exact mode of the device-pointer entry point (option "device_fallback_slab_bytes"): the queries the launch
+        // flagged are listed on the device and searched again with the slab, on the caller's stream, no host round trip.
+        // The re-run rewrites their results, counters and status words (bit 0 clear: a slab slot per node cannot overflow);
+        // with more flagged queries than the slab holds, the ones left over keep their flag.  Two small launches per call.
+        const int32_t cap = (int32_t)idx->fb_queries;
+        hipLaunchKernelGGL(flagged_list_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint32_t *)d_status, nq, (int32_t *)idx->dFbMap.p, cap);
+        if (hipGetLastError() != hipSuccess) return fail(HNSW_ERR_HIP, "flagged-query listing failed");
+        rc = search_rerun_device(idx, a.Q, nq, q_stride, params, d_ids, d_dist, d_ndist, d_nhops, d_status, (const int32_t *)idx->dFbMap.p,
+                                 cap, (uint32_t *)idx->dFbSlab.p, (int32_t)std::min<int64_t>(idx->iv.n, 0x7FFFFFFF), (hipStream_t)stream);
+    }
     if (ev && !rc) {
         HIP_TRY(hipEventRecord(ev[2], (hipStream_t)stream));
         idx->tev_used += 3;                 // an early return above leaves the triple unclaimed: nothing half-recorded is ever read

@@ -85,6 +85,10 @@ struct hnsw_index {
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt, sFlag; // scratch for the host-buffer entry points (sFlag: the launch's "any query flagged" word)
     uint32_t *hFlag = nullptr, *hFlagDev = nullptr;          // the same word in pinned host memory (zero-copy calls) and its device address
+    // option "device_fallback_slab_bytes": a slab of the caller's chosen size for the exactness fallback of
+    // hnsw_search_batch_device, run on the caller's stream without a host round trip (dFbMap: the flagged queries' list)
+    hnsw_host::DevBuf dFbSlab, dFbMap;
+    int64_t fb_queries = 0;                                  // how many flagged queries one launch can repair (slab bytes / (4 n))
     hipStream_t hs[4] = {nullptr, nullptr, nullptr, nullptr}; // streams of the chunked host-buffer search and of requests (lazy)
     std::vector<hnsw_request *> free_requests;               // finished requests keep their buffers for the next submit
     std::vector<hnsw_request *> all_requests;                // every request ever created (released with the index)

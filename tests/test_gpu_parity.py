@@ -353,6 +353,28 @@ def test_tie_overflow_beyond_lds_stack(H, oracle):
     H.search_batch_device(hg, Qd.data_ptr(), 3, 1, 128, 10, ids.data_ptr(), dd.data_ptr(), 0, 0, st.data_ptr(), 0)
     torch.cuda.synchronize()
     assert ((st.cpu().numpy() & 1) == 1).all()     # flagged: more than 64 tied evicted entries
+    assert not np.array_equal(ids.cpu().numpy(), want[0])      # ... and incomplete: Z is missing
+    # opt-in exact mode of the device entry point: the flagged queries are listed and searched again ON THE DEVICE, on the
+    # caller's stream (option device_fallback_slab_bytes; a flagged query needs 4 n bytes of slab)
+    with pytest.raises(H.InvalidArgument, match="holds no query"):
+        hg.set_option("device_fallback_slab_bytes", 4 * n - 1)
+    nd_t = torch.zeros(3, dtype=torch.int32, device=dev)
+    nh_t = torch.zeros(3, dtype=torch.int32, device=dev)
+    for room, repaired in ((4 * n * 8, 3), (4 * n * 2, 2)):              # room for all three; for two of them
+        hg.set_option("device_fallback_slab_bytes", room)
+        st.zero_()
+        H.search_batch_device(hg, Qd.data_ptr(), 3, 1, 128, 10, ids.data_ptr(), dd.data_ptr(), nd_t.data_ptr(), nh_t.data_ptr(), st.data_ptr(), 0)
+        torch.cuda.synchronize()
+        ok = (st.cpu().numpy() & 1) == 0
+        assert ok.sum() == repaired                                       # the ones the slab had no room for keep their flag
+        np.testing.assert_array_equal(ids.cpu().numpy()[ok], want[0][ok])
+        np.testing.assert_array_equal(dd.cpu().numpy()[ok].view(np.uint32), want[1][ok].view(np.uint32))
+        np.testing.assert_array_equal(nh_t.cpu().numpy()[ok], want[3][ok])
+    hg.set_option("device_fallback_slab_bytes", 0)                        # freed: flags only again
+    st.zero_()
+    H.search_batch_device(hg, Qd.data_ptr(), 3, 1, 128, 10, ids.data_ptr(), dd.data_ptr(), 0, 0, st.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert ((st.cpu().numpy() & 1) == 1).all()
 
 
 @pytest.mark.parametrize("levels", [3, 8])
