@@ -6,6 +6,8 @@
 // usable device every compute entry point fails with HNSW_ERR_NO_DEVICE.
 #include "hnsw_internal.h"
 
+#include <mutex>
+
 using hnsw_dev::IndexView;
 using hnsw_dev::SearchArgs;
 using namespace hnsw_host;
@@ -13,6 +15,21 @@ using namespace hnsw_host;
 namespace hnsw_host {
 
 thread_local std::string g_last_error;
+
+// Host ranges registered through hnsw_host_register, with the device address the runtime gave them.  The host-buffer
+// entry points access a caller's matrix directly from the device (zero-copy) only when it lies inside one of THESE
+// ranges: what the runtime's pointer queries say about memory somebody else pinned (or pinned once and freed) is not
+// trusted with a kernel's loads and stores.
+struct HostRange { const char *p; size_t bytes; char *dev; };
+std::mutex g_ranges_mu;
+std::vector<HostRange> g_ranges;
+
+void *registered_device_address(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ranges_mu);
+    for (const HostRange &r : g_ranges)
+        if ((const char *)p >= r.p && (const char *)p + bytes <= r.p + r.bytes) return r.dev + ((const char *)p - r.p);
+    return nullptr;
+}
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -561,16 +578,11 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
         HIP_TRY(hipHostMalloc((void **)&idx->hFlag, 64, hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void **)&idx->hFlagDev, idx->hFlag, 0));
     }
-    // device address of a registered host range (both ends checked), or nullptr
+    // device address of a range the caller registered with hnsw_host_register, or nullptr
     auto mapped = [&](const void *p, size_t bytes) -> void * {
         static const int enabled = env_int("HNSW_ZERO_COPY", 1);
         if (!enabled || !p || bytes == 0) return nullptr;
-        hipPointerAttribute_t a0{}, a1{};
-        if (hipPointerGetAttributes(&a0, p) != hipSuccess || hipPointerGetAttributes(&a1, (const char *)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost) return nullptr;
-        void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, const_cast<void *>(p), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        return dp;
+        return registered_device_address(p, bytes);
     };
     const float *zq = (const float *)mapped(queries, qbytes);
     int32_t *zi = (int32_t *)mapped(out_ids, (size_t)nq * k * 4);
@@ -714,11 +726,23 @@ int32_t hnsw_host_register(void *p, int64_t bytes) {
     if (!locked(p) || !locked((const char *)p + bytes - 1))
         return fail(HNSW_ERR_BAD_ARG, "hnsw_host_register: part of the %lld-byte array is registered already, its end is not "
                     "(unregister the shorter range first)", (long long)bytes);
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }   // no mapping: copies only
+    if (dev) {
+        std::lock_guard<std::mutex> lk(g_ranges_mu);
+        bool known = false;
+        for (HostRange &r : g_ranges) if (r.p == (const char *)p) { r.bytes = std::max(r.bytes, (size_t)bytes); r.dev = (char *)dev; known = true; }
+        if (!known) g_ranges.push_back({(const char *)p, (size_t)bytes, (char *)dev});
+    }
     return HNSW_OK;
 }
 
 int32_t hnsw_host_unregister(void *p) {
     if (!p) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_unregister: null buffer");
+    {
+        std::lock_guard<std::mutex> lk(g_ranges_mu);
+        for (size_t i = 0; i < g_ranges.size(); ++i) if (g_ranges[i].p == (const char *)p) { g_ranges.erase(g_ranges.begin() + (long)i); break; }
+    }
     hipError_t e = hipHostUnregister(p);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e)); }
     return HNSW_OK;
