@@ -1348,165 +1348,6 @@ hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_
     }
 }
 
-// ---- the same descent with FOUR queries per wavefront (byte rows of 65..128 dimensions, L2, upper rows of <= 16) ----
-// The ordering pre-pass of a 10 k batch is 10 000 one-wave descents on a chip that holds 8192 waves: two passes (8192 +
-// 1808) of ~15 hops of three dependent loads each, i.e. pure latency.  An upper-layer hop of an M <= 16 graph evaluates
-// at most 16 neighbours of 128 bytes: exactly what ONE 16-lane DPP row holds (lane j of the row <-> neighbour j; lane l16
-// <-> bytes 4 l16 .. 4 l16 + 3 and 64 + 4 l16 .. of every vector).  So a wave walks four queries at once, one per DPP row:
-// 2500 waves, one pass.  Per hop and row: the node's {row offset, level} (8 bytes), its neighbour row (lane j loads entry
-// j), the 16 ids through LDS to every lane of the row, 16 x 2 dwords of vector in flight per lane, then per neighbour
-// the same arithmetic as hop_round -- the exact integer dot products when the row's query is byte-valued (|x - q|^2 =
-// x.x - 2 x.q + q.q; one transposing reduction leaves neighbour j's sum in lane j), else the float chain on the converted
-// bytes with the kernel's own summation order (chunks l16 and 16 + l16 per lane, then the row_ror tree) -- so keys are
-// those of greedy_descend bit for bit.  Then the row minimum, the FIRST lane that holds it (Ohnsw.search_one_simple scans
-// in list order and moves on strict improvement only, lib/ohnsw.ml:497-507), and a move if it is strictly closer.  A row
-// whose walk has ended on this layer idles until the other three have (their layers run in lockstep).
-__device__ __forceinline__ int32_t transpose_reduce16_all_i32(int32_t (&t)[16], int l16) {
-    constexpr int ROR8 = 0x128, HALF_MIRROR = 0x141, QP_1032 = 0xB1, QP_2301 = 0x4E;
-    const bool b3 = (l16 & 8) != 0, b2 = (l16 & 4) != 0, b1 = (l16 & 2) != 0, b0 = (l16 & 1) != 0;
-    int32_t u[8], v[4], w[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) u[j] = (b3 ? t[j + 8] : t[j]) + dpp_i32<ROR8>(b3 ? t[j] : t[j + 8]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (b2 ? u[j + 4] : u[j]) + dpp_i32<HALF_MIRROR>(b2 ? u[j] : u[j + 4]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) w[j] = (b1 ? v[j + 2] : v[j]) + dpp_i32<QP_2301>(b1 ? v[j] : v[j + 2]);
-    return (b0 ? w[1] : w[0]) + dpp_i32<QP_1032>(b0 ? w[0] : w[1]);     // lane l16: the row's sum of t[l16]
-}
-__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {            // minimum over the 16 lanes of a DPP row, in every lane
-    v = dpp_min_u32<0x128>(v); v = dpp_min_u32<0x124>(v); v = dpp_min_u32<0x122>(v); v = dpp_min_u32<0x121>(v);
-    return v;
-}
-
-template <int METRIC>      // L2 only (METRIC = 0); a template so that the header may be included by several translation units
-__global__ void __launch_bounds__(64)
-hnsw_descent4_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq, int32_t to_layer,
-                     int32_t *out_entry, uint32_t *out_key, uint32_t *out_nd,
-                     uint32_t *out_sortkey, int32_t *out_index, float *stage) {
-    __shared__ int32_t ids_lds[64];
-    const int lane = threadIdx.x, g = lane >> 4, l16 = lane & 15;
-    const int64_t q = (int64_t)blockIdx.x * 4 + g;
-    const bool live = q < nq;
-    // the row's query: this lane's two chunks, as floats and (when byte-valued) as packed bytes
-    float4 qf[2];
-    {
-        const float *qp = Q + (live ? q : 0) * q_stride;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e0 = 4 * (i * 16 + l16);
-            qf[i].x = (e0 + 0 < iv.d) ? qp[e0 + 0] : 0.f; qf[i].y = (e0 + 1 < iv.d) ? qp[e0 + 1] : 0.f;
-            qf[i].z = (e0 + 2 < iv.d) ? qp[e0 + 2] : 0.f; qf[i].w = (e0 + 3 < iv.d) ? qp[e0 + 3] : 0.f;
-        }
-        if (stage && live) {
-            float *sp = stage + q * q_stride;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e0 = 4 * (i * 16 + l16);
-                if (e0 + 0 < iv.d) sp[e0 + 0] = qf[i].x;
-                if (e0 + 1 < iv.d) sp[e0 + 1] = qf[i].y;
-                if (e0 + 2 < iv.d) sp[e0 + 2] = qf[i].z;
-                if (e0 + 3 < iv.d) sp[e0 + 3] = qf[i].w;
-            }
-        }
-    }
-    uint32_t qb[2];
-    bool ok = true;
-    uint32_t sq = 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float c[4] = {qf[i].x, qf[i].y, qf[i].z, qf[i].w};
-        uint32_t u = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ok = ok && c[j] >= 0.0f && c[j] <= 255.0f && c[j] == truncf(c[j]); u |= ((uint32_t)c[j] & 0xFFu) << (8 * j); }
-        qb[i] = u;
-        sq = __builtin_amdgcn_udot4(u, u, sq, false);
-    }
-    const uint32_t rowmask = 0xFFFFu;
-    const uint64_t okm = ballot(ok);
-    const bool qint = ((uint32_t)(okm >> (16 * g)) & rowmask) == rowmask;     // every lane of THIS row saw bytes
-    const int32_t q2 = reduce16_i32((int32_t)sq);
-    const char *xl = reinterpret_cast<const char *>(iv.X8) + 4 * l16;
-    const uint32_t st8 = (uint32_t)iv.stride8;
-
-    // keys of up to 16 rows listed in ids_lds[16 g ..] for this DPP row: lane j <- neighbour j (KEY_INF where id < 0)
-    auto evaluate = [&](int32_t mine) -> uint32_t {
-        __syncthreads();
-        ids_lds[lane] = mine;
-        __syncthreads();
-        int32_t id[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) id[j] = ids_lds[16 * g + j];
-        uint32_t va[16], vb[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t *row = reinterpret_cast<const uint32_t *>(xl + (uint64_t)(uint32_t)(id[j] < 0 ? 0 : id[j]) * st8);
-            va[j] = row[0]; vb[j] = row[16];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        uint32_t key;
-        if (qint) {
-            int32_t t[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                uint32_t sxq = __builtin_amdgcn_udot4(va[j], qb[0], 0u, false), sxx = __builtin_amdgcn_udot4(va[j], va[j], 0u, false);
-                sxq = __builtin_amdgcn_udot4(vb[j], qb[1], sxq, false); sxx = __builtin_amdgcn_udot4(vb[j], vb[j], sxx, false);
-                t[j] = (int32_t)sxx - 2 * (int32_t)sxq;
-            }
-            key = dist_to_key<0>((float)(transpose_reduce16_all_i32(t, l16) + q2));
-        } else {
-            key = KEY_INF;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint32_t u = i ? vb[j] : va[j];
-                    const float4 z = make_float4((float)(u & 0xFFu), (float)((u >> 8) & 0xFFu), (float)((u >> 16) & 0xFFu), (float)(u >> 24));
-                    float dx = z.x - qf[i].x; acc = __builtin_fmaf(dx, dx, acc);
-                    float dy = z.y - qf[i].y; acc = __builtin_fmaf(dy, dy, acc);
-                    float dz = z.z - qf[i].z; acc = __builtin_fmaf(dz, dz, acc);
-                    float dw = z.w - qf[i].w; acc = __builtin_fmaf(dw, dw, acc);
-                }
-                const uint32_t kj = dist_to_key<0>(reduce16(acc));
-                key = (l16 == j) ? kj : key;
-            }
-        }
-        return mine >= 0 ? key : KEY_INF;
-    };
-
-    int32_t cur = iv.entry_point;
-    uint32_t n_dist = 1;
-    // the entry point's key: it is "neighbour 0" of a one-entry list
-    uint32_t cur_key = row_min_u32(evaluate(l16 == 0 ? cur : -1));        // lane 0's key to the whole row
-    for (int layer = iv.max_layer; layer >= to_layer; --layer) {
-        bool walking = live;
-        while (ballot(walking) != 0ull) {
-            int32_t nb = -1;
-            if (walking) {
-                const int2 ref = iv.upper_ref[cur];
-                if (l16 < iv.SU && layer <= ref.y) nb = iv.nbrU[((int64_t)ref.x + (layer - 1)) * iv.SU + l16];
-            }
-            const uint64_t vm = ballot(nb >= 0);
-            const int cnt = __builtin_popcount((uint32_t)(vm >> (16 * g)) & rowmask);
-            n_dist += (uint32_t)cnt;
-            const uint32_t key = evaluate(nb);
-            const uint32_t best = row_min_u32(key);
-            const uint64_t at = ballot(key == best);
-            const int j = __builtin_ctz(((uint32_t)(at >> (16 * g)) & rowmask) | 0x10000u);   // first in list order among equals
-            const int32_t bid = ids_lds[16 * g + (j & 15)];
-            const bool move = walking && cnt != 0 && best < cur_key;                         // strict, :502
-            cur = move ? bid : cur;
-            cur_key = move ? best : cur_key;
-            walking = move;
-        }
-    }
-    if (live && l16 == 0) {
-        out_entry[q] = cur; out_key[q] = cur_key; out_nd[q] = n_dist;
-        out_sortkey[q] = ~cur_key;
-        out_index[q] = (int32_t)q;
-    }
-}
-
 // ---- gathered distances (bench_dist/bench_dist.ml counterpart) --------------------------------
 // One 16-lane group per (query, id) pair, UB x 4 pairs of the same query in flight per wave; same
 // arithmetic and summation order as the search kernel.

@@ -142,14 +142,6 @@ int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, i
     int32_t *index = (int32_t *)(base + 5 * slot), *order = (int32_t *)(base + 6 * slot);
     void *temp = base + 7 * slot;
     const int nch = pick_nch(idx->iv.nchunks);
-    // byte rows of 65..128 dimensions, L2, upper rows of at most 16 neighbours: four queries per wave, one per DPP row
-    // (hnsw_descent4_kernel): the whole batch descends in one pass of nq / 4 waves.  HNSW_DESCENT4=0: one query per wave.
-    static const int descent4 = env_int("HNSW_DESCENT4", 1);
-    if (descent4 && idx->iv.X8 && nch == 2 && idx->info.metric == HNSW_METRIC_L2 && idx->iv.SU <= 16 && idx->iv.stride8 == 128) {
-        hipLaunchKernelGGL(hnsw_dev::hnsw_descent4_kernel<0>, dim3((unsigned)((nq + 3) / 4)), dim3(64), 0, st, idx->iv, d_queries, q_stride, nq, to_layer,
-                           entry, key, nd, sortkey, index, d_stage);
-        e = hipGetLastError();
-    } else
     e = idx->info.metric == HNSW_METRIC_L2 ? launch_descent<0>(nch, idx->iv, d_queries, q_stride, nq, to_layer, entry, key, nd, sortkey, index, d_stage, st)
                                            : launch_descent<1>(nch, idx->iv, d_queries, q_stride, nq, to_layer, entry, key, nd, sortkey, index, d_stage, st);
     if (e == hipSuccess) {

@@ -92,39 +92,6 @@ def test_byte_rows_functor_rule_and_ordered_launch(H):
     hg.release()
 
 
-@pytest.mark.parametrize("d,M", [(65, 8), (100, 16), (128, 16), (128, 12)])
-def test_four_queries_per_wave_descent(H, oracle, d, M):
-    """The ordering pre-pass of byte rows with 65..128 dimensions and upper rows of at most 16 neighbours walks FOUR
-    queries per wave, one per DPP row (hnsw_descent4_kernel).  Its entry nodes, keys and evaluation counts must be those of
-    the one-query-per-wave descent inside the search kernel (order_queries = 0) and of the oracle: a batch that is not a
-    multiple of four, byte-valued and other queries mixed inside one wave (integer and float arithmetic side by side),
-    queries that are data points (distance 0), duplicates."""
-    n, nq = 30000, 4999
-    X = _bytes_data(n, d, 300 + d, hi=218)
-    Q = _bytes_data(nq, d, 400 + d, hi=218)
-    Q[1::3] += np.float32(0.5)                  # every third query is not byte-valued: its DPP row takes the float chain
-    Q[7] = -Q[7]
-    Q[8:12] = X[100:104]                        # a whole wave of queries that are data points
-    Q[12] = Q[13]
-    hg = H.Ohnsw.build_batch_bigarray(X, M, 60, seed=5)
-    assert hg.max_layer >= 2
-    res = {}
-    for order in (1, 0):
-        hg.set_option("order_queries", order)
-        res[order] = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=100, counters=True)
-    for x, y in zip(res[1], res[0]):
-        np.testing.assert_array_equal(np.asarray(x).view(np.uint32) if np.asarray(x).dtype == np.float32 else x,
-                                      np.asarray(y).view(np.uint32) if np.asarray(y).dtype == np.float32 else y)
-    hg.export()
-    g = oracle.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, hg.upper)
-    sp = oracle.Space.l2(X, arith=oracle.TREE16)
-    oi, od, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q[:400], k=10, ef=100, ties=oracle.TIES_CANONICAL, counters=True)
-    np.testing.assert_array_equal(res[1][0][:400], oi)
-    np.testing.assert_array_equal(res[1][1][:400].view(np.uint32), od.view(np.uint32))
-    np.testing.assert_array_equal(res[1][3][:400], onh)
-    hg.release()
-
-
 @pytest.mark.parametrize("spoil", ["fraction", "256", "negative", "nan"])
 def test_data_that_is_not_bytes_keeps_float_rows(H, spoil):
     X = _bytes_data(600, 32, 11)
