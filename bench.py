@@ -14,7 +14,8 @@ all-gathered over RCCL (weak scaling: per-GPU work fixed).
 `value` is measured the way the reference's benchmark times knn_batch (benchmark/benchmark.ml:89-96) and SURVEY 8d
 prescribes: host matrices in, host results out, one synchronous call per batch -- hnsw_search_batch, the body of
 Ohnsw.knn_batch_bigarray (H2D of the queries + ordering pre-pass + search kernel + D2H of the results; the caller's
-matrices registered once with hnsw_host_register, as a benchmark loop that reuses its Bigarrays would).  Named beside it:
+matrices in page-locked memory -- hnsw_host_alloc, or registered once with hnsw_host_register -- as a benchmark loop
+that reuses its Bigarrays would have them: the device then reads and writes them directly).  Named beside it:
 `device_resident` (hnsw_search_batch_device: queries already in HBM, results left there), `float32_rows` (the same
 batch through the general-format kernel), `harder_set_at_recall_gate`, `drop_in` (pageable matrices; two requests in
 flight), `secondary` (a harder SIFT-like set), `others` (C3, C5), and for N > 1 `strong` (C4 as BASELINE.json words it:
@@ -335,23 +336,24 @@ def main():
     #      caller's registered matrices.  N > 1 (one process per GPU): the same sequence per rank with the exchange in it
     #      -- H2D of the rank's query shard, search, all-gather of the per-shard results over RCCL (the full table ends
     #      up resident on every GPU), D2H of the rank's own shard, stream synchronisation. ----
+    # the caller's matrices live in page-locked memory (hnsw_host_alloc; hnsw_host_register on an mmap-backed array is the
+    # same to the library): the device reads the queries and writes the results directly, no copies
+    Qh = H.host_empty((nq, d), np.float32)
+    Qh[:] = Qd.cpu().numpy()
     if not multi:
-        Qh = Qd.cpu().numpy()
-        host_i = np.empty((nq, k), np.int32)
-        host_d = np.empty((nq, k), np.float32)
-        for a_ in (Qh, host_i, host_d):
-            H.pin(a_)                                     # hnsw_host_register: the caller's matrices, registered once
+        host_i = H.host_empty((nq, k), np.int32)
+        host_d = H.host_empty((nq, k), np.float32)
     else:
-        Qh_t = Qd.cpu().pin_memory()
         host_res = torch.empty(2 * nres, dtype=torch.int32).pin_memory()
 
     def host_step(ef_, slot=0):
         if not multi:
             H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef_, out=(host_i, host_d))
             return
+        # hnsw_search_batch_h2d: the rank's registered query matrix is read by the device directly (as in hnsw_search_batch),
+        # the shard's results stay in HBM for the exchange
+        H.search_batch_h2d(hg, Qh, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(), 0, 0, st_d.data_ptr(), stream.cuda_stream)
         with torch.cuda.stream(stream):
-            Qd.copy_(Qh_t, non_blocking=True)
-            search(ef_, slot=slot)
             gather(slot).wait()                           # the current stream waits for the collective
             host_res.copy_(res[slot], non_blocking=True)
         stream.synchronize()
@@ -512,9 +514,6 @@ def main():
     #      synchronous call per batch, benchmark/benchmark.ml:89-96), PCIe copies included ----
     drop_in = None
     if world == 1 and rank == 0:
-        if not multi:
-            for a_ in (Qh, host_i, host_d):
-                H.unpin(a_)                    # the headline's matrices are done with
         Qh = Qd.cpu().numpy()
         reps = max(5, min(args.steps, 10))
         hi_, hd_ = H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef)       # warm-up, and the exact result of every query
@@ -539,12 +538,13 @@ def main():
 
         # (a) as the reference's benchmark calls it: fresh pageable matrices (the runtime stages the copies)
         sync_p = timed_calls(lambda: H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef))
-        # (b) the caller registered its query and result matrices once (hnsw_host_register; an OCaml benchmark loop
-        #     passes the same Bigarrays again and again) and the results land in them
-        oi_ = np.empty((nq, k), np.int32)
-        od_ = np.empty((nq, k), np.float32)
-        for a_ in (Qh, oi_, od_):
-            H.pin(a_)
+        # (b) the caller's query and result matrices are page-locked (hnsw_host_alloc / hnsw_host_register; an OCaml benchmark
+        #     loop passes the same Bigarrays again and again) and the results land in them
+        Qp = H.host_empty((nq, d), np.float32)
+        Qp[:] = Qh
+        oi_ = H.host_empty((nq, k), np.int32)
+        od_ = H.host_empty((nq, k), np.float32)
+        Qh_pageable, Qh = Qh, Qp
         H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef, out=(oi_, od_))
         checks["registered_arrays_equal_device_call"] = bool(np.array_equal(oi_, got) and np.array_equal(od_.view(np.uint32), got_dist.view(np.uint32)))
         sync_r = timed_calls(lambda: H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef, out=(oi_, od_)))
@@ -561,10 +561,8 @@ def main():
         sub = timed_calls(one_submit_wait)
         while inflight:
             inflight.pop(0).wait(out=(oi_, od_))
-        for a_ in (Qh, oi_, od_):
-            H.unpin(a_)
         drop_in = {"synchronous": leg(*sync_r, "the headline protocol again, as the median of %d single calls: hnsw_search_batch, the caller's query / result "
-                                               "matrices registered once (hnsw_host_register): H2D -> ordering pre-pass + search kernel -> D2H, one blocking "
+                                               "matrices page-locked (hnsw_host_alloc / hnsw_host_register: queries read and results written by the device directly) -> ordering pre-pass + search kernel, one blocking "
                                                "call per %d-query batch = the body of Ohnsw.knn_batch_bigarray" % (reps, nq)),
                    "synchronous_pageable": leg(*sync_p, "the same call on fresh pageable matrices (copies staged by the runtime)"),
                    "submit_wait_2_in_flight": leg(*sub, "hnsw_search_submit / hnsw_search_wait, two requests in flight, registered matrices"),
@@ -628,10 +626,9 @@ def main():
             hg2.set_option("time_kernels", 0)
             return w, sm, pm
 
-        Q2h = Q2d.cpu().numpy()
-        h2i, h2d = np.empty((nq, k), np.int32), np.empty((nq, k), np.float32)
-        for a_ in (Q2h, h2i, h2d):
-            H.pin(a_)
+        Q2h = H.host_empty((nq, d), np.float32)
+        Q2h[:] = Q2d.cpu().numpy()
+        h2i, h2d = H.host_empty((nq, k), np.int32), H.host_empty((nq, k), np.float32)
 
         def timed2_host(ef_, steps):
             """the headline protocol on this set: hnsw_search_batch, registered host matrices in and out"""
@@ -710,8 +707,6 @@ def main():
                     break
         log("secondary (256 blobs, sigma 40): %.0f q/s at ef=%d, recall@10 %.4f, %.0f evaluations/query, frac %.3f (%.1fs)" %
             (nq / w2, ef, rec2, nd2, ach2 / HBM_PEAK_GBS, time.time() - t0))
-        for a_ in (Q2h, h2i, h2d):
-            H.unpin(a_)
         hg2.release()
         del hg2
         # Is the batched device builder the reason this set misses the gate at ef 128?  The same recipe at n = 100 000,
@@ -1128,10 +1123,11 @@ def main():
                                        "closer_to_SIFT1M": True})},
             "protocol": ("one synchronous call per %d-query batch with HOST matrices in and out, as benchmark/benchmark.ml:89-96 times knn_batch "
                          "and SURVEY 8d prescribes: " % nq) +
-                        ("hnsw_search_batch (H2D of the queries, ordering pre-pass, search kernel, D2H of the results; the caller's matrices "
-                         "registered once with hnsw_host_register)" if world == 1 else
-                         "per rank H2D of its query shard (pinned), search, RCCL all-gather of the per-shard results (the full table resident on every "
-                         "GPU), D2H of the rank's own shard, stream synchronisation") +
+                        ("hnsw_search_batch (H2D of the queries, ordering pre-pass, search kernel, D2H of the results; the caller's matrices in "
+                         "page-locked memory: hnsw_host_alloc / hnsw_host_register)" if world == 1 else
+                         "per rank hnsw_search_batch_h2d (its registered query shard read by the device, ordering pre-pass, search kernel, results in "
+                         "HBM), RCCL all-gather of the per-shard results (the full table resident on every GPU), D2H of the rank's own shard, stream "
+                         "synchronisation") +
                         "; the rate with the queries already resident in HBM and the results left there is `device_resident`",
             "device_resident": {"value": round(qps_dev, 1), "unit": "queries/s", "ms_per_step": round(1e3 * wall_dev / args.steps, 4),
                                 "ms_per_step_stats": headline_steps, "kernel_ms": round(dev_lib["search_ms"], 4), "prepass_ms": round(dev_lib["prepass_ms"], 4),

@@ -196,14 +196,23 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
                           const hnsw_search_params *params, int32_t *out_ids, float *out_dist,
                           uint32_t *out_ndist, uint32_t *out_nhops);
 
-/* Optional: page-lock a host array of the caller (hipHostRegister) so that the copies of the host-buffer entry points
- * (hnsw_search_batch, hnsw_search_submit / hnsw_search_wait, hnsw_multi_search_batch) run asynchronously at PCIe speed
- * instead of being staged by the runtime.  The CALLER owns the lifetime: the array must stay allocated (an OCaml
- * Bigarray: reachable) until hnsw_host_unregister; the library never registers anything behind the caller's back.
- * Registering an array twice is not an error.  OCaml side: Hnsw_mi355x.pin / unpin on the query and result Bigarrays of
- * a benchmark loop (benchmark/benchmark.ml:86-98 passes the same matrices again and again). */
+/* Optional: page-locked query / result matrices.  The host-buffer entry points (hnsw_search_batch, hnsw_search_batch_h2d,
+ * hnsw_search_submit / hnsw_search_wait, hnsw_multi_search_batch) then do not copy such a matrix at all where they can: the
+ * device reads the queries straight out of it (each query once, by the wave that searches it: the transfer runs under the
+ * ordering pre-pass) and writes every query's results straight into the caller's result matrices as the query finishes.
+ * Everything is complete when the call returns.  Two ways to get such memory:
+ *   hnsw_host_alloc / hnsw_host_free        the library allocates page-locked memory (hipHostMalloc); the OCaml side wraps it
+ *                                           as a Bigarray (Ctypes.bigarray_of_ptr; Hnsw_mi355x.alloc_mat).
+ *   hnsw_host_register / hnsw_host_unregister  page-lock an array the caller already has (hipHostRegister).  The CALLER owns
+ *                                           the lifetime: the array stays allocated (a Bigarray: reachable) until
+ *                                           hnsw_host_unregister; the library never registers anything behind the caller's
+ *                                           back.  Registering an array twice is not an error; an array of which only a
+ *                                           part is registered already is refused.
+ * Only ranges obtained through these four calls are accessed directly; any other pointer is staged through copies. */
 int32_t hnsw_host_register(void *p, int64_t bytes);
 int32_t hnsw_host_unregister(void *p);
+int32_t hnsw_host_alloc(void **out, int64_t bytes);
+int32_t hnsw_host_free(void *p);
 
 /* Same, device buffers, asynchronous on `stream` (a hipStream_t; NULL = default stream).
  * d_status (optional, [nq] uint32): bit 0 set if the query's list of tied, still expandable
@@ -218,6 +227,17 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
                                  int64_t q_stride, const hnsw_search_params *params,
                                  int32_t *d_ids, float *d_dist, uint32_t *d_ndist,
                                  uint32_t *d_nhops, uint32_t *d_status, void *stream);
+
+/* The batch call with its two ends apart: the queries come from HOST memory ([nq][q_stride], as hnsw_search_batch takes
+ * them: read by the device directly when the caller registered the matrix with hnsw_host_register, staged through the
+ * handle's scratch otherwise), the results are left in DEVICE buffers, everything asynchronous on `stream` -- for a caller
+ * that exchanges per-shard results between devices (one process per GPU and an RCCL all-gather: bench.py --gpus N,
+ * ocaml-hnsw_amd/sharding.py) before anything goes back to the host.  The queries must stay valid until the stream has
+ * passed the call; one such call in flight per handle (it uses the handle's query scratch).  As hnsw_search_batch_device:
+ * flags only (d_status), unless the option "device_fallback_slab_bytes" is set. */
+int32_t hnsw_search_batch_h2d(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
+                              const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
+                              uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, void *stream);
 
 /* The same batch call in two halves, for callers that keep batches coming: a single batch ends with
  * a drain phase (its last queries run on a nearly empty chip at their serial latency, DESIGN.md

@@ -31,14 +31,14 @@ SEM_OHNSW, SEM_FUNCTOR, SEM_FUNCTOR_NEAREST_K = 0, 1, 2
 ABI_SYMBOLS = [
     "hnsw_abi_version", "hnsw_last_error", "hnsw_device_count", "hnsw_index_create",
     "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_index_row_bytes", "hnsw_search_batch",
-    "hnsw_search_batch_device", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
+    "hnsw_search_batch_device", "hnsw_search_batch_h2d", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
     "hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_save", "hnsw_index_load",
     "hnsw_search_layer_batch", "hnsw_search_one_batch",
     "hnsw_search_submit", "hnsw_search_wait", "hnsw_index_kernel_times",
     "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
     "hnsw_multi_search_batch_device", "hnsw_multi_copy_result", "hnsw_multi_debug_counters",
-    "hnsw_host_register", "hnsw_host_unregister",
+    "hnsw_host_register", "hnsw_host_unregister", "hnsw_host_alloc", "hnsw_host_free",
 ]
 
 
@@ -109,6 +109,7 @@ def load():
     L.hnsw_index_row_bytes.restype = i32
     L.hnsw_search_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp]
     L.hnsw_search_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.hnsw_search_batch_h2d.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.hnsw_knn.argtypes = [vp, vp, vp, vp, vp, vp]
     L.hnsw_distance_batch.argtypes = [vp, vp, i64, i64, vp, i32, vp]
     L.hnsw_distance_batch_device.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp]
@@ -128,7 +129,7 @@ def load():
               "hnsw_index_export_upper"):
         getattr(L, f).restype = i32
     for f in ("hnsw_device_count", "hnsw_index_create", "hnsw_index_destroy", "hnsw_index_get_info",
-              "hnsw_index_set_option", "hnsw_search_batch", "hnsw_search_batch_device", "hnsw_knn",
+              "hnsw_index_set_option", "hnsw_search_batch", "hnsw_search_batch_device", "hnsw_search_batch_h2d", "hnsw_knn",
               "hnsw_distance_batch", "hnsw_distance_batch_device"):
         getattr(L, f).restype = i32
     L.hnsw_search_layer_batch.argtypes = [vp, i32, vp, i64, i64, vp, i32, vp, vp, vp, vp, vp, vp]
@@ -150,6 +151,10 @@ def load():
         L.hnsw_host_register.argtypes = [vp, i64]
         L.hnsw_host_unregister.argtypes = [vp]
         L.hnsw_host_register.restype = L.hnsw_host_unregister.restype = i32
+    if hasattr(L, "hnsw_host_alloc"):
+        L.hnsw_host_alloc.argtypes = [vp, i64]
+        L.hnsw_host_free.argtypes = [vp]
+        L.hnsw_host_alloc.restype = L.hnsw_host_free.restype = i32
     for f in ("hnsw_search_layer_batch", "hnsw_search_one_batch", "hnsw_multi_create", "hnsw_multi_destroy",
               "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
               "hnsw_multi_search_batch_device", "hnsw_multi_copy_result", "hnsw_multi_debug_counters"):
@@ -364,9 +369,37 @@ class Hgraph:
             pass
 
 
+class _HostBlock:
+    """page-locked memory from hnsw_host_alloc, exposed through the array interface; freed with its last numpy view"""
+
+    def __init__(self, shape, dtype):
+        dt = _np.dtype(dtype)
+        self.shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.nbytes = max(1, int(_np.prod(self.shape, dtype=_np.int64)) * dt.itemsize)
+        p = _C.c_void_p()
+        _check(load().hnsw_host_alloc(_C.byref(p), self.nbytes))
+        self.ptr = p.value
+        self.__array_interface__ = {"data": (self.ptr, False), "shape": self.shape, "typestr": dt.str, "version": 3}
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                load().hnsw_host_free(_C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def host_empty(shape, dtype=_np.float32):
+    """A numpy array in page-locked memory the library allocates (hnsw_host_alloc): the host-buffer entry points read such
+    query matrices and write such result matrices directly from the device, without copies.  Freed with the array."""
+    return _np.asarray(_HostBlock(shape, dtype))
+
+
 def pin(array):
     """hnsw_host_register: page-lock a host array the caller keeps alive (its query or result matrix of a benchmark
-    loop), so that the host-buffer entry points copy it at PCIe speed.  Undo with unpin() BEFORE the array is freed."""
+    loop): the host-buffer entry points then access it directly from the device.  Undo with unpin() BEFORE the array is
+    freed (host_empty() gives memory the library owns instead)."""
     a = _np.asarray(array)
     if not a.flags["C_CONTIGUOUS"]:
         raise InvalidArgument("pin: array must be C-contiguous")
@@ -444,6 +477,20 @@ def search_batch_device(hgraph, d_queries, nq, q_stride, ef, k, d_ids, d_dist, d
     _check(load().hnsw_search_batch_device(hgraph.handle, d_queries, nq, q_stride, _C.byref(p), d_ids,
                                            d_dist, d_ndist or None, d_nhops or None,
                                            d_status or None, stream or None))
+
+
+def search_batch_h2d(hgraph, batch, ef, k, d_ids, d_dist, d_ndist=0, d_nhops=0, d_status=0, stream=0,
+                     fill=FILL_OHNSW, sem=SEM_OHNSW):
+    """hnsw_search_batch_h2d: queries from a HOST matrix (read by the device directly when it was registered with pin()),
+    results left in device buffers (pointers as ints), asynchronous on HIP stream `stream`.  The matrix must stay alive
+    until the stream has passed the call."""
+    Q, qs = _rows(batch)
+    if Q.ndim != 2 or Q.shape[0] < 1 or Q.shape[1] != hgraph.d:
+        raise InvalidArgument("batch must be [nq][d], nq >= 1")
+    p = _SearchParams(ef, k, fill, sem)
+    _check(load().hnsw_search_batch_h2d(hgraph.handle, _ptr(Q), Q.shape[0], max(qs, hgraph.d), _C.byref(p), d_ids, d_dist,
+                                        d_ndist or None, d_nhops or None, d_status or None, stream or None))
+    return Q          # the array the device reads: keep it alive until the stream is synchronised
 
 
 class Ohnsw:

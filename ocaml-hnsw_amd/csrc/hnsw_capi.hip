@@ -633,6 +633,25 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
     return HNSW_OK;
 }
 
+int32_t hnsw_search_batch_h2d(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
+                              const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
+                              uint32_t *d_ndist, uint32_t *d_nhops, uint32_t *d_status, void *stream) {
+    int rc = check_params(idx, params);
+    if (rc) return rc;
+    if (nq == 0) return HNSW_OK;
+    if (nq < 0 || nq > 0x7FFFFFFFLL || !queries || !d_ids || !d_dist) return fail(HNSW_ERR_BAD_ARG, "bad buffers");
+    if (q_stride < idx->iv.d) return fail(HNSW_ERR_BAD_ARG, "q_stride < d");
+    HIP_TRY(hipSetDevice(idx->device));
+    const size_t qbytes = ((size_t)(nq - 1) * q_stride + idx->iv.d) * sizeof(float);
+    if ((rc = idx->sQ.ensure(qbytes))) return rc;
+    static const int zero_copy = env_int("HNSW_ZERO_COPY", 1);
+    const float *zq = zero_copy ? (const float *)registered_device_address(queries, qbytes) : nullptr;
+    if (!zq) HIP_TRY(hipMemcpyAsync(idx->sQ.p, queries, qbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    // registered matrix: read by the device directly, the pre-pass (when there is one) leaves the device copy in sQ
+    return search_batch_device_flag(idx, zq ? zq : (const float *)idx->sQ.p, nq, q_stride, params, d_ids, d_dist, d_ndist, d_nhops, d_status,
+                                    nullptr, stream, zq ? (float *)idx->sQ.p : nullptr);
+}
+
 int32_t hnsw_search_submit(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
                            const hnsw_search_params *params, hnsw_request **out) {
     if (!out) return fail(HNSW_ERR_BAD_ARG, "null out");
@@ -710,6 +729,18 @@ int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uin
     return done(HNSW_OK);
 }
 
+namespace {
+void remember_range(const void *p, size_t bytes, void *dev) {
+    std::lock_guard<std::mutex> lk(g_ranges_mu);
+    for (HostRange &r : g_ranges) if (r.p == (const char *)p) { r.bytes = std::max(r.bytes, bytes); r.dev = (char *)dev; return; }
+    g_ranges.push_back({(const char *)p, bytes, (char *)dev});
+}
+void forget_range(const void *p) {
+    std::lock_guard<std::mutex> lk(g_ranges_mu);
+    for (size_t i = 0; i < g_ranges.size(); ++i) if (g_ranges[i].p == (const char *)p) { g_ranges.erase(g_ranges.begin() + (long)i); return; }
+}
+} // namespace
+
 int32_t hnsw_host_register(void *p, int64_t bytes) {
     if (!p || bytes <= 0) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_register: null buffer or bytes <= 0");
     hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
@@ -728,23 +759,35 @@ int32_t hnsw_host_register(void *p, int64_t bytes) {
                     "(unregister the shorter range first)", (long long)bytes);
     void *dev = nullptr;
     if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }   // no mapping: copies only
-    if (dev) {
-        std::lock_guard<std::mutex> lk(g_ranges_mu);
-        bool known = false;
-        for (HostRange &r : g_ranges) if (r.p == (const char *)p) { r.bytes = std::max(r.bytes, (size_t)bytes); r.dev = (char *)dev; known = true; }
-        if (!known) g_ranges.push_back({(const char *)p, (size_t)bytes, (char *)dev});
-    }
+    if (dev) remember_range(p, (size_t)bytes, dev);
     return HNSW_OK;
 }
 
 int32_t hnsw_host_unregister(void *p) {
     if (!p) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_unregister: null buffer");
-    {
-        std::lock_guard<std::mutex> lk(g_ranges_mu);
-        for (size_t i = 0; i < g_ranges.size(); ++i) if (g_ranges[i].p == (const char *)p) { g_ranges.erase(g_ranges.begin() + (long)i); break; }
-    }
+    forget_range(p);
     hipError_t e = hipHostUnregister(p);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e)); }
+    return HNSW_OK;
+}
+
+int32_t hnsw_host_alloc(void **out, int64_t bytes) {
+    if (!out || bytes <= 0) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_alloc: null out or bytes <= 0");
+    *out = nullptr;
+    void *p = nullptr, *dev = nullptr;
+    hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(e == hipErrorOutOfMemory ? HNSW_ERR_OOM : HNSW_ERR_HIP, "hipHostMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); }
+    if (hipHostGetDevicePointer(&dev, p, 0) == hipSuccess && dev) remember_range(p, (size_t)bytes, dev);
+    else (void)hipGetLastError();
+    *out = p;
+    return HNSW_OK;
+}
+
+int32_t hnsw_host_free(void *p) {
+    if (!p) return HNSW_OK;
+    forget_range(p);
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostFree failed: %s", hipGetErrorString(e)); }
     return HNSW_OK;
 }
 

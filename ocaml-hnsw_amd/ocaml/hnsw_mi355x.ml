@@ -186,11 +186,17 @@ let hnsw_search_batch_device =
   foreign ~from:lib "hnsw_search_batch_device"
     (index @-> ptr float @-> int64_t @-> int64_t @-> ptr search_params @-> ptr int32_t @-> ptr float @-> ptr uint32_t
      @-> ptr uint32_t @-> ptr uint32_t @-> ptr void @-> returning int32_t)
+let hnsw_search_batch_h2d =
+  foreign ~from:lib "hnsw_search_batch_h2d"
+    (index @-> ptr float @-> int64_t @-> int64_t @-> ptr search_params @-> ptr int32_t @-> ptr float @-> ptr uint32_t
+     @-> ptr uint32_t @-> ptr uint32_t @-> ptr void @-> returning int32_t)
 let hnsw_distance_batch_device =
   foreign ~from:lib "hnsw_distance_batch_device"
     (index @-> ptr float @-> int64_t @-> int64_t @-> ptr int32_t @-> int32_t @-> ptr float @-> ptr void @-> returning int32_t)
 let hnsw_host_register = foreign ~from:lib "hnsw_host_register" (ptr void @-> int64_t @-> returning int32_t)
 let hnsw_host_unregister = foreign ~from:lib "hnsw_host_unregister" (ptr void @-> returning int32_t)
+let hnsw_host_alloc = foreign ~from:lib "hnsw_host_alloc" (ptr (ptr void) @-> int64_t @-> returning int32_t)
+let hnsw_host_free = foreign ~from:lib "hnsw_host_free" (ptr void @-> returning int32_t)
 
 (* Error convention -> the reference's exceptions (lib/ohnsw.ml:25,343,862) *)
 let check rc =
@@ -714,6 +720,18 @@ let stats_compute (t : t) ~max_layer : (int * (int * int * float * int list)) li
    never registers memory on its own. *)
 let pin (m : (_, _, _) A2.t) = check (hnsw_host_register (to_voidp (bigarray_start array2 m)) (Int64.of_int (A2.size_in_bytes m)))
 let unpin (m : (_, _, _) A2.t) = check (hnsw_host_unregister (to_voidp (bigarray_start array2 m)))
+
+(* A Lacaml-shaped matrix (float32, Fortran layout, dim x n) in page-locked memory the LIBRARY allocates (hnsw_host_alloc):
+   page-locked from the start, no registration to undo.
+   Freed by the finaliser of the returned Bigarray's proxy (keep using the Bigarray only through the returned value). *)
+let alloc_mat ~dim ~n : Lacaml.S.mat =
+  let out = allocate (ptr void) null in
+  check (hnsw_host_alloc out (Int64.of_int (4 * dim * n)));
+  let p = !@out in
+  let m = bigarray_of_ptr array2 (n, dim) Bigarray.float32 (from_voidp float p) in          (* n rows of dim floats in memory ... *)
+  let m = Bigarray.Array2.change_layout m Bigarray.fortran_layout in                      (* ... = a dim x n Fortran matrix, as Lacaml's *)
+  Gc.finalise (fun _ -> ignore (hnsw_host_free p)) m;
+  m
 
 (* the graph of a device index as a [flat] (the input of unflatten_ohnsw / unflatten_ba): e.g. an index built on the
    device with [build], handed back to the OCaml builder so that Ohnsw.insert can go on from there *)

@@ -34,6 +34,22 @@ def test_exports_every_declared_symbol(H):
     assert L.hnsw_abi_version() == 1
 
 
+def test_ctypes_mirror_declares_every_argument_list(H):
+    """Every entry point that takes arguments has its ctypes argtypes set with the header's arity: without them ctypes
+    passes a Python int as a 32-bit C int and a 64-bit pointer arrives truncated (found the hard way: a device fault)."""
+    L = H.load()
+    hdr = open(os.path.join(ROOT, "include", "hnsw_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for m in re.finditer(r"\b(hnsw_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n_args = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        fn = getattr(L, name)
+        if n_args == 0:
+            continue
+        assert fn.argtypes is not None, "%s: no argtypes in ocaml-hnsw_amd/__init__.py" % name
+        assert len(fn.argtypes) == n_args, "%s: %d argtypes, the header declares %d arguments" % (name, len(fn.argtypes), n_args)
+
+
 def test_no_torch_types_in_abi():
     hdr = open(os.path.join(ROOT, "include", "hnsw_mi355x.h")).read()
     assert "torch" not in hdr and "at::" not in hdr and "std::" not in hdr

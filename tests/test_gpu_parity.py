@@ -377,6 +377,43 @@ def test_tie_overflow_beyond_lds_stack(H, oracle):
     assert ((st.cpu().numpy() & 1) == 1).all()
 
 
+def test_host_queries_device_results(H, oracle):
+    """hnsw_search_batch_h2d: queries from a host matrix (registered: read by the device directly; pageable: staged), results
+    in device buffers on the caller's stream -- the same bits as the all-host and the all-device call, for a batch large
+    enough to be ordered (the pre-pass then leaves the device copy of the queries) and for a small one."""
+    import torch
+    dev = torch.device("cuda", 0)
+    X = _dataset("sift", 20000, 128, 3)
+    hg = H.Ohnsw.build_batch_bigarray(X, 16, 80, seed=2)
+    for nq in (9000, 300):
+        Q = _mmap_array((nq, 128), np.float32, _dataset("sift", nq, 128, 4 + nq))
+        want_i, want_d, want_nd, want_nh = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=128, counters=True)
+        ids = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+        dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+        nd = torch.zeros(nq, dtype=torch.int32, device=dev)
+        nh = torch.zeros(nq, dtype=torch.int32, device=dev)
+        st = torch.zeros(nq, dtype=torch.int32, device=dev)
+        for registered in (False, True):
+            if registered:
+                H.pin(Q)
+            try:
+                ids.fill_(-9)
+                keep = H.search_batch_h2d(hg, Q, 128, 10, ids.data_ptr(), dd.data_ptr(), nd.data_ptr(), nh.data_ptr(), st.data_ptr(), 0)
+                torch.cuda.synchronize()
+                del keep
+            finally:
+                if registered:
+                    H.unpin(Q)
+            np.testing.assert_array_equal(ids.cpu().numpy(), want_i)
+            np.testing.assert_array_equal(dd.cpu().numpy().view(np.uint32), want_d.view(np.uint32))
+            np.testing.assert_array_equal(nd.cpu().numpy().astype(np.uint32), want_nd)
+            np.testing.assert_array_equal(nh.cpu().numpy().astype(np.uint32), want_nh)
+            assert not (st.cpu().numpy() & 1).any()
+    with pytest.raises(H.InvalidArgument):
+        H.search_batch_h2d(hg, X[:4, :64], 16, 4, ids.data_ptr(), dd.data_ptr())
+    hg.release()
+
+
 @pytest.mark.parametrize("levels", [3, 8])
 def test_functor_accept_rule_on_ties(H, oracle, levels):
     """Hnsw.Ba: Nearest.insert_distance (lib/hnsw.ml:494-506) accepts an element that is not farther
@@ -540,50 +577,89 @@ def test_nearest_k_compat_reproduces_the_reference_output(H, oracle):
             np.testing.assert_array_equal(plain.view(np.uint32), got.view(np.uint32))
 
 
+def _mmap_array(shape, dtype, fill=None):
+    """a numpy array on an anonymous mmap region of its own (page aligned, nothing else in its pages)"""
+    import mmap
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    a = np.frombuffer(mmap.mmap(-1, max(nbytes, 1)), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    if fill is not None:
+        a[...] = fill
+    return a
+
+
 def test_registered_host_arrays_and_caller_owned_results(H, oracle):
-    """hnsw_host_register / hnsw_host_unregister (the caller owns the lifetime) and results written into the caller's
-    matrices: same bits as the plain call, for the synchronous call and for submit / wait; registering twice is fine."""
+    """Page-locked matrices of the caller -- registered (hnsw_host_register / hnsw_host_unregister: the caller owns the
+    lifetime) or allocated by the library (hnsw_host_alloc) -- and results written into them: the device accesses them
+    directly, same bits as the plain call, for the synchronous call and for submit / wait; registering twice is fine;
+    arrays registered only in part are refused."""
     X = _dataset("sift", 5000, 128, 3)
-    Q = _dataset("sift", 3000, 128, 4)          # > 64 KiB so that the copies are worth pinning
+    Q0 = _dataset("sift", 3000, 128, 4)
     hg = H.Ohnsw.build_batch_bigarray(X, 16, 80, seed=2)
     k, ef = 10, 128
-    want_i, want_d = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef)
-    ids = np.full((Q.shape[0], k), -7, np.int32)
-    dist = np.zeros((Q.shape[0], k), np.float32)
-    for a in (Q, ids, dist):
-        H.pin(a)
-    H.pin(Q)                                     # twice: not an error
-    try:
-        got = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, out=(ids, dist))
-        assert got[0] is ids and got[1] is dist
-        np.testing.assert_array_equal(ids, want_i)
-        np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
-        ids[:] = -7
-        r = H.submit(hg, Q, ef, k)
-        r.wait(out=(ids, dist))
-        np.testing.assert_array_equal(ids, want_i)
-        np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
-    finally:
-        for a in (Q, ids, dist):
-            H.unpin(a)
-    with pytest.raises(H.Failure):
-        H.unpin(ids)                             # not registered any more
+    want_i, want_d = H.Ohnsw.knn_batch_bigarray(hg, k, Q0, ef=ef)
+    for how in ("registered", "allocated"):
+        if how == "registered":
+            Q = _mmap_array(Q0.shape, np.float32, Q0)
+            ids, dist = _mmap_array((Q.shape[0], k), np.int32, -7), _mmap_array((Q.shape[0], k), np.float32, 0)
+            for a in (Q, ids, dist):
+                H.pin(a)
+            H.pin(Q)                                 # twice: not an error
+        else:
+            Q = H.host_empty(Q0.shape, np.float32)
+            Q[:] = Q0
+            ids, dist = H.host_empty((Q.shape[0], k), np.int32), H.host_empty((Q.shape[0], k), np.float32)
+            ids[:] = -7
+        try:
+            got = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, out=(ids, dist))
+            assert got[0] is ids and got[1] is dist
+            np.testing.assert_array_equal(ids, want_i)
+            np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
+            ids[:] = -7
+            got = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, out=(ids, dist), counters=True)     # counters staged, results direct
+            np.testing.assert_array_equal(ids, want_i)
+            assert (got[2] > 0).all()
+            ids[:] = -7
+            r = H.submit(hg, Q, ef, k)
+            r.wait(out=(ids, dist))
+            np.testing.assert_array_equal(ids, want_i)
+            np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
+            # page-locked queries, pageable results and the other way round
+            pi, pd = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef)
+            np.testing.assert_array_equal(pi, want_i)
+            ids[:] = -7
+            H.Ohnsw.knn_batch_bigarray(hg, k, Q0, ef=ef, out=(ids, dist))
+            np.testing.assert_array_equal(ids, want_i)
+            # a sub-matrix of a page-locked matrix (rows 100..): still inside the registered range
+            sub_i, sub_d = H.Ohnsw.knn_batch_bigarray(hg, k, Q[100:], ef=ef)
+            np.testing.assert_array_equal(sub_i, want_i[100:])
+        finally:
+            if how == "registered":
+                for a in (Q, ids, dist):
+                    H.unpin(a)
+        if how == "registered":
+            with pytest.raises(H.Failure):
+                H.unpin(ids)                         # not registered any more
+    ids, dist = np.full((Q0.shape[0], k), -7, np.int32), np.zeros((Q0.shape[0], k), np.float32)
     with pytest.raises(H.InvalidArgument):
-        H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, out=(ids[:, :5], dist))
+        H.Ohnsw.knn_batch_bigarray(hg, k, Q0, ef=ef, out=(ids[:, :5], dist))
     # a strided view or a Fortran-ordered matrix has the right shape and dtype but is not nq * k contiguous words
-    big_i, big_d = np.zeros((Q.shape[0], 2 * k), np.int32), np.zeros((Q.shape[0], 2 * k), np.float32)
+    big_i, big_d = np.zeros((Q0.shape[0], 2 * k), np.int32), np.zeros((Q0.shape[0], 2 * k), np.float32)
     for bad in ((big_i[:, :k], big_d[:, :k]), (np.asfortranarray(ids), dist)):
-        r = H.submit(hg, Q, ef, k)
+        r = H.submit(hg, Q0, ef, k)
         with pytest.raises(H.InvalidArgument, match="contiguous"):
             r.wait(out=bad)
         r.wait(out=(ids, dist))                  # the request is still there to be waited for
         np.testing.assert_array_equal(ids, want_i)
     assert not big_i.any() and not big_d.any()
     # an existing registration that covers only the head of the array does not make the whole array registered
-    whole = np.zeros(1 << 22, np.uint8)
+    whole = _mmap_array((1 << 22,), np.uint8, 0)
     H.pin(whole[:1 << 20])
     try:
         with pytest.raises(H.InvalidArgument, match="registered already"):
             H.pin(whole)
     finally:
         H.unpin(whole[:1 << 20])
+    # a small array inside the malloc heap registers like any other (its pages stay mapped while the block is alive)
+    small = np.arange(64, dtype=np.float32)
+    H.pin(small)
+    H.unpin(small)
