@@ -833,7 +833,8 @@ def main():
             others["C3"] = other_config("C3 GloVe-1.2M shape", 1_183_514, 100, 1, 32, 200, 256, 100, 2, 200,
                                         {"TBps": 6.84, "what": "random whole 384-byte rows (the split layout's main rows) from a 1.07 GB table, independent "
                                                                 "requests, 4-8 waves/SIMD: tools/gather_ceiling.hip, profiles/r04_gather_ceiling.txt (6.22 from 4.3 GB; "
-                                                                "this index is 2.5 GB)"})
+                                                                "this index is 2.5 GB).  A search may exceed it: its walks re-read popular rows from L2 / "
+                                                                "Infinity Cache, the ceiling's requests are uniform"})
         except Exception as e:   # never lose the headline line to a secondary leg
             others["C3"] = {"skipped": "failed: %r" % (e,)}
         if free_gb is not None and free_gb < 24:

@@ -5,6 +5,8 @@
 //   Hnsw::Ba::knn / knn_batch                                                    lib/hnsw.ml:763-777
 //   Hnsw::Ohnsw::search_k / search_one, Hnsw::Ba::search                         lib/ohnsw.ml:492-588, lib/hnsw_algo.ml:350-437
 //   Hnsw::MultiHgraph (one process, several GPUs)                                SURVEY 8e
+//   Hnsw::Stats::compute (Hgraph.Stats)                                          lib/hnsw.ml:353-375
+//   Hnsw::HostMat (a page-locked Lacaml-shaped matrix the device accesses directly: hnsw_host_alloc)
 //
 // Same names, argument meaning and error behaviour: OCaml Invalid_argument -> std::invalid_argument
 // ("knn: empty hgraph", lib/ohnsw.ml:862), Failure -> std::runtime_error.  A `Mat` is a
@@ -62,6 +64,49 @@ public:
 };
 
 struct value_distance { int node; float distance_to_target; }; // lib/hnsw_algo.ml:85
+
+// A Lacaml-shaped float32 matrix (dim x n) in page-locked memory the library allocates (hnsw_host_alloc): knn_batch*
+// reads such a query matrix straight from the device, without an upload step.
+class HostMat {
+public:
+    HostMat(int32_t dim, int64_t n) : dim_(dim), n_(n) {
+        void *p = nullptr;
+        check(hnsw_host_alloc(&p, (int64_t)sizeof(float) * dim * (n > 0 ? n : 1)));
+        data_ = static_cast<float *>(p);
+    }
+    HostMat(const HostMat &) = delete;
+    HostMat &operator=(const HostMat &) = delete;
+    ~HostMat() { if (data_) hnsw_host_free(data_); }
+    float *data() { return data_; }
+    float *col(int64_t j) { return data_ + j * dim_; }          // Lacaml.S.Mat.col m (j + 1)
+    Mat mat() const { return Mat{data_, n_, dim_}; }
+private:
+    float *data_ = nullptr;
+    int32_t dim_;
+    int64_t n_;
+};
+
+// Hgraph.Stats (lib/hnsw.ml:353-375): per layer its size and the mima record {min; max; mean; isolated}; `isolated` is the
+// reference's list -- node ids, descending (consed during the ascending fold of min_max_connectivity).
+namespace Stats {
+struct mima { int min, max; double mean; std::vector<int64_t> isolated; };
+struct t { int64_t num_nodes; std::vector<int64_t> layer_sizes; std::vector<mima> layer_connectivity; };
+inline t compute(const Hgraph &g) {
+    hnsw_index_info inf{};
+    check(hnsw_index_get_info(g.handle(), &inf));
+    t out{inf.n, {}, {}};
+    for (int layer = 0; layer <= inf.max_layer; ++layer) {
+        hnsw_layer_stats s{};
+        check(hnsw_index_layer_stats(g.handle(), layer, &s));
+        mima m{s.min_degree, s.max_degree, s.mean_degree, std::vector<int64_t>((size_t)s.num_isolated)};
+        int64_t cnt = 0;
+        check(hnsw_index_layer_isolated(g.handle(), layer, m.isolated.data(), s.num_isolated, &cnt));
+        out.layer_sizes.push_back(s.num_nodes);
+        out.layer_connectivity.push_back(std::move(m));
+    }
+    return out;
+}
+} // namespace Stats
 
 namespace detail {
 inline void search(const Hgraph &g, const Mat &batch, int ef, int k, int fill, std::vector<int32_t> &ids, std::vector<float> &dist, int sem = HNSW_SEM_OHNSW) {

@@ -98,6 +98,25 @@ int main() {
         EXPECT(ra.first[0] == 0 && ra.first[1] == 1 && ra.first[2] == 4 && ra.first[3] == 3);
         EXPECT(rb.first[0] == 2 && rb.first[1] == 3);
     }
+    {   // Hgraph.Stats (lib/hnsw.ml:353-375) on a graph with an isolated node: ring of 4 + node 4 alone; ids 1-based as Hnsw.Ba's
+        static int32_t deg0[5] = {2, 2, 2, 2, 0}; static int32_t nbr0[10] = {4, 2, 1, 3, 2, 4, 3, 1, 0, 0};
+        hnsw_index_desc d{};
+        d.vectors = vals; d.n = 5; d.d = 1; d.row_stride = 1; d.metric = HNSW_METRIC_L2; d.id_base = 1;
+        d.max_degree0 = 2; d.max_degree = 1; d.max_layer = 0; d.entry_point = 1; d.deg0 = deg0; d.nbr0 = nbr0;
+        auto g = Hnsw::Hgraph::create(d);
+        auto st = Hnsw::Stats::compute(g);
+        EXPECT(st.num_nodes == 5 && st.layer_sizes.size() == 1 && st.layer_sizes[0] == 5);
+        const auto &m = st.layer_connectivity[0];
+        EXPECT(m.min == 0 && m.max == 2 && std::fabs(m.mean - 8.0 / 5.0) < 1e-12);
+        EXPECT(m.isolated.size() == 1 && m.isolated[0] == 5);
+    }
+    {   // a page-locked query matrix (hnsw_host_alloc): read by the device directly, same answers
+        auto g = ring5(vals, 2, 0);
+        Hnsw::HostMat q(1, 3);
+        q.col(0)[0] = 0.f; q.col(1)[0] = 4.5f; q.col(2)[0] = 2.2f;
+        auto r = Hnsw::Ohnsw::knn_batch_bigarray(g, 2, q.mat());
+        EXPECT(r.first[0][0] == 0 && r.first[0][1] == 1 && r.first[1][0] == 4 && r.first[1][1] == 3 && r.first[2][0] == 2 && r.first[2][1] == 3);
+    }
     std::printf(fails ? "FAILED (%d)\n" : "front-end ok\n", fails);
     return fails ? 1 : 0;
 }
