@@ -109,8 +109,10 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "global_load_dword " DB ", " AD ", off offset:64\n\t"
 // x.q -> TA and x.x -> DA for this lane's 8 dimensions; HNSW_COMBINE: |x - q|^2 - q.q = x.x - 2 x.q -> DA.
 // gfx950 hazard (not interlocked, and nothing inserts wait states into inline assembly): the result of a v_dot4 may be
-// read or overwritten by a DIFFERENT vector instruction only 3 / 4 wait states later (a following v_dot4 that takes it
-// as its accumulator is fine), so the combines come after other batches' dot products or after an s_nop.
+// read or overwritten by a DIFFERENT vector instruction only 3 wait states later (a following v_dot4 that takes it
+// as its accumulator is fine), so the combines come after other batches' dot products or after an s_nop.  These and the
+// other hand-counted states of this file (VALU-written SGPR / VCC -> VALU 2, -> lane select 4; VALU-written VGPR -> DPP 2)
+// are checked on the disassembled code object by tools/check_asm_hazards.py (tests/test_asm_hazards.py, CPU side).
 #define HNSW_DOTS(DA, DB, TA)                                                            \
     "v_dot4_u32_u8 " TA ", " DA ", %[qb0], 0\n\t"                                        \
     "v_dot4_u32_u8 " DA ", " DA ", " DA ", %[q2v]\n\t"                                     \

@@ -47,11 +47,19 @@ for trial in range(trials):
     hg.set_option("order_queries", int(rng.integers(-1, 2)))
     hg.set_option("vt_bits", int(rng.choice([0, 4, 6, 9, 11, 13])))
     hg.set_option("byte_rows", int(rng.integers(0, 4) != 0))        # (no effect where the data has no byte copy)
+    hg.set_option("split_rows", int(rng.integers(0, 4) != 0))       # (no effect where the row shape has no split copy)
     nq = int(rng.choice([1, 3, 17, 64, 200]))
     Q = (X[rng.integers(0, n, nq)] + (rng.integers(0, 2, size=(nq, d)) if metric == 0 else 0)).astype(np.float32)
     if rng.integers(0, 3) == 0:
         Q[rng.integers(0, nq)] += np.float32(0.5)                      # a query that is not byte-valued among byte-valued ones
-    ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True)
+    out = None
+    if rng.integers(0, 3) == 0:                                        # page-locked matrices: read and written by the device in place
+        Qp = H.host_empty(Q.shape, np.float32)
+        Qp[:] = Q
+        Q = Qp
+        if rng.integers(0, 2) == 0:
+            out = (H.host_empty((nq, k), np.int32), H.host_empty((nq, k), np.float32))
+    ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True, out=out)
     oi, od, ond, onh = o.Ohnsw.knn_batch_bigarray(g, sp, Q, k=k, ef=ef, ties=o.TIES_CANONICAL, counters=True)
     oi = np.where(oi >= 0, oi + id_base, -1)
     ok = np.array_equal(ids, oi) and np.array_equal(dist.view(np.uint32), od.view(np.uint32)) and np.array_equal(nh, onh)
