@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--pmc-child", default=None, help="(internal) load this index file and run a few steps: the process rocprofv3 wraps")
     ap.add_argument("--no-bench-dist", action="store_true", help="skip the bench_dist counterpart (object `bench_dist`; about 8 s)")
     ap.add_argument("--no-others", action="store_true", help="skip the C3 / C5 configurations (object `others`; about 100 s)")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the clustered variant of C3 inside `others` (its dispatches carry C3's kernel name)")
     ap.add_argument("--pipelined", action="store_true",
                     help="also time the same steps alternated over two HIP streams (extra object `pipelined`, never `value`); "
                          "off by default so that the default run's kernel trace holds serialized launches only")
@@ -882,6 +883,8 @@ def main():
         except Exception as e:   # never lose the headline line to a secondary leg
             others["C3"] = {"skipped": "failed: %r" % (e,)}
         try:     # the same shape on data with structure: what "q/s at recall >= 0.95" means for the inner-product path
+            if args.no_clustered:
+                raise RuntimeError("--no-clustered")
             others["C3_clustered"] = other_config("C3 GloVe-1.2M shape, clustered", 1_183_514, 100, 1, 32, 200, 256, 100, 12, 200,
                                                   {"TBps": 6.84, "what": "as C3"}, kind="clustered")
         except Exception as e:

@@ -121,11 +121,31 @@ hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t q
     return hipGetLastError();
 }
 
+// log2 entries of the knn kernel's visited cache: search_vt_bits' choice, then grown for free.  A kernel variant whose
+// REGISTERS cap it at few waves per CU (C3's split-row kernel: 106 VGPRs, 16 waves) leaves LDS unused; a larger cache then
+// costs no residency and saves re-evaluations, which on clustered data are many (1.18 M x 100 unit vectors around 256
+// directions, M 32, ef 256: 8239 evaluations per query with 2^11 tags against 5015 in the oracle, 6592 with 2^12: 5.22 ->
+// 4.36 ms per 10 k batch; 2^13 would halve the residency: 5.17 ms).  So: the largest cache (up to 2^14 tags) that keeps the
+// waves per CU the variant reaches with the base size.  Never changes results; "vt_bits" / HNSW_VT_BITS still override.
+int knn_vt_bits(hnsw_index *idx, int ef, int semf) {
+    const int base = search_vt_bits(idx, ef);
+    if (idx->vt_bits_override || env_int("HNSW_VT_BITS", 0) > 0 || !env_int("HNSW_VT_GROW", 1)) return base;
+    const int nslot = pick_nslot(ef), nch = pick_nch(idx->iv.nchunks);
+    const int vkey = ((nslot * 2 + semf) * 4 + variant_full(idx)) * 32 + base;
+    if (idx->vt_grow_key == vkey) return idx->vt_grow_bits;
+    const search_occupancy_fn occ = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)];
+    const int occ0 = occ(nch, nslot, hnsw_dev::wave_lds_words(base) * sizeof(uint32_t));
+    int b = base;
+    while (occ0 > 0 && b < 14 && occ(nch, nslot, hnsw_dev::wave_lds_words(b + 1) * sizeof(uint32_t)) >= occ0) ++b;
+    idx->vt_grow_key = vkey; idx->vt_grow_bits = b;
+    return b;
+}
+
 // how many one-wave workgroups of the search kernel for this ef are resident on the device at once (no LDS padding)
 int64_t resident_queries(hnsw_index *idx, int ef, int semf) {
     // cached in the handle; the answer depends on the kernel variant's registers and LDS
     const int nslot = pick_nslot(ef), nch = pick_nch(idx->iv.nchunks);
-    const size_t lds = hnsw_dev::wave_lds_words(search_vt_bits(idx, ef)) * sizeof(uint32_t);
+    const size_t lds = hnsw_dev::wave_lds_words(knn_vt_bits(idx, ef, semf)) * sizeof(uint32_t);
     const int vkey = (nslot * 2 + semf) * 4 + variant_full(idx);
     if (idx->resident_queries && idx->resident_nslot == vkey && idx->resident_lds == lds) return idx->resident_queries;
     const int per_cu = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)](nch, nslot, lds);
@@ -148,7 +168,7 @@ int64_t resident_queries(hnsw_index *idx, int ef, int semf) {
 int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
     const int forced = idx->lds_pad >= 0 ? idx->lds_pad : env_int("HNSW_LDS_PAD", -1);
     if (forced >= 0) {     // an explicit request is clamped to what a workgroup may ask for beside its own scratch
-        const int64_t base_f = (int64_t)(hnsw_dev::wave_lds_words(search_vt_bits(idx, ef)) * sizeof(uint32_t));
+        const int64_t base_f = (int64_t)(hnsw_dev::wave_lds_words(knn_vt_bits(idx, ef, semf)) * sizeof(uint32_t));
         return (int)std::max<int64_t>(0, std::min<int64_t>(std::min(forced, 32768), 65536 - base_f));
     }
     const int64_t resident = resident_queries(idx, ef, semf);
@@ -157,7 +177,7 @@ int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
     // memory system, and holds as many queries as the registers allow (C2: 0.60 ms per call at 8192 held, 0.65 at 5376)
     if (idx->iv.X8) return 0;
     constexpr int64_t GRANULE = 1280, GRANULES_PER_CU = 128;
-    const int64_t base = (int64_t)(hnsw_dev::wave_lds_words(search_vt_bits(idx, ef)) * sizeof(uint32_t));
+    const int64_t base = (int64_t)(hnsw_dev::wave_lds_words(knn_vt_bits(idx, ef, semf)) * sizeof(uint32_t));
     const int64_t passes = (nq + resident - 1) / resident;
     const int64_t want_per_cu = (nq + passes * idx->cus - 1) / (passes * idx->cus);
     const int64_t k0 = (base + GRANULE - 1) / GRANULE;
@@ -433,7 +453,7 @@ int search_rerun_device(hnsw_index *idx, const float *d_queries, int64_t nq, int
     SearchArgs a{};
     a.Q = d_queries; a.q_stride = q_stride; a.nq = c; a.ef = p->ef; a.k = p->k;
     a.fill = p->fill; a.sem = p->semantics;
-    a.vt_bits = search_vt_bits(idx, p->ef);
+    a.vt_bits = knn_vt_bits(idx, p->ef, p->semantics ? 1 : 0);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_nd; a.out_nhops = d_nh; a.out_status = d_st;
     a.qmap = qmap; a.q_limit = nq; a.ovf_g = slab; a.ovf_gcap = cap; a.prio_tail = 0x7FFFFFFF;
     return launch_search_args(idx, a, st);
@@ -475,7 +495,7 @@ extern "C++" int hnsw_host::search_batch_device_flag(hnsw_index *idx, const floa
     HIP_TRY(hipSetDevice(idx->device));
     SearchArgs a{};
     a.Q = d_queries; a.q_stride = q_stride; a.nq = nq; a.ef = params->ef; a.k = params->k; a.fill = params->fill; a.sem = params->semantics;
-    a.vt_bits = search_vt_bits(idx, params->ef);
+    a.vt_bits = knn_vt_bits(idx, params->ef, params->semantics ? 1 : 0);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_ndist; a.out_nhops = d_nhops; a.out_status = d_status;
     a.any_flag = d_any_flag;
     a.prio_tail = 0x7FFFFFFF;

@@ -107,6 +107,7 @@ struct hnsw_index {
     std::vector<OrderScratch> order_scratch;
     int order_mode = -1;                 // option "order_queries": -1 automatic (batches larger than half of resident_queries), 0 never, 1 always
     int vt_bits_override = 0;
+    int vt_grow_key = -1, vt_grow_bits = 0;   // knn_vt_bits' cached choice for (kernel variant, base size)
     int lds_pad = -1;                    // option "lds_pad": extra LDS bytes per search wave (-1 = balanced_lds_pad's choice)
 };
 

@@ -29,6 +29,9 @@ def _bytes_data(n, d, seed, hi=255):
 
 
 def _both_ways(H, hg, fn):
+    # evaluation counts include re-evaluations, which depend on the visited cache's size; the library sizes that cache per
+    # kernel variant (as large as the variant's residency allows), so the two formats are compared at one explicit size
+    hg.set_option("vt_bits", 12)
     assert hg.row_bytes() == hg.info().d
     a = fn()
     hg.set_option("byte_rows", 0)
@@ -36,6 +39,7 @@ def _both_ways(H, hg, fn):
     b = fn()
     hg.set_option("byte_rows", 1)
     assert hg.row_bytes() == hg.info().d
+    hg.set_option("vt_bits", 0)
     return a, b
 
 

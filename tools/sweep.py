@@ -18,6 +18,16 @@ def make(nn, seed):
     g = torch.Generator(device=dev); g.manual_seed(seed)
     if KIND == "uniform":
         return torch.rand((nn, d), generator=g, device=dev) * 2 - 1
+    if KIND == "cunit":      # unit vectors clustered around CENTRES random directions (bench.py: others.C3_clustered)
+        gc = torch.Generator(device=dev); gc.manual_seed(4321)
+        cen = torch.randn((centres, d), generator=gc, device=dev); cen = cen / cen.norm(dim=1, keepdim=True)
+        out = torch.empty((nn, d), device=dev)
+        for s0 in range(0, nn, 1 << 20):
+            m = min(1 << 20, nn - s0)
+            idx = torch.randint(0, centres, (m,), generator=g, device=dev)
+            x = cen[idx] + sigma * torch.randn((m, d), generator=g, device=dev) / (d ** 0.5)
+            out[s0:s0 + m] = x / x.norm(dim=1, keepdim=True)
+        return out
     x = torch.randn((nn, d), generator=g, device=dev)      # "unit": N(0,1) normalised (GloVe/DEEP-like)
     return x / x.norm(dim=1, keepdim=True)
 
