@@ -18,10 +18,18 @@
  *                            (lib/hnsw_algo.ml:350-391): one layer, explicit start nodes
  *   hnsw_search_one_batch    Ohnsw.search_one (lib/ohnsw.ml:492-512), Search.search_one
  *                            (lib/hnsw_algo.ml:393-437)
+ *   hnsw_search_batch_h2d    the same call with host queries in and DEVICE results out (per-rank step of a
+ *                            one-process-per-GPU deployment: results are exchanged between devices first)
  *   hnsw_search_submit/_wait the same batch call in two halves (several batches in flight)
  *   hnsw_multi_*             the batch entry point over several GPUs from one host process (RCCL all-gather)
  *   hnsw_distance_batch      Ohnsw.distance_l2 / EuclideanBa.distance (lib/ohnsw.ml:899,
  *                            lib/hnsw.ml:809-815) as timed by bench_dist/bench_dist.ml:22-33
+ *   hnsw_index_layer_stats / hnsw_index_layer_isolated   Hgraph.Stats.compute (lib/hnsw.ml:353-375)
+ *   hnsw_select_neighbours_batch  Ohnsw.select_neighbours (lib/ohnsw.ml:647-663),
+ *                            Hnsw_algo.SelectNeighbours.select_neighbours (lib/hnsw_algo.ml:572-609)
+ *   hnsw_build               Ohnsw.build_batch_bigarray (lib/ohnsw.ml:840-857), batched on the device
+ *   hnsw_host_alloc / hnsw_host_register   (nothing in the reference) page-locked query / result matrices,
+ *                            which the entry points above read and write from the device in place
  *
  * Plain pointers and sizes only.  All host buffers stay owned by the caller and are not
  * retained after a call returns (OCaml Bigarrays are not moved by the GC, so they can be passed

@@ -584,7 +584,7 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
     // Upload, search (ordered longest walk first when the batch is larger than the chip holds) and download on one
     // of the handle's streams, ONE stream synchronisation at the end.
     //
-    // Matrices the caller registered (hnsw_host_register) are not copied at all: the device reads the queries straight
+    // Page-locked matrices of the caller (hnsw_host_alloc / hnsw_host_register) are not copied at all: the device reads the queries straight
     // from the caller's matrix -- each query once, by the wave that searches it (the descent pre-pass keeps a device copy
     // for the search kernel), so the 5 MB of a 10 k x 128 batch cross PCIe UNDER the descent instead of before it -- and
     // the kernel writes each query's results straight into the caller's result matrices as the query finishes, so there is
@@ -614,7 +614,7 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
     int32_t *dI = zi ? zi : (int32_t *)idx->sIds.p;
     float *dD = zi ? zd : (float *)idx->sDist.p;
     uint32_t *dNd = znd ? znd : (uint32_t *)idx->sNd.p, *dNh = znh ? znh : (uint32_t *)idx->sNh.p;
-    *idx->hFlag = 0;
+    *(volatile uint32_t *)idx->hFlag = 0;
     if (!zq) HIP_TRY(hipMemcpyAsync(idx->sQ.p, queries, qbytes, hipMemcpyHostToDevice, st));
     rc = search_batch_device_flag(idx, dQ, nq, q_stride, params, dI, dD, dNd, dNh, (uint32_t *)idx->sSt.p, idx->hFlagDev, st,
                                   zq ? (float *)idx->sQ.p : nullptr);
@@ -634,7 +634,7 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
         if (rc) return rc;
         if (es != hipSuccess) return fail(HNSW_ERR_HIP, "search failed: %s", hipGetErrorString(es));
     }
-    if (!(*idx->hFlag & 1u)) return HNSW_OK;
+    if (!(*(volatile uint32_t *)idx->hFlag & 1u)) return HNSW_OK;      // written by the kernel (pinned host memory)
     // Exactness fallback for queries whose tie-overflow stack outgrew its LDS slots (rare: the rows
     // of the whole batch are then copied out again)
     int64_t n_rerun = 0;
