@@ -40,11 +40,9 @@ LLVM = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 DOT_SAME_AB, DOT_DIFF_READ, DOT_DIFF_WRITE = 3, 3, 3
 VALU_SGPR_VALU, RWLANE_SELECT, DPP_VGPR, DPP_EXEC, EXEC_RWLANE, VGPR_READLANE, VMEM_SGPR, TRANS_USE = 2, 4, 2, 5, 4, 1, 5, 1
-MAX_LOOKBACK = 5
 
 TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
 VMEM_PREFIX = ("global_", "buffer_", "flat_", "scratch_", "tbuffer_")
-NO_DST = ("v_nop", "v_cmp_", "v_cmpx_")           # handled separately
 
 
 def disassemble(path):
@@ -118,7 +116,6 @@ class Ins:
         parts = text.split(None, 1)
         self.mn = parts[0]
         rest = parts[1] if len(parts) > 1 else ""
-        mods = ""
         self.ops = split_operands(rest)
         mn = self.mn
         self.dead = False
