@@ -422,17 +422,58 @@ let create ?(device = 0) ?(metric = 0) ~id_base (vectors : Lacaml.S.mat) (f : fl
   Gc.finalise (fun t -> ignore (hnsw_index_destroy t.handle)) t;
   t
 
+(* A Lacaml-shaped matrix (float32, Fortran layout, dim x n) in page-locked memory the LIBRARY allocates (hnsw_host_alloc):
+   knn_batch* reads such a query matrix and writes such result matrices straight from the device, without copies.
+   Freed by the finaliser of the returned Bigarray (keep using the memory only through the returned value). *)
+let alloc_mat ~dim ~n : Lacaml.S.mat =
+  let out = allocate (ptr void) null in
+  check (hnsw_host_alloc out (Int64.of_int (4 * dim * (max n 1))));
+  let p = !@out in
+  let m = bigarray_of_ptr array2 (n, dim) Bigarray.float32 (from_voidp float p) in          (* n rows of dim floats in memory ... *)
+  let m = Bigarray.Array2.change_layout m Bigarray.fortran_layout in                      (* ... = a dim x n Fortran matrix, as Lacaml's *)
+  Gc.finalise (fun _ -> ignore (hnsw_host_free p)) m;
+  m
+
+(* the same for the int32 id table of a batch (k x nq Fortran = [nq][k] in memory) *)
+let alloc_ids ~k ~nq : (int32, Bigarray.int32_elt, Bigarray.fortran_layout) A2.t =
+  let out = allocate (ptr void) null in
+  check (hnsw_host_alloc out (Int64.of_int (4 * k * (max nq 1))));
+  let p = !@out in
+  let m = bigarray_of_ptr array2 (nq, k) Bigarray.int32 (from_voidp int32_t p) in
+  let m = Bigarray.Array2.change_layout m Bigarray.fortran_layout in
+  Gc.finalise (fun _ -> ignore (hnsw_host_free p)) m;
+  m
+
+(* Page-locked result scratch, one pair per (k, nq) shape seen (a benchmark or serving loop repeats its shape): the search
+   kernel writes every query's results straight into it as the query finishes -- no download step -- and [search] hands
+   fresh matrices to its caller, as the reference does (lib/ohnsw.ml:879-881), by two blits of 4 k nq bytes each.
+   (Allocating page-locked memory costs far more than a batch takes, so the scratch is kept, not the results.) *)
+let result_scratch : (int * int, (int32, Bigarray.int32_elt, Bigarray.fortran_layout) A2.t * Lacaml.S.mat) Hashtbl.t =
+  Hashtbl.create 4
+let scratch_for ~k ~nq =
+  match Hashtbl.find_opt result_scratch (k, nq) with
+  | Some s -> s
+  | None ->
+    if Hashtbl.length result_scratch >= 8 then Hashtbl.reset result_scratch;   (* shapes keep changing: do not hoard *)
+    let s = (alloc_ids ~k ~nq, alloc_mat ~dim:k ~n:nq) in
+    Hashtbl.replace result_scratch (k, nq) s;
+    s
+
 let search ?(semantics = 0) t (batch : Lacaml.S.mat) ~ef ~k ~fill =
   let nq = A2.dim2 batch in
-  (* results as the reference lays them out: k x nq Fortran = [nq][k] in memory *)
-  let distances = Lacaml.S.Mat.create k nq in
-  let ids = A2.create Bigarray.int32 Bigarray.fortran_layout k nq in
+  (* results as the reference lays them out: k x nq Fortran = [nq][k] in memory; written by the device into the
+     page-locked scratch, then copied into fresh matrices for the caller *)
+  let ids_s, dist_s = scratch_for ~k ~nq in
   let p = make search_params in
   setf p p_ef (Int32.of_int ef); setf p p_k (Int32.of_int k); setf p p_fill (Int32.of_int fill);
   setf p p_semantics (Int32.of_int semantics);
   check (hnsw_search_batch t.handle (bigarray_start array2 batch) (Int64.of_int nq)
-           (Int64.of_int t.dim) (addr p) (bigarray_start array2 ids)
-           (bigarray_start array2 distances) (from_voidp uint32_t null) (from_voidp uint32_t null));
+           (Int64.of_int t.dim) (addr p) (bigarray_start array2 ids_s)
+           (bigarray_start array2 dist_s) (from_voidp uint32_t null) (from_voidp uint32_t null));
+  let distances = Lacaml.S.Mat.create k nq in
+  let ids = A2.create Bigarray.int32 Bigarray.fortran_layout k nq in
+  A2.blit dist_s distances;
+  A2.blit ids_s ids;
   ids, distances
 
 (* ---- from the reference's own index values, nothing else needed ----------------------------------- *)
@@ -720,18 +761,6 @@ let stats_compute (t : t) ~max_layer : (int * (int * int * float * int list)) li
    never registers memory on its own. *)
 let pin (m : (_, _, _) A2.t) = check (hnsw_host_register (to_voidp (bigarray_start array2 m)) (Int64.of_int (A2.size_in_bytes m)))
 let unpin (m : (_, _, _) A2.t) = check (hnsw_host_unregister (to_voidp (bigarray_start array2 m)))
-
-(* A Lacaml-shaped matrix (float32, Fortran layout, dim x n) in page-locked memory the LIBRARY allocates (hnsw_host_alloc):
-   page-locked from the start, no registration to undo.
-   Freed by the finaliser of the returned Bigarray's proxy (keep using the Bigarray only through the returned value). *)
-let alloc_mat ~dim ~n : Lacaml.S.mat =
-  let out = allocate (ptr void) null in
-  check (hnsw_host_alloc out (Int64.of_int (4 * dim * n)));
-  let p = !@out in
-  let m = bigarray_of_ptr array2 (n, dim) Bigarray.float32 (from_voidp float p) in          (* n rows of dim floats in memory ... *)
-  let m = Bigarray.Array2.change_layout m Bigarray.fortran_layout in                      (* ... = a dim x n Fortran matrix, as Lacaml's *)
-  Gc.finalise (fun _ -> ignore (hnsw_host_free p)) m;
-  m
 
 (* the graph of a device index as a [flat] (the input of unflatten_ohnsw / unflatten_ba): e.g. an index built on the
    device with [build], handed back to the OCaml builder so that Ohnsw.insert can go on from there *)
