@@ -410,7 +410,17 @@ def test_host_queries_device_results(H, oracle):
             np.testing.assert_array_equal(nh.cpu().numpy().astype(np.uint32), want_nh)
             assert not (st.cpu().numpy() & 1).any()
     with pytest.raises(H.InvalidArgument):
-        H.search_batch_h2d(hg, X[:4, :64], 16, 4, ids.data_ptr(), dd.data_ptr())
+        H.search_batch_h2d(hg, X[:4, :64], 16, 4, ids.data_ptr(), dd.data_ptr())          # wrong dimension
+    with pytest.raises(H.InvalidArgument, match="k=20 > ef=5"):
+        H.search_batch_h2d(hg, X[:4], 5, 20, ids.data_ptr(), dd.data_ptr())
+    L = H.load()
+    import ctypes
+    p = H._SearchParams(16, 4, 0, 0)
+    assert L.hnsw_search_batch_h2d(hg.handle, None, 4, 128, ctypes.byref(p), ids.data_ptr(), dd.data_ptr(), None, None, None, None) == -1   # HNSW_ERR_BAD_ARG
+    assert L.hnsw_search_batch_h2d(hg.handle, X.ctypes.data, 0, 128, ctypes.byref(p), ids.data_ptr(), dd.data_ptr(), None, None, None, None) == 0   # empty batch
+    out = ctypes.c_void_p()
+    assert L.hnsw_host_alloc(ctypes.byref(out), 0) == -1 and L.hnsw_host_alloc(None, 64) == -1
+    assert L.hnsw_host_free(None) == 0
     hg.release()
 
 
