@@ -899,6 +899,51 @@ def main():
             except Exception as e:
                 others["C5"] = {"skipped": "failed: %r" % (e,)}
 
+    # ---- C1 (BASELINE.json configs[0]: the reference's own CPU-runnable case -- 10 k random fp32 vectors, d = 32, M 8,
+    #      efConstruction 100, ef 32, k 10, 1000 queries): the CPU restatement does the whole of it, build included (the
+    #      oracle's restatement of Ohnsw.insert), as benchmark/benchmark.ml does; the GPU searches the SAME graph and must
+    #      return the same bits.  A parity / context point, never `value`. ----
+    c1 = None
+    if world == 1 and rank == 0 and not args.no_cpu and not args.dataset and not args.no_others:
+        from oracle import oracle as o
+        t0 = time.time()
+        rng1 = np.random.default_rng(0)
+        X1 = rng1.uniform(-1.0, 1.0, size=(10_000, 32)).astype(np.float32)       # Lacaml Mat.random's default range, benchmark/dataset.ml:48
+        Q1 = rng1.uniform(-1.0, 1.0, size=(1_000, 32)).astype(np.float32)
+        sp1 = o.Space.l2(X1, arith=o.SEQ_F32)
+        t = time.perf_counter()
+        g1 = o.build_ohnsw(sp1, 8, 100, seed=0, ties=o.TIES_CANONICAL)
+        build1 = time.perf_counter() - t
+        t = time.perf_counter()
+        ci1, cd1 = o.Ohnsw.knn_batch_bigarray(g1, sp1, Q1, k=10, ef=32, ties=o.TIES_CANONICAL)
+        cpu1 = time.perf_counter() - t
+        hg1 = H.Hgraph(X1, g1.deg0, g1.nbr0, g1.upper, entry_point=g1.entry_point, id_base=0, max_degree=8).to_device(gpu)
+        gi1, gd1 = H.Ohnsw.knn_batch_bigarray(hg1, 10, Q1, ef=32)
+        ts1 = []
+        for _ in range(7):
+            t = time.perf_counter()
+            H.Ohnsw.knn_batch_bigarray(hg1, 10, Q1, ef=32)
+            ts1.append(time.perf_counter() - t)
+        ts1.sort()
+        sp1k = o.Space.l2(X1, arith=o.TREE16)                                     # the kernel's summation order: bit parity
+        ki1, kd1 = o.Ohnsw.knn_batch_bigarray(g1, sp1k, Q1, k=10, ef=32, ties=o.TIES_CANONICAL)
+        gt1 = brute_force_topk(torch.from_numpy(X1).to(dev), torch.from_numpy(Q1).to(dev), 10)
+        c1 = {"workload": "C1: 10 000 x 32 uniform fp32, M=8 efConstruction=100 (graph built by the CPU restatement of Ohnsw.insert), ef=32 k=10, 1000 queries",
+              "cpu_restatement": {"value": round(1000 / cpu1, 1), "unit": "queries/s", "cores": 1, "build_s": round(build1, 2),
+                                  "what": "single-thread C restatement of Ohnsw.build_batch_bigarray + knn_batch_bigarray, the reference's arithmetic"},
+              "gpu_same_graph": {"value": round(1000 / ts1[len(ts1) // 2], 1), "unit": "queries/s", "ms_per_batch": round(1e3 * ts1[len(ts1) // 2], 4),
+                                 "what": "hnsw_search_batch on the same graph, pageable host matrices (1000 queries: a latency point, 1/8 of the chip's wave slots)"},
+              "recall_at_10": round(recall_ids(gi1, gt1), 4),
+              "checks": {"gpu_ids_equal_cpu_reference_arithmetic": bool(np.array_equal(gi1, ci1)),
+                         "gpu_bits_equal_oracle_kernel_order": bool(np.array_equal(gi1, ki1) and np.array_equal(gd1.view(np.uint32), kd1.view(np.uint32))),
+                         "max_rel_distance_error_vs_reference_arithmetic": float(np.nanmax(np.abs(gd1 - cd1) / np.maximum(np.abs(cd1), 1e-30)))}}
+        hg1.release()
+        log("C1: cpu restatement %.0f q/s (build %.1f s), gpu on the same graph %.0f q/s, recall@10 %.3f, ids equal %s (%.1fs)" %
+            (c1["cpu_restatement"]["value"], build1, c1["gpu_same_graph"]["value"], c1["recall_at_10"],
+             c1["checks"]["gpu_ids_equal_cpu_reference_arithmetic"], time.time() - t0))
+        if others is not None:
+            others["C1"] = c1
+
     # ---- bench_dist counterpart (bench_dist/bench_dist.ml:8-33: 1 M calls of distance_l2 at d = 784, checksum, s/call,
     #      calls/s): 1 M gathered distances over random rows of a 1 M x 784 table, one launch ----
     bench_dist = None
