@@ -345,6 +345,14 @@ def test_tie_overflow_beyond_lds_stack(H, oracle):
     np.testing.assert_array_equal(got[0], want[0])
     np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
     np.testing.assert_array_equal(got[3], want[3])
+    # the same through page-locked matrices: the fallback's re-run writes the repaired rows into the caller's memory in place
+    Qp = H.host_empty(Q.shape, np.float32)
+    Qp[:] = Q
+    oi, od = H.host_empty((3, 10), np.int32), H.host_empty((3, 10), np.float32)
+    got = H.Ohnsw.knn_batch_bigarray(hg, 10, Qp, ef=128, counters=True, out=(oi, od))
+    np.testing.assert_array_equal(oi, want[0])
+    np.testing.assert_array_equal(od.view(np.uint32), want[1].view(np.uint32))
+    np.testing.assert_array_equal(got[3], want[3])
     dev = torch.device("cuda", 0)
     Qd = torch.from_numpy(Q).to(dev)
     ids = torch.empty((3, 10), dtype=torch.int32, device=dev)
