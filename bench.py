@@ -392,12 +392,15 @@ def main():
 
     lib_times = {}
     step_stats = {}
-    wall, host_stats, _ = timed_host(ef, args.steps, args.warmup)                               # the K timed steps of `value`
-    wall_hi, host_stats_i, host_lib = timed_host(ef, args.steps, 1, instrument=True)           # the same K steps with the library's events
+    # the K timed steps of `value`, with the library's kernel events in them (roofline.kernel_ms is measured over THIS region;
+    # three event records per call cost about 0.003 ms of a 0.44 ms step), and once more without, for the record
+    wall, host_stats, host_lib = timed_host(ef, args.steps, args.warmup, instrument=True)
+    wall_hi = wall
+    wall_plain, _, _ = timed_host(ef, args.steps, 1)
     qps = world * nq * args.steps / wall
     search_ms, prepass_ms = host_lib["search_ms"], host_lib["prepass_ms"]
-    log("ef=%d, host matrices in and out: %.0f q/s, %.3f ms/step (median %.3f; %.3f with the kernel events); per step: ordering pre-pass %.3f ms + search kernel %.3f ms%s" %
-        (ef, qps, 1e3 * wall / args.steps, host_stats["median"], 1e3 * wall_hi / args.steps, prepass_ms, search_ms, " [byte rows]" if byte_rows else ""))
+    log("ef=%d, host matrices in and out: %.0f q/s, %.3f ms/step (median %.3f; %.3f without the kernel events); per step: ordering pre-pass %.3f ms + search kernel %.3f ms%s" %
+        (ef, qps, 1e3 * wall / args.steps, host_stats["median"], 1e3 * wall_plain / args.steps, prepass_ms, search_ms, " [byte rows]" if byte_rows else ""))
     # ---- the same steps with the queries already resident in HBM and the results left there (hnsw_search_batch_device) ----
     wall_dev, _ = timed(ef, args.steps, args.warmup, instrument=False)
     wall_dev_i, kern_ms = timed(ef, args.steps, 1)
@@ -1172,11 +1175,10 @@ def main():
                     "bytes_per_query": round(bq, 1), "n_dist_per_query": round(n_dist_mean, 1),
                     "n_hops_per_query": round(n_hops_mean, 1), "counters": src,
                     "kernel_ms_source": "HIP events the library records on its launch stream around its own launches (option time_kernels), mean "
-                                        "over a second pass of the same %d steps of the `value` protocol: three event records per call cost the "
-                                        "stream about 0.009 ms, so the timed steps of `value` run without them (%.4f ms per step with them)"
-                                        % (args.steps, 1e3 * wall_hi / args.steps),
+                                        "over the %d timed steps of `value` themselves (the same steps without the event records: %.4f ms per step)"
+                                        % (args.steps, 1e3 * wall_plain / args.steps),
                     "step": {"host_call_ms": round(1e3 * wall / args.steps, 4), "host_call_ms_stats": host_stats,
-                             "host_call_ms_with_kernel_events": round(1e3 * wall_hi / args.steps, 4),
+                             "host_call_ms_without_kernel_events": round(1e3 * wall_plain / args.steps, 4),
                              "device_call_ms": round(kern_ms, 4), "device_call_ms_stats": headline_steps, "prepass_ms": round(prepass_ms, 4),
                              "kernel_ms_in_device_resident_steps": round(dev_lib["search_ms"], 4),
                              "prepass": "hnsw_descent_kernel + radix sort (longest-first ordering)" if ordered else None,
