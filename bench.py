@@ -393,7 +393,7 @@ def main():
     lib_times = {}
     step_stats = {}
     # the K timed steps of `value`, with the library's kernel events in them (roofline.kernel_ms is measured over THIS region;
-    # three event records per call cost about 0.003 ms of a 0.44 ms step), and once more without, for the record
+    # three event records per call cost 0.003-0.015 ms of a 0.44 ms step), and once more without, for the record
     wall, host_stats, host_lib = timed_host(ef, args.steps, args.warmup, instrument=True)
     wall_hi = wall
     wall_plain, _, _ = timed_host(ef, args.steps, 1)
