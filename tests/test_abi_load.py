@@ -99,7 +99,8 @@ def test_ocaml_binding_binds_every_declared_symbol():
     missing = [s for s in _declared_symbols() if not re.search(r'foreign[^"]*"%s"' % s, ml)]
     assert not missing, missing
     for wrapper in ("let knn ", "let ba_knn ", "let knn_batch_bigarray ", "let knn_batch ", "let distance_batch ",
-                    "let select_neighbours ", "let build ", "let save ", "let load ", "let stats ", "let pin ", "let unpin ", "let export "):
+                    "let select_neighbours ", "let build ", "let save ", "let load ", "let stats ", "let isolated ", "let stats_compute ",
+                    "let pin ", "let unpin ", "let alloc_mat ", "let alloc_ids ", "let scratch_for ", "let export "):
         assert wrapper in ml, wrapper
     # struct field orders match the header (ctypes structures are positional)
     hdr = open(os.path.join(ROOT, "include", "hnsw_mi355x.h")).read()
