@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""One-off check at the edge of the hand-scheduled loops' 32-bit row offsets: the layer-0 loop forms the byte
+"""One-off check (not collected by pytest; it uses the oracle, so it lives under tests/) at the edge of the hand-scheduled loops' 32-bit row offsets: the layer-0 loop forms the byte
 offset (id + 1) * S0 * 4 + lane * 4 in 32 bits and is taken only while ((n + 1) * S0 < 2^30).  Two indexes of byte-valued
 65-dimensional vectors, M = 16 (S0 = 32): n just BELOW the limit (the loop runs with offsets up to 2^32 - 128) and n just
 ABOVE it (hipcc's loop with 64-bit addresses takes over); both must equal the oracle bit for bit.
-    python tools/large_n_edge_check.py            (about 45 GB of host memory, a few minutes on the GPU)"""
+    python tests/large_n_edge_check.py            (about 45 GB of host memory, a few minutes on the GPU)"""
 import os
 import sys
 import time
