@@ -523,122 +523,11 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "9:\n\t"
 
 // Runs the layer-0 search to completion.  On entry W holds the start node (unexpanded) and the visited cache knows it.
-__device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, WList<2> &w, const WaveCtx &cx,
-                                                           uint32_t &n_dist, uint32_t &n_hops, uint32_t &status, uint32_t maxhops = 0xFFFFFFFFu) {
-    const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
-    const uint64_t nbrm = (uint64_t)(uintptr_t)iv.nbr0 - 4ull * (uint64_t)iv.S0;   // one row before the table: rows are addressed by id + 1
-    const uint64_t rowm = iv.S0 >= 64 ? ~0ull : ((1ull << iv.S0) - 1ull);
-    const uint32_t rowb = (uint32_t)iv.S0 * 4u, st8 = (uint32_t)iv.stride8;
-    const uint32_t vtb = lds_offset(cx.vt), cand = lds_offset(cx.cand_id);
-    const uint32_t setm = cx.set_mask, setb = (uint32_t)cx.set_bits;
-    const uint32_t q2 = (uint32_t)uniform(cx.q2);
-    uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
-    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt), od = wmax;   // od: the tie list's distance
-    // temporaries
-    uint32_t nb, pnb, vw, va, tag, r4, co, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
-    uint64_t ad0, ad1;    // row addresses, alternating by batch (a load has long read its address when the register's next turn comes)
-    uint64_t um0, um1, g0, fresh, b3m, b2m;   // um0 / um1 double as the insertion's equality masks, fresh as the round's accept mask
-    uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;   // kd doubles as the hop's node (its low key half, id + 1), sx / tmp as the shift's carries
-    asm volatile(
-        // low key halves inside the loop: id + 1 with the expanded flag in bit 31 (a rotation of the (id + 1) << 1 | flag the
-        // rest of the kernel keeps): the unexpanded members are the non-negative ones, a node id is one subtraction away
-        "v_alignbit_b32 %[l0], %[l0], %[l0], 1\n\t"
-        "v_alignbit_b32 %[l1], %[l1], %[l1], 1\n\t"
-        HNSW_HOP_CONSTANTS
-        "s_mov_b32 %[pref], -1\n"
-        HNSW_ASM_ALIGN
-        // ================================ one hop ================================
-        "1:\n\t"
-#ifdef HNSW_ASM_DEBUG
-        "s_cmp_ge_u32 %[nh], %[maxh]\n\t"                                 // debugging: leave after maxh hops, the C++ loop goes on from here
-        "s_cbranch_scc1 99f\n\t"
-#endif
-        HNSW_PROBE(0)
-        // pop: the first unexpanded member of W (pop_min, :565) and its flag; it is nearly always in the lower slot (the
-        // upper one: label 2, behind the loop)
-        "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n\t"
-        "v_cmp_lt_i32_e64 %[um1], -1, %[l1]\n\t"
-        "s_cmp_eq_u64 %[um0], 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_ff1_i32_b64 %[i], %[um0]\n\t"
-        "v_readlane_b32 %[kd], %[l0], %[i]\n\t"
-        "s_bitset0_b64 %[um0], %[i]\n\t"
-        "s_mov_b32 m0, %[i]\n\t"
-        "s_or_b32 %[t], %[kd], 0x80000000\n\t"
-        "v_writelane_b32 %[l0], %[t], m0\n"
-        "3:\n"                                                              // kd = the node's low key half, id + 1
-        HNSW_HOP_ADJACENCY
-        HNSW_HOP_FILTER_ISSUE
-        HNSW_PROBE(1)
-#if HNSW_ASM_PREFETCH
-        // the next nearest unexpanded member of W: its row is fetched now, beside this hop's vectors
-        "s_cmp_eq_u64 %[um0], 0\n\t"
-        "s_cbranch_scc1 7f\n\t"
-        "s_ff1_i32_b64 %[i], %[um0]\n\t"
-        "v_readlane_b32 %[pref], %[l0], %[i]\n"
-        HNSW_HOP_PREFETCH_LOAD
-#endif
-        HNSW_HOP_FILTER_COMPACT
-        HNSW_PROBE(2)
-        HNSW_HOP_ROUND_COMMON
-        "50:\n\t"
-        HNSW_PROBE(3)
-        HNSW_INSERT_LOOP
-        HNSW_PROBE(4)
-        "s_cmp_gt_i32 %[cnt], 0\n\t"
-        "s_cbranch_scc0 1b\n\t"
-        HNSW_HOP_NEXT_ROUND
-        // ---- behind the loop: the ways less often taken
-        "2:\n\t"                                                            // pop from the upper slot
-        "s_cmp_eq_u64 %[um1], 0\n\t"
-        "s_cbranch_scc1 90f\n\t"
-        "s_ff1_i32_b64 %[i], %[um1]\n\t"
-        "v_readlane_b32 %[kd], %[l1], %[i]\n\t"
-        "s_bitset0_b64 %[um1], %[i]\n\t"
-        "s_mov_b32 m0, %[i]\n\t"
-        "s_or_b32 %[t], %[kd], 0x80000000\n\t"
-        "v_writelane_b32 %[l1], %[t], m0\n\t"
-        "s_branch 3b\n"
-#if HNSW_ASM_PREFETCH
-        "7:\n\t"                                                            // the next one is in the upper slot, or there is none
-        "s_mov_b32 %[pref], -1\n\t"
-        "s_cmp_eq_u64 %[um1], 0\n\t"
-        "s_cbranch_scc1 9b\n\t"
-        "s_ff1_i32_b64 %[i], %[um1]\n\t"
-        "v_readlane_b32 %[pref], %[l1], %[i]\n\t"
-        "s_branch 8b\n"
-#endif
-        HNSW_HOP_ADJACENCY_MISS
-        HNSW_HOP_ROUNDS_RARE
-        HNSW_INSERT_RARE
-        // ---- no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568)
-        HNSW_HOP_TAIL
-        // back to the flag-in-bit-0 form
-        "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
-        "\n\tv_alignbit_b32 %[l1], %[l1], %[l1], 31"
-        : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]),
-          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc), [od] "+&s"(od),
-          [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
-          [co] "=&v"(co), [q2v] "=&v"(q2v),
-          [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
-          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
-          [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
-          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1),
-          [um0] "=&s"(um0), [um1] "=&s"(um1), [g0] "=&s"(g0), [fresh] "=&s"(fresh),
-          [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
-          [pref] "=&s"(pref), [cnt] "=&s"(cnt),
-          [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t),
-          [nw] "=&s"(nw), [tmp] "=&s"(tmp)
-        : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
-          [nbrm] "s"(nbrm), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
-          [cand] "s"(cand), [candm4] "s"(cand - 4u), [q2] "s"(q2)
-#ifdef HNSW_ASM_DEBUG
-          , [maxh] "s"(maxhops)
-#endif
-        : "vcc", "scc", "m0", "memory" HNSW_PROBE_CLOBBER);
-    w.wmax = wmax; w.ovf_cnt = od == wmax ? (int)oc : 0;
-    n_dist = nd; n_hops = nh; status = st;
-}
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_asm
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
 
 // =====================================================================================================================
 // The same loop for W in FOUR key registers per lane (ef 129..256) and in ONE (ef <= 64).  Shared with the two-slot
@@ -989,96 +878,11 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm(const IndexView &iv, 
     "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
     "s_branch 141b\n"
 
-__device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv, WList<4> &w, const WaveCtx &cx,
-                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-    const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
-    const uint64_t nbrm = (uint64_t)(uintptr_t)iv.nbr0 - 4ull * (uint64_t)iv.S0;   // one row before the table: rows are addressed by id + 1
-    const uint64_t rowm = iv.S0 >= 64 ? ~0ull : ((1ull << iv.S0) - 1ull);
-    const uint32_t rowb = (uint32_t)iv.S0 * 4u, st8 = (uint32_t)iv.stride8;
-    const uint32_t vtb = lds_offset(cx.vt), cand = lds_offset(cx.cand_id);
-    const uint32_t setm = cx.set_mask, setb = (uint32_t)cx.set_bits;
-    const uint32_t q2 = (uint32_t)uniform(cx.q2);
-    uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
-    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt), od = wmax;   // od: the tie list's distance
-    uint32_t nb, pnb, vw, va, tag, r4, co, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
-    uint64_t ad0, ad1;    // row addresses, alternating by batch (a load has long read its address when the register's next turn comes)
-    uint64_t um0, um1, um2, um3, fresh, b3m, b2m;
-    uint32_t pref, cnt, sx, lastad, i, kd, klo, P, t, nw, tmp, mx0, mx1, mx2;
-    asm volatile(
-        // low key halves inside the loop: id + 1 with the expanded flag in bit 31 (a rotation of the (id + 1) << 1 | flag the
-        // rest of the kernel keeps): the unexpanded members are the non-negative ones, a node id is one subtraction away
-        "v_alignbit_b32 %[l0], %[l0], %[l0], 1\n\t"
-        "v_alignbit_b32 %[l1], %[l1], %[l1], 1\n\t"
-        "v_alignbit_b32 %[l2], %[l2], %[l2], 1\n\t"
-        "v_alignbit_b32 %[l3], %[l3], %[l3], 1\n\t"
-        HNSW_HOP_CONSTANTS
-        "v_readlane_b32 %[mx0], %[h0], 63\n\t"                            // the slots' maxima (distance halves)
-        "v_readlane_b32 %[mx1], %[h1], 63\n\t"
-        "v_readlane_b32 %[mx2], %[h2], 63\n\t"
-        "s_mov_b32 %[pref], -1\n"
-        HNSW_ASM_ALIGN_K(HNSW_ASM_ALIGN_PAD4)
-        // ================================ one hop ================================
-        "1:\n\t"
-        // pop: the first unexpanded member of W (pop_min, :565) and its flag
-        "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n\t"
-        "v_cmp_lt_i32_e64 %[um1], -1, %[l1]\n\t"
-        "v_cmp_lt_i32_e64 %[um2], -1, %[l2]\n\t"
-        "v_cmp_lt_i32_e64 %[um3], -1, %[l3]\n"
-        HNSW_POP_SLOT0("%[um0]", "%[l0]", "61f")
-        "3:\n"                                                          // kd = the node's low key half, id + 1
-        HNSW_HOP_ADJACENCY
-        HNSW_HOP_FILTER_ISSUE
-#if HNSW_ASM_PREFETCH
-        "s_mov_b32 %[pref], -1\n\t"
-        HNSW_PEEK_SLOT0("%[um0]", "%[l0]", "71f")
-        HNSW_HOP_PREFETCH_LOAD
-#endif
-        HNSW_HOP_FILTER_COMPACT
-        HNSW_HOP_ROUND_COMMON
-        "50:\n\t"
-        HNSW_INSERT_LOOP4
-        "s_cmp_gt_i32 %[cnt], 0\n\t"
-        "s_cbranch_scc0 1b\n\t"
-        HNSW_HOP_NEXT_ROUND
-        // ---- behind the loop
-        HNSW_POP_SLOT("61", "%[um1]", "%[l1]", "62f")
-        HNSW_POP_SLOT("62", "%[um2]", "%[l2]", "63f")
-        HNSW_POP_SLOT("63", "%[um3]", "%[l3]", "90f")
-#if HNSW_ASM_PREFETCH
-        HNSW_PEEK_SLOT("71", "%[um1]", "%[l1]", "72f")
-        HNSW_PEEK_SLOT("72", "%[um2]", "%[l2]", "73f")
-        HNSW_PEEK_SLOT("73", "%[um3]", "%[l3]", "9b")
-#endif
-        HNSW_HOP_ADJACENCY_MISS
-        HNSW_HOP_ROUNDS_RARE
-        HNSW_INSERT_RARE4
-        HNSW_HOP_TAIL
-        // back to the flag-in-bit-0 form
-        "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
-        "\n\tv_alignbit_b32 %[l1], %[l1], %[l1], 31"
-        "\n\tv_alignbit_b32 %[l2], %[l2], %[l2], 31"
-        "\n\tv_alignbit_b32 %[l3], %[l3], %[l3], 31"
-        : [h0] "+&v"(w.hi[0]), [h1] "+&v"(w.hi[1]), [h2] "+&v"(w.hi[2]), [h3] "+&v"(w.hi[3]),
-          [l0] "+&v"(w.lo[0]), [l1] "+&v"(w.lo[1]), [l2] "+&v"(w.lo[2]), [l3] "+&v"(w.lo[3]),
-          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc), [od] "+&s"(od),
-          [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
-          [co] "=&v"(co), [q2v] "=&v"(q2v),
-          [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
-          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
-          [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
-          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1),
-          [um0] "=&s"(um0), [um1] "=&s"(um1), [um2] "=&s"(um2), [um3] "=&s"(um3), [fresh] "=&s"(fresh),
-          [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
-          [pref] "=&s"(pref), [cnt] "=&s"(cnt),
-          [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [P] "=&s"(P), [t] "=&s"(t),
-          [nw] "=&s"(nw), [tmp] "=&s"(tmp), [mx0] "=&s"(mx0), [mx1] "=&s"(mx1), [mx2] "=&s"(mx2)
-        : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
-          [nbrm] "s"(nbrm), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
-          [cand] "s"(cand), [candm4] "s"(cand - 4u), [q2] "s"(q2)
-        : "vcc", "scc", "m0", "memory");
-    w.wmax = wmax; w.ovf_cnt = od == wmax ? (int)oc : 0;
-    n_dist = nd; n_hops = nh; status = st;
-}
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
 
 // ---- one slot (ef <= 64): no cascade; the same steps as the two-slot loop's upper slot --------------------------------
 #define HNSW_INSERT_LOOP1                                                                                                   \
@@ -1151,72 +955,11 @@ __device__ __forceinline__ void search_layer0_bytes_l2_asm4(const IndexView &iv,
     "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
     "s_branch 12b\n"
 
-__device__ __forceinline__ void search_layer0_bytes_l2_asm1(const IndexView &iv, WList<1> &w, const WaveCtx &cx,
-                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-    const uint64_t xl = (uint64_t)(uintptr_t)iv.X8 + 4u * (uint32_t)cx.l16;
-    const uint64_t nbrm = (uint64_t)(uintptr_t)iv.nbr0 - 4ull * (uint64_t)iv.S0;   // one row before the table: rows are addressed by id + 1
-    const uint64_t rowm = iv.S0 >= 64 ? ~0ull : ((1ull << iv.S0) - 1ull);
-    const uint32_t rowb = (uint32_t)iv.S0 * 4u, st8 = (uint32_t)iv.stride8;
-    const uint32_t vtb = lds_offset(cx.vt), cand = lds_offset(cx.cand_id);
-    const uint32_t setm = cx.set_mask, setb = (uint32_t)cx.set_bits;
-    const uint32_t q2 = (uint32_t)uniform(cx.q2);
-    uint32_t wmax = (uint32_t)uniform((int)w.wmax), nd = (uint32_t)uniform((int)n_dist), nh = (uint32_t)uniform((int)n_hops);
-    uint32_t st = (uint32_t)uniform((int)status), oc = (uint32_t)uniform(w.ovf_cnt), od = wmax;   // od: the tie list's distance
-    uint32_t nb, pnb, vw, va, tag, r4, co, q2v, id0, id1, id2, id3, d0, d1, d2, d3, d4, d5, d6, d7, ta, tb, ckey, cid, t0, t1;
-    uint64_t ad0, ad1;    // row addresses, alternating by batch (a load has long read its address when the register's next turn comes)
-    uint64_t um0, um1, fresh, b3m, b2m;    // um1: the visited filter's second compare only
-    uint32_t pref, cnt, sx, lastad, i, kd, klo, p, t, nw, tmp;
-    asm volatile(
-        // low key halves inside the loop: id + 1 with the expanded flag in bit 31 (a rotation of the (id + 1) << 1 | flag the
-        // rest of the kernel keeps): the unexpanded members are the non-negative ones, a node id is one subtraction away
-        "v_alignbit_b32 %[l0], %[l0], %[l0], 1\n\t"
-        HNSW_HOP_CONSTANTS
-        "s_mov_b32 %[pref], -1\n"
-        HNSW_ASM_ALIGN_K(HNSW_ASM_ALIGN_PAD1)
-        "1:\n\t"
-        "v_cmp_lt_i32_e64 %[um0], -1, %[l0]\n"
-        HNSW_POP_SLOT0("%[um0]", "%[l0]", "90f")
-        "3:\n"                                                          // kd = the node's low key half, id + 1
-        HNSW_HOP_ADJACENCY
-        HNSW_HOP_FILTER_ISSUE
-#if HNSW_ASM_PREFETCH
-        "s_mov_b32 %[pref], -1\n\t"
-        HNSW_PEEK_SLOT0("%[um0]", "%[l0]", "9f")
-        HNSW_HOP_PREFETCH_LOAD
-#endif
-        HNSW_HOP_FILTER_COMPACT
-        HNSW_HOP_ROUND_COMMON
-        "50:\n\t"
-        HNSW_INSERT_LOOP1
-        "s_cmp_gt_i32 %[cnt], 0\n\t"
-        "s_cbranch_scc0 1b\n\t"
-        HNSW_HOP_NEXT_ROUND
-        HNSW_HOP_ADJACENCY_MISS
-        HNSW_HOP_ROUNDS_RARE
-        HNSW_INSERT_RARE1
-        HNSW_HOP_TAIL
-        // back to the flag-in-bit-0 form
-        "\n\tv_alignbit_b32 %[l0], %[l0], %[l0], 31"
-        : [h0] "+&v"(w.hi[0]), [l0] "+&v"(w.lo[0]),
-          [wmax] "+&s"(wmax), [nd] "+&s"(nd), [nh] "+&s"(nh), [st] "+&s"(st), [oc] "+&s"(oc), [od] "+&s"(od),
-          [nb] "=&v"(nb), [pnb] "=&v"(pnb), [vw] "=&v"(vw), [va] "=&v"(va), [tag] "=&v"(tag), [r4] "=&v"(r4),
-          [co] "=&v"(co), [q2v] "=&v"(q2v),
-          [id0] "=&v"(id0), [id1] "=&v"(id1), [id2] "=&v"(id2), [id3] "=&v"(id3),
-          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7),
-          [ta] "=&v"(ta), [tb] "=&v"(tb), [ckey] "=&v"(ckey), [cid] "=&v"(cid), [t0] "=&v"(t0), [t1] "=&v"(t1),
-          [ad0] "=&v"(ad0), [ad1] "=&v"(ad1),
-          [um0] "=&s"(um0), [um1] "=&s"(um1), [fresh] "=&s"(fresh),
-          [b3m] "=&s"(b3m), [b2m] "=&s"(b2m),
-          [pref] "=&s"(pref), [cnt] "=&s"(cnt),
-          [sx] "=&s"(sx), [lastad] "=&s"(lastad), [i] "=&s"(i), [kd] "=&s"(kd), [klo] "=&s"(klo), [p] "=&s"(p), [t] "=&s"(t),
-          [nw] "=&s"(nw), [tmp] "=&s"(tmp)
-        : [qb0] "v"(cx.qb[0]), [qb1] "v"(cx.qb[1]), [xl] "v"(xl), [lane] "v"(cx.lane),
-          [nbrm] "s"(nbrm), [rowm] "s"(rowm), [rowb] "s"(rowb), [st8] "s"(st8), [vtb] "s"(vtb), [setm] "s"(setm), [setb] "s"(setb),
-          [cand] "s"(cand), [candm4] "s"(cand - 4u), [q2] "s"(q2)
-        : "vcc", "scc", "m0", "memory");
-    w.wmax = wmax; w.ovf_cnt = od == wmax ? (int)oc : 0;
-    n_dist = nd; n_hops = nh; status = st;
-}
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
 
 
 // =====================================================================================================================
