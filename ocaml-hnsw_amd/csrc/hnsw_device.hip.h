@@ -1055,6 +1055,16 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         }
     }
 #endif
+#if HNSW_ASM_LOOP && HNSW_ASM_LOOP_F32 && !defined(HNSW_PHASE_TIMING)
+    if constexpr (NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4) && SEM == 0 && (ROWS == 0 || ROWS == 1)) {
+        // float32 rows of 65..128 dimensions (17..32 chunks), either metric, the Ohnsw rule, ef <= 256: the same hand-scheduled
+        // loop with the float round (hnsw_hop_asm.hip.h); same preconditions as above
+        if (layer == 0 && cx.ovf.g == nullptr && iv.nchunks > 16 && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30)) {
+            search_layer0_f32_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status);
+            return;
+        }
+    }
+#endif
     int pref_id = -1, pref_nb = -1;
     PhaseClock pc;
 #ifdef HNSW_PHASE_TIMING

@@ -24,6 +24,9 @@ namespace hnsw_dev {
 #ifndef HNSW_ASM_LOOP
 #define HNSW_ASM_LOOP 1
 #endif
+#ifndef HNSW_ASM_LOOP_F32       /* the float32-row instantiations (0: those shapes keep search_layer's C++ loop) */
+#define HNSW_ASM_LOOP_F32 1
+#endif
 // measurement builds (-DHNSW_ASM_PHASE=k, tools/asm_phases.sh): shader-clock cycles spent between probe point k and k + 1 of
 // every hop, summed into the n_dist counter.  Points: 0 hop start, 1 adjacency row in registers, 2 fresh list written,
 // 3 round evaluated and accept mask known, 4 insertions done.  s[90:93] are used by name (declared clobbered).
@@ -479,36 +482,39 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_waitcnt vmcnt(0)"  /* a speculative row fetch may still be in flight */  
 
 // per-lane constants of the hop: the candidate a lane's sum belongs to in a round of 1 / 2 / 4 batches (bytes 0 / 1 / 2 of co; 0xff
-// on the lanes that hold no candidate's sum), the lane-bit masks of the transposing reduction (d0..d2 are scratch here)
-#define HNSW_HOP_CONSTANTS \
+// on the lanes that hold no candidate's sum), the lane-bit masks of the transposing reduction (D0..D2 are scratch here;
+// Q2V: the byte rows' q.q accumulator start, while vcc still marks lane 0 of every 16)
+#define HNSW_HOP_CONSTANTS_X(D0, D1, D2, Q2V) \
         "v_lshrrev_b32_e32 %[r4], 4, %[lane]\n\t"  /* r */                                             \
         "v_bfe_u32 %[t0], %[lane], 3, 1\n\t"                                                           \
-        "v_lshl_add_u32 %[d1], %[r4], 1, %[t0]\n\t"  /* NB 2: 2 r + bit 3 of the lane */               \
+        "v_lshl_add_u32 " D1 ", %[r4], 1, %[t0]\n\t"  /* NB 2: 2 r + bit 3 of the lane */               \
         "v_bfe_u32 %[t0], %[lane], 2, 2\n\t"                                                           \
-        "v_lshl_add_u32 %[d2], %[r4], 2, %[t0]\n\t"  /* NB 4: 4 r + bits 3:2 */                        \
-        "v_mov_b32_e32 %[d0], %[r4]\n\t"  /* NB 1: candidate r */                                      \
+        "v_lshl_add_u32 " D2 ", %[r4], 2, %[t0]\n\t"  /* NB 4: 4 r + bits 3:2 */                        \
+        "v_mov_b32_e32 " D0 ", %[r4]\n\t"  /* NB 1: candidate r */                                      \
         "v_mov_b32_e32 %[t1], 0xff\n\t"  /* lanes that hold no candidate's sum: never below cnt */     \
         "v_and_b32_e32 %[t0], 15, %[lane]\n\t"                                                         \
         "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
         "s_nop 1\n\t"  /* gfx950: a vector write of vcc, then 2 wait states before a vector read */    \
-        "v_cndmask_b32_e32 %[d0], %[t1], %[d0], vcc\n\t"                                               \
-        "v_mov_b32_e32 %[q2v], %[q2]\n\t"  /* q.q, once per 16 lanes: the accumulator x.x starts from */ \
-        "v_cndmask_b32_e32 %[q2v], 0, %[q2v], vcc\n\t"                                                 \
+        "v_cndmask_b32_e32 " D0 ", %[t1], " D0 ", vcc\n\t"                                               \
+        Q2V                                                                                            \
         "v_and_b32_e32 %[t0], 7, %[lane]\n\t"                                                          \
         "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
         "s_nop 1\n\t"                                                                                  \
-        "v_cndmask_b32_e32 %[d1], %[t1], %[d1], vcc\n\t"                                               \
+        "v_cndmask_b32_e32 " D1 ", %[t1], " D1 ", vcc\n\t"                                               \
         "v_and_b32_e32 %[t0], 3, %[lane]\n\t"                                                          \
         "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"                                                           \
         "s_nop 1\n\t"                                                                                  \
-        "v_cndmask_b32_e32 %[d2], %[t1], %[d2], vcc\n\t"                                               \
-        "v_lshl_or_b32 %[co], %[d1], 8, %[d0]\n\t"  /* one byte per round shape */                       \
-        "v_lshl_or_b32 %[co], %[d2], 16, %[co]\n\t"                                                      \
+        "v_cndmask_b32_e32 " D2 ", %[t1], " D2 ", vcc\n\t"                                               \
+        "v_lshl_or_b32 %[co], " D1 ", 8, " D0 "\n\t"  /* one byte per round shape */                       \
+        "v_lshl_or_b32 %[co], " D2 ", 16, %[co]\n\t"                                                      \
         "v_lshlrev_b32_e32 %[r4], 2, %[r4]\n\t"  /* 4 r: byte offset of candidate r in the id list */  \
         "v_and_b32_e32 %[t0], 8, %[lane]\n\t"                                                          \
         "v_cmp_ne_u32_e64 %[b3m], 0, %[t0]\n\t"                                                        \
         "v_and_b32_e32 %[t0], 4, %[lane]\n\t"                                                          \
         "v_cmp_ne_u32_e64 %[b2m], 0, %[t0]\n\t"                                                        
+#define HNSW_HOP_CONSTANTS HNSW_HOP_CONSTANTS_X("%[d0]", "%[d1]", "%[d2]",                                                  \
+        "v_mov_b32_e32 %[q2v], %[q2]\n\t"  /* q.q, once per 16 lanes: the accumulator x.x starts from */                   \
+        "v_cndmask_b32_e32 %[q2v], 0, %[q2v], vcc\n\t")
 
 // labels 8 / 9: pref holds the low key half of the next nearest unexpanded member of W: its node, and its adjacency row
 // requested into pnb beside this hop's vectors
@@ -960,6 +966,246 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_ROWS 2
 #define HNSW_LOOP_METRIC 0
 #include "hnsw_hop_loop.inc"
+
+// =====================================================================================================================
+// The same loops over FLOAT32 rows of 65..128 dimensions (two float4 chunks per lane of a 16-lane group): the shape data
+// that is not byte-valued takes (C2's general format, C3, C5).  Pop, adjacency, visited filter, compaction and insertion
+// are the text above; the round differs: two global_load_dwordx4 per row and lane, the distance in hop_round's operation
+// order -- per lane x, y, z, w of chunk 0, then of chunk 1 (v_sub_f32 + v_fmac_f32 for L2, v_fmac_f32 for the inner
+// product), then the 16 lanes of the group summed pairwise at lane distance 8, 4, 2, 1 (reduce16) -- so every key is the
+// one hop_round computes, bit for bit.  Float sums depend on their order, so the transposing reduction of the integer
+// rounds (which pairs lanes by mirroring) is not available as it is: here a lane distance d always pairs lane l with
+// lane l ^ d -- row_ror:8 for 8, TWO bank-masked v_add_f32_dpp for 4 (row_ror:4 into the lanes with bit 2 set, row_ror:12
+// into the others: neither crosses into the other half of the row, which belongs to another candidate by then),
+// quad_perm for 2 and 1 -- and the round's candidates are still folded into one register on the way (keep / give selects
+// by lane bit 3, then bit 2), which leaves the keys exactly where the integer rounds leave them: the accept mask, the
+// ids and the insertion do not know the difference.
+// The 32 row registers are addressed BY NAME (v[HNSW_F32_BASE] ..: inline assembly cannot name a component of a 128-bit
+// operand) and declared clobbered; chunk c, component k of batch b is HNSW_FX(b, c, k).
+// Ragged rows (d not a multiple of 4 x 16 lanes: 17..31 chunks): the lanes whose second chunk lies past the row end are
+// switched off (EXEC = cvm) around that chunk's load and arithmetic, which is hop_round's "the chunk's contribution is
+// dropped whole".
+// =====================================================================================================================
+#define HNSW_F32_BASE 40
+#define HNSW_F32_CLOBBER , "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", \
+                           "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71"
+#define HNSW_FX(B, C, K) "v[" HNSW_STR(HNSW_F32_BASE) "+" #B "*8+" #C "*4+" #K "]"
+#define HNSW_FX4(B, C) "v[" HNSW_STR(HNSW_F32_BASE) "+" #B "*8+" #C "*4:" HNSW_STR(HNSW_F32_BASE) "+" #B "*8+" #C "*4+3]"
+#define HNSW_F32_CONSTANTS HNSW_HOP_CONSTANTS_X(HNSW_FX(0, 0, 0), HNSW_FX(0, 0, 1), HNSW_FX(0, 0, 2), "")
+// row address (one 64-bit multiply-add) and the row's two float4 per lane
+#define HNSW_F32_ROW_LOAD(ID, AD, B)                                                     \
+    "v_mad_u64_u32 " AD ", vcc, " ID ", %[st8], %[xl]\n\t"                               \
+    "global_load_dwordx4 " HNSW_FX4(B, 0) ", " AD ", off\n\t"                            \
+    HNSW_F32_RAG_ON                                                                      \
+    "global_load_dwordx4 " HNSW_FX4(B, 1) ", " AD ", off offset:256\n\t"                 \
+    HNSW_F32_RAG_OFF
+// the lane's share of batch B's distance -> HNSW_FX(B, 0, 0)
+#define HNSW_F32_SUB(B, C, K, Q) "v_sub_f32_e32 " HNSW_FX(B, C, K) ", " HNSW_FX(B, C, K) ", " Q "\n\t"
+#define HNSW_F32_SQ(B, C, K) "v_fmac_f32_e32 " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, C, K) ", " HNSW_FX(B, C, K) "\n\t"
+#define HNSW_F32_DIST_L2(B)                                                              \
+    HNSW_F32_SUB(B, 0, 0, "%[qf0]") HNSW_F32_SUB(B, 0, 1, "%[qf1]") HNSW_F32_SUB(B, 0, 2, "%[qf2]") HNSW_F32_SUB(B, 0, 3, "%[qf3]") \
+    "v_mul_f32_e32 " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, 0, 0) "\n\t" /* fma(dx, dx, +0): a square is never -0 */ \
+    HNSW_F32_SQ(B, 0, 1) HNSW_F32_SQ(B, 0, 2) HNSW_F32_SQ(B, 0, 3)                       \
+    HNSW_F32_RAG_ON                                                                      \
+    HNSW_F32_SUB(B, 1, 0, "%[qf4]") HNSW_F32_SUB(B, 1, 1, "%[qf5]") HNSW_F32_SUB(B, 1, 2, "%[qf6]") HNSW_F32_SUB(B, 1, 3, "%[qf7]") \
+    HNSW_F32_SQ(B, 1, 0) HNSW_F32_SQ(B, 1, 1) HNSW_F32_SQ(B, 1, 2) HNSW_F32_SQ(B, 1, 3)  \
+    HNSW_F32_RAG_OFF
+#define HNSW_F32_MAC(B, C, K, Q) "v_fmac_f32_e32 " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, C, K) ", " Q "\n\t"
+#define HNSW_F32_DIST_IP(B)                                                              \
+    "v_fma_f32 " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, 0, 0) ", %[qf0], 0\n\t"  /* (a product may be -0: the sum starts from +0) */ \
+    HNSW_F32_MAC(B, 0, 1, "%[qf1]") HNSW_F32_MAC(B, 0, 2, "%[qf2]") HNSW_F32_MAC(B, 0, 3, "%[qf3]") \
+    HNSW_F32_RAG_ON                                                                      \
+    HNSW_F32_MAC(B, 1, 0, "%[qf4]") HNSW_F32_MAC(B, 1, 1, "%[qf5]") HNSW_F32_MAC(B, 1, 2, "%[qf6]") HNSW_F32_MAC(B, 1, 3, "%[qf7]") \
+    HNSW_F32_RAG_OFF
+// lane l <- KEEP[l] + GIVE[l ^ 4] (DST may be KEEP; TMP is scratch).  Both rotations are computed for every lane and the lane's
+// bit 2 picks: merging them under bank masks instead would make the second instruction read what the first has just written
+// (gfx950 wants two wait states in front of ANY register a DPP instruction reads)
+#define HNSW_F32_XOR4(DST, GIVE, KEEP, TMP)                                              \
+    "v_add_f32_dpp " TMP ", " GIVE ", " KEEP " row_ror:12" HNSW_DPP_ALL "\n\t"  /* l <- l + 4: the lanes with bit 2 clear */ \
+    "v_add_f32_dpp " DST ", " GIVE ", " KEEP " row_ror:4" HNSW_DPP_ALL "\n\t"   /* l <- l - 4: the lanes with bit 2 set */   \
+    "v_cndmask_b32_e64 " DST ", " TMP ", " DST ", %[b2m]\n\t"
+#define HNSW_ACCEPT_EARLY_A "v_add_u32_e32 %[cid], 1, %[cid]\n\t"           /* HNSW_ACCEPT_EARLY's two halves */
+#define HNSW_ACCEPT_EARLY_B(SHAPE) "v_cmp_gt_u32_sdwa vcc, %[cnt], %[co] src0_sel:DWORD src1_sel:BYTE_" #SHAPE "\n\t"
+// the group's sum -> key (dist_to_key): L2 the sum's bits (HNSW_F32_SUM is %[ckey] itself); inner product 1 - sum, sign-flipped
+#define HNSW_F32_KEY_IP                                                                  \
+    "v_sub_f32_e32 %[t1], 1.0, %[t1]\n\t"                                                \
+    "v_ashrrev_i32_e32 %[t0], 31, %[t1]\n\t"                                             \
+    "v_or_b32_e32 %[t0], 0x80000000, %[t0]\n\t"                                          \
+    "v_xor_b32_e32 %[ckey], %[t1], %[t0]\n\t"
+
+#define HNSW_F32_ROUND_COMMON \
+        "20:\n\t"                                                                                                                     \
+        "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
+        "s_cbranch_scc1 40f\n\t"                                                                                                      \
+        "s_cmp_lt_u32 %[cnt], 5\n\t"                                                                                                  \
+        "s_cbranch_scc1 25f\n\t"                                                                                                      \
+  /* ---- 8 rows: two batches */                                                                                                      \
+        "30:\n\t"                                                                                                                     \
+        HNSW_ID_READ0("%[id0]", 1)                                                                                                    \
+        HNSW_ID_READN("%[id1]")                                                                                                       \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id0]", "%[ad0]", 0)                                                                                      \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id1]", "%[ad1]", 1)                                                                                      \
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"                                                                        \
+        "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
+        HNSW_F32_DIST(0)                                                                                                              \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_F32_DIST(1)                                                                                                              \
+        "v_cndmask_b32_e64 %[ta], " HNSW_FX(0, 0, 0) ", " HNSW_FX(1, 0, 0) ", %[b3m]\n\t"  /* keep: the sum this half of the group is for */ \
+        "v_cndmask_b32_e64 %[tb], " HNSW_FX(1, 0, 0) ", " HNSW_FX(0, 0, 0) ", %[b3m]\n\t"  /* give: the other half's */                      \
+        HNSW_ACCEPT_EARLY(1)                                                                                                          \
+        "v_add_f32_dpp %[ta], %[tb], %[ta] row_ror:8" HNSW_DPP_ALL "\n\t"                                                             \
+        "s_nop 1\n\t"                                                                                                                 \
+        HNSW_F32_XOR4("%[tb]", "%[ta]", "%[ta]", HNSW_FX(0, 0, 1))                                                                    \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_f32_dpp %[tb], %[tb], %[tb] quad_perm:[2,3,0,1]" HNSW_DPP_ALL "\n\t"                                                   \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_f32_dpp " HNSW_F32_SUM ", %[tb], %[tb] quad_perm:[1,0,3,2]" HNSW_DPP_ALL "\n\t"                                        \
+        HNSW_F32_KEY                                                                                                                  \
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 8\n"
+
+#define HNSW_F32_ROUNDS_RARE \
+        "25:\n\t"                                                                                                                     \
+  /* ---- 4 rows: one batch */                                                                                                        \
+        HNSW_ID_READ0("%[id0]", 0)                                                                                                    \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id0]", "%[ad0]", 0)                                                                                      \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_F32_DIST(0)                                                                                                              \
+        "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
+        HNSW_ACCEPT_EARLY(0)                                                                                                          \
+        "v_add_f32_dpp %[ta], " HNSW_FX(0, 0, 0) ", " HNSW_FX(0, 0, 0) " row_ror:8" HNSW_DPP_ALL "\n\t"                               \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_f32_dpp %[ta], %[ta], %[ta] row_ror:4" HNSW_DPP_ALL "\n\t"                                                             \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_f32_dpp %[ta], %[ta], %[ta] row_ror:2" HNSW_DPP_ALL "\n\t"                                                             \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_f32_dpp " HNSW_F32_SUM ", %[ta], %[ta] row_ror:1" HNSW_DPP_ALL "\n\t"                                                  \
+        HNSW_F32_KEY                                                                                                                  \
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 4\n\t"                                                                                             \
+        "s_branch 50b\n"                                                                                                              \
+  /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
+        "40:\n\t"                                                                                                                     \
+        HNSW_ID_READ0("%[id0]", 2)                                                                                                    \
+        HNSW_ID_READN("%[id1]")                                                                                                       \
+        HNSW_ID_READN("%[id2]")                                                                                                       \
+        HNSW_ID_READN("%[id3]")                                                                                                       \
+        "s_waitcnt lgkmcnt(3)\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id0]", "%[ad0]", 0)                                                                                      \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id1]", "%[ad1]", 1)                                                                                      \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id2]", "%[ad0]", 2)                                                                                      \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id3]", "%[ad1]", 3)                                                                                      \
+        "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"                                                                        \
+        "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"                                                                        \
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"                                                                        \
+        "s_waitcnt vmcnt(6)\n\t"                                                                                                      \
+        HNSW_F32_DIST(0)                                                                                                              \
+        "s_waitcnt vmcnt(4)\n\t"                                                                                                      \
+        HNSW_F32_DIST(1)                                                                                                              \
+        "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
+        HNSW_F32_DIST(2)                                                                                                              \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_F32_DIST(3)                                                                                                              \
+  /* sums of candidates 0..3 of the group in batch registers 0..3 -> quads of the group's 16 lanes (scratch: two row registers) */  \
+        "v_cndmask_b32_e64 %[ta], " HNSW_FX(0, 0, 0) ", " HNSW_FX(2, 0, 0) ", %[b3m]\n\t"  /* keep 0 | 2 */                            \
+        "v_cndmask_b32_e64 " HNSW_FX(0, 0, 1) ", " HNSW_FX(2, 0, 0) ", " HNSW_FX(0, 0, 0) ", %[b3m]\n\t"  /* give */                   \
+        "v_cndmask_b32_e64 %[tb], " HNSW_FX(1, 0, 0) ", " HNSW_FX(3, 0, 0) ", %[b3m]\n\t"  /* keep 1 | 3 */                            \
+        "v_cndmask_b32_e64 " HNSW_FX(1, 0, 1) ", " HNSW_FX(3, 0, 0) ", " HNSW_FX(1, 0, 0) ", %[b3m]\n\t"  /* give */                   \
+        HNSW_ACCEPT_EARLY_A                                                                                                           \
+        "v_add_f32_dpp %[ta], " HNSW_FX(0, 0, 1) ", %[ta] row_ror:8" HNSW_DPP_ALL "\n\t"                                              \
+        "v_add_f32_dpp %[tb], " HNSW_FX(1, 0, 1) ", %[tb] row_ror:8" HNSW_DPP_ALL "\n\t"                                              \
+        "v_cndmask_b32_e64 " HNSW_FX(0, 0, 1) ", %[ta], %[tb], %[b2m]\n\t"  /* keep */                                                \
+        "v_cndmask_b32_e64 " HNSW_FX(1, 0, 1) ", %[tb], %[ta], %[b2m]\n\t"  /* give */                                                \
+        HNSW_ACCEPT_EARLY_B(2)                                                                                                        \
+        "s_nop 0\n\t"                                                                                                                 \
+        HNSW_F32_XOR4(HNSW_FX(0, 0, 1), HNSW_FX(1, 0, 1), HNSW_FX(0, 0, 1), "%[ta]")                                                  \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_f32_dpp %[ta], " HNSW_FX(0, 0, 1) ", " HNSW_FX(0, 0, 1) " quad_perm:[2,3,0,1]" HNSW_DPP_ALL "\n\t"                     \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_f32_dpp " HNSW_F32_SUM ", %[ta], %[ta] quad_perm:[1,0,3,2]" HNSW_DPP_ALL "\n\t"                                        \
+        HNSW_F32_KEY                                                                                                                  \
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 16\n\t"                                                                                            \
+        "s_branch 50b\n"
+
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+
+// the instantiation for a kernel variant's (slots, metric, row shape)
+template <int NSLOT, int METRIC, int ROWS>
+__device__ __forceinline__ void search_layer0_f32_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[2],
+                                                      uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
+    HNSW_F32_CALL(1, 0, 1, search_layer0_f32_l2_full_asm1)   HNSW_F32_CALL(2, 0, 1, search_layer0_f32_l2_full_asm2)   HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_asm4)
+    HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_asm4)
+    HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_asm4)
+    HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_asm4)
+#undef HNSW_F32_CALL
+}
 
 
 // =====================================================================================================================

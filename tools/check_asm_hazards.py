@@ -300,7 +300,10 @@ def check(body, report_limit=50):
 
 def default_objects():
     b = os.path.join(ROOT, "ocaml-hnsw_amd", "build")
-    return [os.path.join(b, f) for f in ("hnsw_search_variants_0_0_2.o", "hnsw_search_variants_0_0_1.o", "hnsw_order.hip.o")]
+    # the translation units with hand-scheduled code: byte rows (0_0_2), float32 rows L2 full / ragged (0_0_1, 0_0_0) and
+    # inner product full / ragged (1_0_1, 1_0_0), the descent pre-pass
+    return [os.path.join(b, f) for f in ("hnsw_search_variants_0_0_2.o", "hnsw_search_variants_0_0_1.o", "hnsw_search_variants_0_0_0.o",
+                                         "hnsw_search_variants_1_0_1.o", "hnsw_search_variants_1_0_0.o", "hnsw_order.hip.o")]
 
 
 def main(argv):
