@@ -949,12 +949,41 @@ struct PhaseClock {};
 #define HNSW_PHASE(pc, i) do { } while (0)
 #endif
 
+// the accepted candidates of one round (`pass`: lanes of ckey / cid), in row order (= ascending lane), each against the CURRENT W
+template <int NSLOT, int SEM>
+__device__ __forceinline__ void accept_candidates(WList<NSLOT> &w, const WaveCtx &cx, uint64_t pass, uint32_t ckey, uint32_t cid,
+                                                  uint32_t &status, PhaseClock &pc) {
+    const int lane = cx.lane;
+    while (pass) {
+        const int i = __builtin_ctzll(pass);
+        pass &= pass - 1;
+        const uint32_t kd = rdlane(ckey, i);
+        if (kd < w.wmax) {
+#ifdef HNSW_PHASE_TIMING
+            pc.n_ins++;
+#endif
+            wlist_insert<NSLOT, SEM>(w, kd, rdlane(cid, i), lane, cx.ovf, status);     // :575-577
+        } else if (SEM && kd == w.wmax && wlist_full(w)) {
+            // Nearest.insert_distance on a tie with max(W): Inserted, W unchanged (lib/hnsw.ml:501-504):
+            // the node joins C only.  It may be a node the visited cache forgot: still in W, or listed.
+            const uint32_t kid = rdlane(cid, i);
+            const uint32_t klo1 = ((kid + 1u) << 1) | 1u;
+            bool known = false;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) known = known || (ballot(w.hi[s] == kd && (w.lo[s] | 1u) == klo1) != 0ull);
+            if (!known && w.ovf_cnt > 0) { __syncthreads(); known = tie_contains(cx.ovf, w.ovf_cnt, kid, lane); }
+            if (!known) tie_add(w, cx.ovf, kid, lane, status);
+        }
+    }
+}
+
+// The rounds of one hop from candidate `base0` of the hop's list on.
 template <int NCH, int RB, int NSLOT, int METRIC, int SEM, int ROWS>
 __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)[NCH], WList<NSLOT> &w,
                                          const WaveCtx &cx, int cnt, uint32_t &status, PhaseClock &pc,
-                                         const char *tail_row = nullptr) {
+                                         const char *tail_row = nullptr, int base0 = 0) {
     const int lane = cx.lane;
-    for (int base = 0; base < cnt;) {
+    for (int base = base0; base < cnt;) {
         uint32_t ckey, cid;
         base += eval_round<NCH, RB, METRIC, ROWS>(iv, qv, cx, base, cnt, ckey, cid, tail_row);
         uint64_t pass = ballot(SEM ? ckey <= w.wmax : ckey < w.wmax);
@@ -978,29 +1007,14 @@ __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)
             continue;
         }
 #endif
-        while (pass) {
-            const int i = __builtin_ctzll(pass);
-            pass &= pass - 1;
-            const uint32_t kd = rdlane(ckey, i);
-            if (kd < w.wmax) {
-#ifdef HNSW_PHASE_TIMING
-                pc.n_ins++;
-#endif
-                wlist_insert<NSLOT, SEM>(w, kd, rdlane(cid, i), lane, cx.ovf, status);     // :575-577
-            } else if (SEM && kd == w.wmax && wlist_full(w)) {
-                // Nearest.insert_distance on a tie with max(W): Inserted, W unchanged (lib/hnsw.ml:501-504):
-                // the node joins C only.  It may be a node the visited cache forgot: still in W, or listed.
-                const uint32_t kid = rdlane(cid, i);
-                const uint32_t klo1 = ((kid + 1u) << 1) | 1u;
-                bool known = false;
-#pragma unroll
-                for (int s = 0; s < NSLOT; ++s) known = known || (ballot(w.hi[s] == kd && (w.lo[s] | 1u) == klo1) != 0ull);
-                if (!known && w.ovf_cnt > 0) { __syncthreads(); known = tie_contains(cx.ovf, w.ovf_cnt, kid, lane); }
-                if (!known) tie_add(w, cx.ovf, kid, lane, status);
-            }
-        }
+        accept_candidates<NSLOT, SEM>(w, cx, pass, ckey, cid, status, pc);
     }
 }
+
+// What a hand-scheduled loop instantiated for the functor rule (hnsw_hop_loop.inc, HNSW_LOOP_SEM 1) hands back when it leaves a
+// hop in the middle: the candidates of the current round not yet dealt with (`pass`: lanes of ckey / cid1 = id + 1), and how
+// many of the hop's `total` fresh neighbours have not been evaluated yet.
+struct HopResume { uint64_t pass; uint32_t ckey, cid1; int total, remaining; };
 
 } // namespace hnsw_dev
 #include "hnsw_hop_asm.hip.h"
@@ -1030,14 +1044,22 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     const int lane = cx.lane;
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
 #if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING)
-    if constexpr (NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4) && METRIC == 0 && SEM == 0 && ROWS == 2) {
-        // the headline shape (d <= 128 byte rows, byte query, L2, Ohnsw rule; ef <= 64 / 65..128 / 129..256): hand-scheduled
-        // loop, same results
-        // (the block forms the byte offset (id + 1) * S0 * 4 + lane * 4 of a row in 32 bits, one row ahead of the node it
-        // fetches: the row AFTER the last node's must still be below 2^32 bytes whatever S0 is; and it restores EXEC with
-        // s_mov_b64 exec, -1: it is entered with all 64 lanes on -- the kernel runs one full wave per query and reaches this
-        // point through wave-uniform branches only)
-        if (layer == 0 && cx.qint && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30)) {
+    // The hand-scheduled loops (hnsw_hop_asm.hip.h), same results.  ASM_B8: the headline shape (d <= 128 byte rows, byte query,
+    // L2; ef <= 64 / 65..128 / 129..256); ASM_F32: float32 rows of 65..128 dimensions (17..32 chunks), either metric.
+    // (The blocks form the byte offset (id + 1) * S0 * 4 + lane * 4 of an adjacency row in 32 bits, one row ahead of the node
+    // they fetch: the row AFTER the last node's must still be below 2^32 bytes whatever S0 is; and they restore EXEC with
+    // s_mov_b64 exec, -1: they are entered with all 64 lanes on -- the kernel runs one full wave per query and reaches this
+    // point through wave-uniform branches only.  A query whose tie list went to the global slab keeps the C++ loop.)
+    constexpr bool ASM_SLOTS = NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4);
+    constexpr bool ASM_B8 = ASM_SLOTS && METRIC == 0 && ROWS == 2;
+    constexpr bool ASM_F32 = HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1);
+    bool asm_ok = false;
+    if constexpr (ASM_B8 || ASM_F32) {
+        asm_ok = layer == 0 && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30) &&
+                 (ASM_B8 ? cx.qint != 0 : iv.nchunks > 16);
+    }
+    if constexpr (ASM_B8 && SEM == 0) {
+        if (asm_ok) {
             if constexpr (NSLOT == 1) { search_layer0_bytes_l2_asm1(iv, w, cx, n_dist, n_hops, status); return; }
             if constexpr (NSLOT == 4) { search_layer0_bytes_l2_asm4(iv, w, cx, n_dist, n_hops, status); return; }
             if constexpr (NSLOT == 2) {
@@ -1054,12 +1076,8 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             }
         }
     }
-#endif
-#if HNSW_ASM_LOOP && HNSW_ASM_LOOP_F32 && !defined(HNSW_PHASE_TIMING)
-    if constexpr (NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4) && SEM == 0 && (ROWS == 0 || ROWS == 1)) {
-        // float32 rows of 65..128 dimensions (17..32 chunks), either metric, the Ohnsw rule, ef <= 256: the same hand-scheduled
-        // loop with the float round (hnsw_hop_asm.hip.h); same preconditions as above
-        if (layer == 0 && cx.ovf.g == nullptr && iv.nchunks > 16 && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30)) {
+    if constexpr (ASM_F32 && SEM == 0) {
+        if (asm_ok) {
             search_layer0_f32_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status);
             return;
         }
@@ -1071,6 +1089,33 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     pc.mark = clock64();
 #endif
     for (;;) {
+#if HNSW_ASM_LOOP && HNSW_ASM_LOOP_SEM1 && !defined(HNSW_PHASE_TIMING)
+        if constexpr ((ASM_B8 || ASM_F32) && SEM != 0) {
+            // The functor rule on the same hand-scheduled loops: while the tie set is empty the two rules differ only in the
+            // moments an entry would ENTER the set (a neighbour evaluated AT max(W).d with W full; an entry evicted while tied
+            // with the new maximum); the loop instantiated for this rule leaves at exactly those moments, in the middle of the
+            // hop, and the hop is finished here.  The hops below then run while the set is alive (it dies when max(W).d drops).
+            if (asm_ok && w.ovf_cnt == 0) {
+                HopResume rs;
+                bool left;
+                if constexpr (ASM_B8) left = search_layer0_bytes_sem1_asm<NSLOT>(iv, w, cx, rs, n_dist, n_hops, status);
+                else left = search_layer0_f32_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
+                if (!left) break;
+                pref_id = -1;
+                if constexpr (NSLOT > 2) {        // the loop keeps the slots' maxima in scalar registers: wlist_insert's copy is stale
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) {
+                        const uint32_t mh = rdlane(w.hi[s], 63), ml = rdlane(w.lo[s], 63);
+                        w.smax_hi = (lane == s) ? mh : w.smax_hi;
+                        w.smax_lo = (lane == s) ? ml : w.smax_lo;
+                    }
+                }
+                accept_candidates<NSLOT, SEM>(w, cx, rs.pass, rs.ckey, rs.cid1 - 1u, status, pc);
+                hop_eval<NCH, RB, NSLOT, METRIC, SEM, ROWS>(iv, qv, w, cx, rs.total, status, pc, nullptr, rs.total - rs.remaining);
+                continue;
+            }
+        }
+#endif
         uint64_t um[NSLOT];
         wlist_unexpanded_masks(w, um);
         int cidx;

@@ -27,6 +27,9 @@ namespace hnsw_dev {
 #ifndef HNSW_ASM_LOOP_F32       /* the float32-row instantiations (0: those shapes keep search_layer's C++ loop) */
 #define HNSW_ASM_LOOP_F32 1
 #endif
+#ifndef HNSW_ASM_LOOP_SEM1      /* the instantiations for the functor accept rule (0: that rule keeps the C++ loop) */
+#define HNSW_ASM_LOOP_SEM1 1
+#endif
 // measurement builds (-DHNSW_ASM_PHASE=k, tools/asm_phases.sh): shader-clock cycles spent between probe point k and k + 1 of
 // every hop, summed into the n_dist counter.  Points: 0 hop start, 1 adjacency row in registers, 2 fresh list written,
 // 3 round evaluated and accept mask known, 4 insertions done.  s[90:93] are used by name (declared clobbered).
@@ -123,6 +126,42 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_dot4_u32_u8 " DA ", " DB ", " DB ", " DA "\n\t"
 #define HNSW_COMBINE(DA, TA) "v_mad_i32_i24 " DA ", " TA ", -2, " DA "\n\t"
 
+// The entry that falls off W is at the new maximum's distance (label LBL; BACK: the way on; LASTLO: the top slot's low halves).
+// A dummy: nothing happens.  Ohnsw rule (HNSW_EVICT_TIE_PUSH): a real, unexpanded one stays in the candidate queue
+// (lib/ohnsw.ml:568 is false for it): pushed on the tie list in LDS.  The list holds entries at distance od; it is alive
+// while od == max(W).d (a list left over from a larger maximum is restarted here); full (64 entries): the query is flagged
+// and searched again by the caller.  Functor rule (HNSW_EVICT_TIE_BAIL): the list is a set with other entries and another
+// pop order (search_layer): the loop is left with the candidate still in `fresh`, see hnsw_hop_loop.inc.
+#define HNSW_EVICT_TIE_PUSH(LBL, BACK, LASTLO, FULL)                                                                        \
+    LBL ":\n\t"                                                                                                             \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 " BACK "\n\t"                                        /* W still holds dummies: nothing real falls off */ \
+    "v_readlane_b32 %[t], " LASTLO ", 63\n\t"                                                                               \
+    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
+    "s_cbranch_scc1 " BACK "\n\t"                                        /* expanded: gone for good */                     \
+    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                                                                         \
+    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
+    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
+    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
+    "s_cbranch_scc1 " FULL "f\n\t"                                                                                          \
+    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
+    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
+    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
+    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
+    "s_mov_b64 exec, 1\n\t"                                                                                                 \
+    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n\t"                                                                                                \
+    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
+    "s_branch " BACK "\n"                                                                                                   \
+    FULL ":\n\t"                                                                                                            \
+    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
+    "s_branch " BACK "\n"
+#define HNSW_EVICT_TIE_BAIL(LBL, BACK, LASTLO, FULL)                                                                        \
+    LBL ":\n\t"                                                                                                             \
+    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
+    "s_cbranch_scc1 " BACK "\n\t"                                        /* W still holds dummies: nothing real falls off */ \
+    "s_branch 98f\n"
+
 // The insertion loop of one round (labels 10 loop entry, 110 next candidate, 19 done): insert_island2's steps, ordered for a
 // wave that runs alone and counted for a chip that is full.  Alone: a scalar instruction that reads what a vector
 // instruction has just written (v_readlane, v_cmp -> SGPR) waits ~16 cycles beyond its issue slot and a taken branch costs
@@ -147,7 +186,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_cmp_gt_u32_e64 %[g0], %[kd], %[h0]\n\t"                                                                              \
     "v_cmp_gt_u32_e32 vcc, %[kd], %[h1]\n\t"                                                                                \
     "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                       \
-    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */      \
+    "s_cbranch_scc1 " HNSW_SEM_REJECT "\n\t"                                              /* no longer below max(W): rejected, :574 */      \
     "s_or_b64 %[um0], %[um0], %[um1]\n\t"                                                                                   \
     "s_cbranch_scc1 14f\n\t"                                              /* members of W at this very distance */          \
     "s_max_u32 %[nw], %[nw], %[kd]\n\t"                                   /* the new max(W).d (this key if it ranks last) */ \
@@ -226,52 +265,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     /* rare: the entry that falls off is at the new maximum's distance.  A dummy: nothing happens.  A real, unexpanded one   */ \
     /* stays in the candidate queue (lib/ohnsw.ml:568 is false for it): pushed on the tie list.  The list holds entries at */ \
     /* distance od; it is alive while od == max(W).d (a list left over from a larger maximum is restarted here)            */ \
-    "15:\n\t"                                                                                                               \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
-    "s_cbranch_scc1 12b\n\t"                                              /* W still holds dummies: nothing real falls off */ \
-    "v_readlane_b32 %[t], %[l1], 63\n\t"                                                                                    \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
-    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                     \
-    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                                                                         \
-    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
-    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
-    "s_cbranch_scc1 16f\n\t"                                                                                                \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
-    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
-    "s_mov_b64 exec, 1\n\t"                                                                                                 \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
-    "s_mov_b64 exec, -1\n\t"                                                                                                \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
-    "s_branch 12b\n"                                                                                                        \
-    "16:\n\t"                                                                                                               \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 12b\n"                                                                                                        \
-    "151:\n\t"                                                                                                              \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
-    "s_cbranch_scc1 141b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
-    "v_readlane_b32 %[t], %[l1], 63\n\t"                                                                                    \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
-    "s_cbranch_scc1 141b\n\t"                                             /* expanded: gone for good */                     \
-    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                                                                         \
-    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
-    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
-    "s_cbranch_scc1 161f\n\t"                                                                                               \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
-    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
-    "s_mov_b64 exec, 1\n\t"                                                                                                 \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
-    "s_mov_b64 exec, -1\n\t"                                                                                                \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
-    "s_branch 141b\n"                                                                                                       \
-    "161:\n\t"                                                                                                              \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 141b\n"
+    HNSW_EVICT_TIE("15", "12b", "%[l1]", "16")                                                                                                        \
+    HNSW_EVICT_TIE("151", "141b", "%[l1]", "161")
 
 // accept ballot of a round: candidate index of this lane within the round = byte SHAPE of the per-lane constant co (0xff on
 // a lane that holds no candidate's sum), valid below cnt, and below the current max(W) (lib/ohnsw.ml:574)
@@ -281,7 +276,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_add_u32_e32 %[cid], 1, %[cid]\n\t"           /* ids -> low key halves: id + 1, unexpanded */          \
     "v_cmp_gt_u32_sdwa vcc, %[cnt], %[co] src0_sel:DWORD src1_sel:BYTE_" #SHAPE "\n\t"
 #define HNSW_ACCEPT_LATE                                                                 \
-    "v_cmp_gt_u32_e64 %[fresh], %[wmax], %[ckey]\n\t"                                     \
+    "v_cmp_" HNSW_SEM_ACCEPT "_u32_e64 %[fresh], %[wmax], %[ckey]\n\t"  /* Ohnsw: below max(W); functor rule: not above */ \
     "s_and_b64 %[fresh], %[fresh], vcc\n\t"
 
 // label 4: the hop's node is in klo: count it, then its adjacency row (Graph.adjacent, :570).  The row was requested during
@@ -534,6 +529,12 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_ROWS 2
 #define HNSW_LOOP_METRIC 0
 #include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
 
 // =====================================================================================================================
 // The same loop for W in FOUR key registers per lane (ef 129..256) and in ONE (ef <= 64).  Shared with the two-slot
@@ -614,7 +615,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_readlane_b32 %[klo], %[cid], %[i]\n\t"                                                                               \
     "v_readlane_b32 %[nw], %[h3], 62\n\t"                                                                                   \
     "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                       \
-    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */      \
+    "s_cbranch_scc1 " HNSW_SEM_REJECT "\n\t"                                              /* no longer below max(W): rejected, :574 */      \
     "s_cmp_lt_u32 %[mx2], %[kd]\n\t"                                      /* the rank's slot, from the slots' maxima */     \
     "s_cbranch_scc0 82f\n\t"                                                                                                \
     "v_cmp_eq_u32_e32 vcc, %[kd], %[h3]\n\t"                                                                                \
@@ -768,126 +769,22 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_cbranch_scc1 811b\n\t"                                                                                               \
     "s_branch 801b\n"                                                                                                       \
     /* rare: the entry that falls off is at the new maximum's distance (see the two-slot loop); one copy per way back */     \
-    "153:\n\t"                                                                                                              \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
-    "s_cbranch_scc1 831b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
-    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
-    "s_cbranch_scc1 831b\n\t"                                             /* expanded: gone for good */                     \
-    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
-    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
-    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
-    "s_cbranch_scc1 163f\n\t"                                                                                               \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
-    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
-    "s_mov_b64 exec, 1\n\t"                                                                                                 \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
-    "s_mov_b64 exec, -1\n\t"                                                                                                \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
-    "s_branch 831b\n"                                                                                                       \
-    "163:\n\t"                                                                                                              \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 831b\n"                                                                                                       \
-    "152:\n\t"                                                                                                              \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
-    "s_cbranch_scc1 821b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
-    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
-    "s_cbranch_scc1 821b\n\t"                                             /* expanded: gone for good */                     \
-    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
-    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
-    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
-    "s_cbranch_scc1 162f\n\t"                                                                                               \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
-    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
-    "s_mov_b64 exec, 1\n\t"                                                                                                 \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
-    "s_mov_b64 exec, -1\n\t"                                                                                                \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
-    "s_branch 821b\n"                                                                                                       \
-    "162:\n\t"                                                                                                              \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 821b\n"                                                                                                       \
-    "151:\n\t"                                                                                                              \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
-    "s_cbranch_scc1 811b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
-    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
-    "s_cbranch_scc1 811b\n\t"                                             /* expanded: gone for good */                     \
-    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
-    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
-    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
-    "s_cbranch_scc1 161f\n\t"                                                                                               \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
-    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
-    "s_mov_b64 exec, 1\n\t"                                                                                                 \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
-    "s_mov_b64 exec, -1\n\t"                                                                                                \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
-    "s_branch 811b\n"                                                                                                       \
-    "161:\n\t"                                                                                                              \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 811b\n"                                                                                                       \
-    "150:\n\t"                                                                                                              \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
-    "s_cbranch_scc1 801b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
-    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
-    "s_cbranch_scc1 801b\n\t"                                             /* expanded: gone for good */                     \
-    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
-    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
-    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
-    "s_cbranch_scc1 160f\n\t"                                                                                               \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
-    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
-    "s_mov_b64 exec, 1\n\t"                                                                                                 \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
-    "s_mov_b64 exec, -1\n\t"                                                                                                \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
-    "s_branch 801b\n"                                                                                                       \
-    "160:\n\t"                                                                                                              \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 801b\n"                                                                                                       \
-    "154:\n\t"                                                                                                              \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
-    "s_cbranch_scc1 141b\n\t"                                             /* W still holds dummies: nothing real falls off */ \
-    "v_readlane_b32 %[t], %[l3], 63\n\t"                                                                                    \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
-    "s_cbranch_scc1 141b\n\t"                                             /* expanded: gone for good */                     \
-    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
-    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
-    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
-    "s_cbranch_scc1 164f\n\t"                                                                                               \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
-    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
-    "s_mov_b64 exec, 1\n\t"                                                                                                 \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
-    "s_mov_b64 exec, -1\n\t"                                                                                                \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
-    "s_branch 141b\n"                                                                                                       \
-    "164:\n\t"                                                                                                              \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 141b\n"
+    HNSW_EVICT_TIE("153", "831b", "%[l3]", "163")                                                                                                       \
+    HNSW_EVICT_TIE("152", "821b", "%[l3]", "162")                                                                                                       \
+    HNSW_EVICT_TIE("151", "811b", "%[l3]", "161")                                                                                                       \
+    HNSW_EVICT_TIE("150", "801b", "%[l3]", "160")                                                                                                       \
+    HNSW_EVICT_TIE("154", "141b", "%[l3]", "164")
 
 #define HNSW_LOOP_NAME search_layer0_bytes_l2_asm4
 #define HNSW_LOOP_NSLOT 4
 #define HNSW_LOOP_ROWS 2
 #define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
 
 // ---- one slot (ef <= 64): no cascade; the same steps as the two-slot loop's upper slot --------------------------------
@@ -903,7 +800,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_cmp_eq_u32_e64 %[um0], %[kd], %[h0]\n\t"                                                                             \
     "v_cmp_gt_u32_e32 vcc, %[kd], %[h0]\n\t"                                                                                \
     "s_cmp_ge_u32 %[kd], %[wmax]\n\t"                                                                                       \
-    "s_cbranch_scc1 18f\n\t"                                              /* no longer below max(W): rejected, :574 */      \
+    "s_cbranch_scc1 " HNSW_SEM_REJECT "\n\t"                                              /* no longer below max(W): rejected, :574 */      \
     "s_cmp_lg_u64 %[um0], 0\n\t"                                                                                            \
     "s_cbranch_scc1 14f\n\t"                                              /* members of W at this very distance */          \
     "s_bcnt1_i32_b64 m0, vcc\n"                                           /* rank = keys at a smaller distance */           \
@@ -937,34 +834,18 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_cbranch_scc1 18b\n\t"                                              /* already in W */                                \
     "s_mov_b32 m0, %[p]\n\t"                                                                                               \
     "s_branch 11b\n"                                                                                                        \
-    "15:\n\t"                                                                                                               \
-    "s_cmp_eq_u32 %[wmax], -2\n\t"                                                                                          \
-    "s_cbranch_scc1 12b\n\t"                                              /* W still holds dummies: nothing real falls off */ \
-    "v_readlane_b32 %[t], %[l0], 63\n\t"                                                                                    \
-    "s_bitcmp1_b32 %[t], 31\n\t"                                                                                            \
-    "s_cbranch_scc1 12b\n\t"                                              /* expanded: gone for good */                     \
-    "s_cmp_eq_u32 %[od], %[nw]\n\t"                                       /* a list left from a larger maximum is restarted */ \
-    "s_cselect_b32 %[oc], %[oc], 0\n\t"                                                                                     \
-    "s_mov_b32 %[od], %[nw]\n\t"                                                                                            \
-    "s_cmp_ge_u32 %[oc], 64\n\t"                                                                                            \
-    "s_cbranch_scc1 16f\n\t"                                                                                                \
-    "s_sub_u32 %[t], %[t], 1\n\t"                                                                                           \
-    "s_lshl2_add_u32 %[tmp], %[oc], %[cand]\n\t"                                                                            \
-    "v_mov_b32_e32 %[t0], %[tmp]\n\t"                                                                                       \
-    "v_mov_b32_e32 %[t1], %[t]\n\t"                                                                                         \
-    "s_mov_b64 exec, 1\n\t"                                                                                                 \
-    "ds_write_b32 %[t0], %[t1] offset:768\n\t"                                                                              \
-    "s_mov_b64 exec, -1\n\t"                                                                                                \
-    "s_add_u32 %[oc], %[oc], 1\n\t"                                                                                         \
-    "s_branch 12b\n"                                                                                                        \
-    "16:\n\t"                                                                                                               \
-    "s_or_b32 %[st], %[st], 1\n\t"                                        /* list full: flagged, the host searches again */ \
-    "s_branch 12b\n"
+    HNSW_EVICT_TIE("15", "12b", "%[l0]", "16")
 
 #define HNSW_LOOP_NAME search_layer0_bytes_l2_asm1
 #define HNSW_LOOP_NSLOT 1
 #define HNSW_LOOP_ROWS 2
 #define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
 
 // =====================================================================================================================
@@ -1194,6 +1075,78 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_ROWS 0
 #define HNSW_LOOP_METRIC 1
 #include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
 
 // the instantiation for a kernel variant's (slots, metric, row shape)
 template <int NSLOT, int METRIC, int ROWS>
@@ -1205,6 +1158,26 @@ __device__ __forceinline__ void search_layer0_f32_asm(const IndexView &iv, WList
     HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_asm4)
     HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_asm4)
 #undef HNSW_F32_CALL
+}
+
+// ... and for the functor rule: true when the loop was left in the middle of a hop (HopResume), false when the search is done
+template <int NSLOT>
+__device__ __forceinline__ bool search_layer0_bytes_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
+                                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+    if constexpr (NSLOT == 1) return search_layer0_bytes_l2_sem1_asm1(iv, w, cx, rs, n_dist, n_hops, status);
+    else if constexpr (NSLOT == 2) return search_layer0_bytes_l2_sem1_asm2(iv, w, cx, rs, n_dist, n_hops, status);
+    else return search_layer0_bytes_l2_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+}
+template <int NSLOT, int METRIC, int ROWS>
+__device__ __forceinline__ bool search_layer0_f32_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
+                                                           const float4 (&qv)[2], uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
+    HNSW_F32_CALL(1, 0, 1, search_layer0_f32_l2_full_sem1_asm1)   HNSW_F32_CALL(2, 0, 1, search_layer0_f32_l2_full_sem1_asm2)   HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_sem1_asm4)
+    HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_sem1_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_sem1_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_sem1_asm4)
+    HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_sem1_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_sem1_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_sem1_asm4)
+    HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_sem1_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_sem1_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_sem1_asm4)
+#undef HNSW_F32_CALL
+    return false;
 }
 
 

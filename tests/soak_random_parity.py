@@ -21,6 +21,12 @@ trials = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 efs = [1, 2, 3, 7, 31, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 513, 700, 1024]
 ds = [1, 2, 3, 4, 5, 7, 16, 31, 33, 63, 64, 65, 96, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 513, 784]
+if os.environ.get("SOAK_DS"):       # e.g. SOAK_DS=65-128 SOAK_EFS=1-256: one kernel family (here: the hand-scheduled loops' domain)
+    lo, hi = (int(x) for x in os.environ["SOAK_DS"].split("-"))
+    ds = list(range(lo, hi + 1))
+if os.environ.get("SOAK_EFS"):
+    lo, hi = (int(x) for x in os.environ["SOAK_EFS"].split("-"))
+    efs = [e for e in efs if lo <= e <= hi] + [int(x) for x in np.random.default_rng(7).integers(lo, hi + 1, 8)]
 bad = 0
 for trial in range(trials):
     n = int(rng.integers(1, 1500))

@@ -50,6 +50,35 @@ def test_ties_everywhere_every_slot_count(H, oracle, levels, d):
         _check(H, oracle, hg, g, sp, Q, ef, k, "levels %d d %d ef %d" % (levels, d, ef))
 
 
+def _check_functor(H, oracle, hg, g, sp, Q, ef, k, ctx=""):
+    """Hnsw_algo.Search / Hnsw.Ba.knn_batch (the functor accept rule) under the (d, id) order: ids, distance bits, counters"""
+    import ocaml_hnsw_amd as A
+    gi, gd, gnd, gnh = A._search(hg, Q, ef, k, A.FILL_BA, True, sem=A.SEM_FUNCTOR)
+    cd, ci = oracle.Functor.knn_batch(g, sp, Q, ef, k, ties=oracle.TIES_CANONICAL, with_ids=True)
+    np.testing.assert_array_equal(gd.view(np.uint32), cd.view(np.uint32), err_msg=ctx)
+    np.testing.assert_array_equal(gi, ci, err_msg=ctx)
+    assert (gnd > 0).all() and (gnh > 0).all(), ctx
+
+
+@pytest.mark.parametrize("levels", [2, 3, 6, 40])
+@pytest.mark.parametrize("d", [65, 128])
+def test_functor_rule_through_the_loops(H, oracle, levels, d):
+    """The loops instantiated for the functor rule leave a hop whenever an entry would enter the tie set and come back when
+    the set is empty again (search_layer): tie-heavy data makes them leave all the time, in every slot count."""
+    rng = np.random.default_rng(300 * levels + d)
+    n = 5000
+    X = rng.integers(0, levels, size=(n, d)).astype(np.float32)
+    X[rng.integers(0, n, 300)] = X[rng.integers(0, n, 300)]
+    Q = rng.integers(0, levels, size=(150, d)).astype(np.float32)
+    Q[:10] = X[:10]
+    sp = oracle.Space.l2(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 12, 60, seed=3)
+    hg = _hgraph(H, X, g, 12)
+    assert hg.to_device(0).row_bytes() == d
+    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256)):
+        _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor levels %d d %d ef %d" % (levels, d, ef))
+
+
 def test_wide_rows_and_long_lists(H, oracle):
     """M = 32: layer-0 rows of 64 neighbours, fresh lists longer than one 16-row round, all four batch shapes."""
     rng = np.random.default_rng(7)
@@ -62,6 +91,7 @@ def test_wide_rows_and_long_lists(H, oracle):
     hg = _hgraph(H, X, g, 32)
     for ef, k in ((48, 10), (128, 10), (250, 50)):
         _check(H, oracle, hg, g, sp, Q, ef, k, "M 32 ef %d" % ef)
+        _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor M 32 ef %d" % ef)
 
 
 @pytest.mark.parametrize("ef", [64, 128, 256])
@@ -145,6 +175,7 @@ def test_random_configurations_of_the_loop_shapes(H, oracle):
         g = oracle.build_ohnsw(sp, M, 40, seed=trial)
         hg = _hgraph(H, X, g, M)
         _check(H, oracle, hg, g, sp, Q, ef, k, "trial %d: n %d d %d M %d levels %d ef %d k %d" % (trial, n, d, M, levels, ef, k))
+        _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor trial %d: n %d d %d M %d levels %d ef %d k %d" % (trial, n, d, M, levels, ef, k))
 
 
 def test_issue_priorities_and_ordering_change_nothing(H, oracle, monkeypatch):

@@ -40,6 +40,16 @@ def _check(H, oracle, hg, g, sp, Q, ef, k, ctx=""):
     assert (nd > 0).all(), ctx
 
 
+def _check_functor(H, oracle, hg, g, sp, Q, ef, k, ctx=""):
+    """the functor accept rule (Hnsw.Ba.knn_batch) under the (d, id) order: the loops leave a hop when an entry would enter the tie set"""
+    import ocaml_hnsw_amd as A
+    gi, gd, gnd, gnh = A._search(hg, Q, ef, k, A.FILL_BA, True, sem=A.SEM_FUNCTOR)
+    cd, ci = oracle.Functor.knn_batch(g, sp, Q, ef, k, ties=oracle.TIES_CANONICAL, with_ids=True)
+    np.testing.assert_array_equal(gd.view(np.uint32), cd.view(np.uint32), err_msg=ctx)
+    np.testing.assert_array_equal(gi, ci, err_msg=ctx)
+    assert (gnd > 0).all() and (gnh > 0).all(), ctx
+
+
 EFS = ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256))
 
 
@@ -61,6 +71,8 @@ def test_order_dependent_sums_every_slot_count(H, oracle, d, metric):
     hg = _hgraph(H, X, g, 12, metric)
     for ef, k in EFS:
         _check(H, oracle, hg, g, sp, Q, ef, k, "metric %d d %d ef %d" % (metric, d, ef))
+        if ef in (17, 100, 192):
+            _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor metric %d d %d ef %d" % (metric, d, ef))
     hg.release()
 
 
@@ -79,6 +91,7 @@ def test_ties_everywhere_float_rows(H, oracle, levels, d, metric):
     hg = _hgraph(H, X, g, 12, metric)
     for ef, k in EFS:
         _check(H, oracle, hg, g, sp, Q, ef, k, "levels %d d %d metric %d ef %d" % (levels, d, metric, ef))
+        _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor levels %d d %d metric %d ef %d" % (levels, d, metric, ef))
     hg.release()
 
 
@@ -111,6 +124,7 @@ def test_wide_rows_and_long_lists_float_rows(H, oracle, metric):
     hg = _hgraph(H, X, g, 32, metric)
     for ef, k in ((48, 10), (128, 10), (250, 50)):
         _check(H, oracle, hg, g, sp, Q, ef, k, "M 32 metric %d ef %d" % (metric, ef))
+        _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor M 32 metric %d ef %d" % (metric, ef))
     hg.release()
 
 
@@ -183,6 +197,7 @@ def test_random_configurations_of_the_float_loop_shapes(H, oracle):
         g = oracle.build_ohnsw(sp, M, 40, seed=trial)
         hg = _hgraph(H, X, g, M, metric, split=trial & 1)
         _check(H, oracle, hg, g, sp, Q, ef, k, "trial %d: n %d d %d M %d metric %d kind %d ef %d k %d" % (trial, n, d, M, metric, kind, ef, k))
+        _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor trial %d: n %d d %d M %d metric %d kind %d ef %d k %d" % (trial, n, d, M, metric, kind, ef, k))
         hg.release()
 
 

@@ -5,7 +5,7 @@
     python tools/ab.py --one <lib>                        # (internal) measure one library
 
 Per library: 64 queries on an idle chip, the 10 k batch (the headline), 100 k queries, the harder set's 10 k
-batch when AB_HARD=1; byte rows and (AB_F32=1) float32 rows.  Prints the median of REPS device calls and an
+batch when AB_HARD=1; byte rows and (AB_F32=1) float32 rows; AB_SEM=1: the functor accept rule (Hnsw.Ba) instead of Ohnsw's.  Prints the median of REPS device calls and an
 md5 over ids, distance bits, evaluation and hop counts of the 10 k batch: variants that are meant to be exact
 must print the same digest.  The index is built by the first library and saved; the others load the file.
 """
@@ -59,7 +59,8 @@ def one(lib):
 
                 def go(c=False):
                     H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef, k, ids.data_ptr(), dist.data_ptr(),
-                                          nd.data_ptr() if c else 0, nh.data_ptr() if c else 0, st.data_ptr() if c else 0, stream.cuda_stream)
+                                          nd.data_ptr() if c else 0, nh.data_ptr() if c else 0, st.data_ptr() if c else 0, stream.cuda_stream,
+                                          sem=int(os.environ.get("AB_SEM", 0)))
                 go(True)
                 torch.cuda.synchronize()
                 if nq == 10000 or digest is None:
