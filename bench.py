@@ -17,8 +17,8 @@ Ohnsw.knn_batch_bigarray (H2D of the queries + ordering pre-pass + search kernel
 matrices in page-locked memory -- hnsw_host_alloc, or registered once with hnsw_host_register -- as a benchmark loop
 that reuses its Bigarrays would have them: the device then reads and writes them directly).  Named beside it:
 `device_resident` (hnsw_search_batch_device: queries already in HBM, results left there), `float32_rows` (the same
-batch through the general-format kernel), `harder_set_at_recall_gate`, `drop_in` (pageable matrices; two requests in
-flight), `secondary` (a harder SIFT-like set), `others` (C3, C5), and for N > 1 `strong` (C4 as BASELINE.json words it:
+batch through the general-format kernel), `harder_set_at_recall_gate`, `functor_api` (Hnsw.Ba.knn_batch: the functor
+module's accept rule through the same protocol), `drop_in` (pageable matrices; two requests in flight), `secondary` (a harder SIFT-like set), `others` (C3, C5), and for N > 1 `strong` (C4 as BASELINE.json words it:
 ONE 10 k batch split over the N GPUs).  `roofline` is the search kernel's: its duration comes from HIP events the
 library records around its own launches inside the timed region.
 
@@ -528,6 +528,7 @@ def main():
     # ---- the drop-in call: what Ohnsw.knn_batch_bigarray becomes (host matrices in and out, one
     #      synchronous call per batch, benchmark/benchmark.ml:89-96), PCIe copies included ----
     drop_in = None
+    functor_result = None
     if world == 1 and rank == 0:
         Qh = Qd.cpu().numpy()
         reps = max(5, min(args.steps, 10))
@@ -576,11 +577,20 @@ def main():
         sub = timed_calls(one_submit_wait)
         while inflight:
             inflight.pop(0).wait(out=(oi_, od_))
+        # (d) the functor module's call (Hnsw.Ba.knn_batch, lib/hnsw.ml:763-777: accept rule of Hnsw_algo.Search, distances only,
+        #     +inf filled): same protocol, same matrices
+        fi_ = H.host_empty((nq, k), np.int32)
+        fd_ = H.host_empty((nq, k), np.float32)
+        H._search(hg, Qh, ef, k, H.FILL_BA, sem=H.SEM_FUNCTOR, out=(fi_, fd_))
+        functor_result = (fi_.copy(), fd_.copy())
+        sync_f = timed_calls(lambda: H._search(hg, Qh, ef, k, H.FILL_BA, sem=H.SEM_FUNCTOR, out=(fi_, fd_)))
         drop_in = {"synchronous": leg(*sync_r, "the headline protocol again, as the median of %d single calls: hnsw_search_batch, the caller's query / result "
                                                "matrices page-locked (hnsw_host_alloc / hnsw_host_register: queries read and results written by the device directly) -> ordering pre-pass + search kernel, one blocking "
                                                "call per %d-query batch = the body of Ohnsw.knn_batch_bigarray" % (reps, nq)),
                    "synchronous_pageable": leg(*sync_p, "the same call on fresh pageable matrices (copies staged by the runtime)"),
                    "submit_wait_2_in_flight": leg(*sub, "hnsw_search_submit / hnsw_search_wait, two requests in flight, registered matrices"),
+                   "functor_api": leg(*sync_f, "the body of Hnsw.Ba.knn_batch: the same blocking call with the functor module's accept rule "
+                                               "(Hnsw_algo.Search: a neighbour AT max(W).d is still expanded) and its +inf fill, registered matrices"),
                    "batches_timed": reps, "statistic": "median of the per-call wall times (min / max beside it)"}
         log("drop-in (host buffers): synchronous %.0f q/s (%.3f ms/batch; pageable %.3f ms), submit/wait x2 %.0f q/s (%.3f ms/batch)" %
             (nq / sync_r[0], 1e3 * sync_r[0], 1e3 * sync_p[0], nq / sub[0], 1e3 * sub[0]))
@@ -1109,6 +1119,11 @@ def main():
             checks["parity_ids_equal"] = bool(np.array_equal(oids, got[:sample]))
             checks["parity_dist_bits_equal"] = bool(np.array_equal(odist.view(np.uint32), got_dist[:sample].view(np.uint32)))
             checks["gpu_reevaluation_overhead"] = round(float(gpu_nd[:sample].mean() / max(ond.mean(), 1) - 1), 4)
+            if functor_result is not None:      # the functor module's rule on the same sample (ties in the (d, id) order)
+                fs = min(sample, 500)
+                ofd, ofi = o.Functor.knn_batch(g, sp, Qs[:fs], ef, k, ties=o.TIES_CANONICAL, with_ids=True)
+                checks["functor_parity_ids_equal"] = bool(np.array_equal(ofi, functor_result[0][:fs]))
+                checks["functor_parity_dist_bits_equal"] = bool(np.array_equal(ofd.view(np.uint32), functor_result[1][:fs].view(np.uint32)))
             if world == 1:
                 # the baseline is timed with the REFERENCE's arithmetic (Lacaml-style sequential fp32 sum, sqrt in
                 # double: oracle SEQ_F32), not with the kernel's summation order used for the parity leg above
@@ -1261,6 +1276,10 @@ def main():
                               "what": "option byte_rows = 0: the same index, batch and protocol through the float32 rows (the general-format kernel, "
                                       "what data that is not byte-valued takes); details in roofline.float32_rows"}),
             "harder_set_at_recall_gate": harder_gate,
+            "functor_api": (None if not drop_in else
+                            {"value": drop_in["functor_api"]["value"], "unit": "queries/s", "ms_per_step": drop_in["functor_api"]["ms_per_batch"],
+                             "what": "Hnsw.Ba.knn_batch (lib/hnsw.ml:763-777), the functor module's entry point, through the headline's protocol: "
+                                     "accept rule of Hnsw_algo.Search, same index, batch, ef and k; median of %d blocking calls" % drop_in["batches_timed"]}),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "drop_in": drop_in, "secondary": secondary,
             "recall_gate": {"threshold": 0.95, "metric": "id-set recall@10 against exact brute force",
                             "headline_set": {"ef": ef if gate_ok else checks.get("ef_for_recall_0.95"),
