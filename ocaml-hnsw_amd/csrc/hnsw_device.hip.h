@@ -1268,10 +1268,13 @@ __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv,
 // loop itself needs 57 VGPRs and ~45 SGPRs, but left alone the allocator spreads the C++ paths around it over all 102
 // SGPRs, which costs the eighth wave (it now parks ~20 scalars of the prologue / epilogue in VGPR lanes instead); the
 // other variants are left to the allocator
+#ifndef HNSW_SEM1_8WAVES       /* the functor-rule kernels of the headline shape at eight waves per SIMD too */
+#define HNSW_SEM1_8WAVES 1
+#endif
 #ifndef HNSW_SEARCH_MIN_WAVES
 #define HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS, SEMF) \
     (((NCH) <= 2 && (NSLOT) <= 2 && (METRIC) == 0 && (ROWS) == 1) ? 7 : \
-     (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) <= 4 && (METRIC) == 0 && (ROWS) == 2 && (SEMF) == 0) ? 8 : 1)
+     (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) <= 4 && (METRIC) == 0 && (ROWS) == 2 && ((SEMF) == 0 || HNSW_SEM1_8WAVES)) ? 8 : 1)
 #endif
 // SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); ROWS: 0 | 1 | 2 | 3, see hop_round
 template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, int ROWS>

@@ -102,6 +102,8 @@ def _asm_kernels(objs):
     for obj, metric, rows in (("hnsw_search_variants_0_0_1.o", 0, 1), ("hnsw_search_variants_0_0_0.o", 0, 0),
                               ("hnsw_search_variants_1_0_1.o", 1, 1), ("hnsw_search_variants_1_0_0.o", 1, 0)):
         want += [(obj, "hnsw_search_kernelILi2ELi4ELi%dELi%dELi0ELi%dE" % (s, metric, rows)) for s in (1, 2, 4)]
+    want += [("hnsw_search_variants_0_1_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi1ELi2E" % s) for s in (1, 2, 4)]     # the functor rule's instantiations
+    want += [("hnsw_search_variants_1_1_0.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi1ELi0E" % s) for s in (2,)]
     want += [("hnsw_order.hip.o", "hnsw_descent_kernelILi2ELi8ELi0ELi2E")]
     out = []
     for obj, frag in want:
@@ -111,11 +113,37 @@ def _asm_kernels(objs):
     return out
 
 
+def _owned_nops(body):
+    """the s_nop instructions that pad a hazard (the checker's business): not the runs that align a loop head
+    (HNSW_ASM_ALIGN_K: three or more in a row), not the single ones the compiler puts between two memory instructions of
+    its own code (they end a "soft clause" whose later load overwrites an earlier one's address registers: an XNACK replay
+    rule, not a wait-state rule)"""
+    mem = ("global_", "buffer_", "flat_", "scratch_", "s_load", "s_buffer_load")
+    live = [i for i in body if not getattr(i, "dead", False)]
+    out = []
+    for n, i in enumerate(live):
+        if i.mn != "s_nop":
+            continue
+        a = n
+        while a > 0 and live[a - 1].mn == "s_nop":
+            a -= 1
+        b = n
+        while b + 1 < len(live) and live[b + 1].mn == "s_nop":
+            b += 1
+        if b - a + 1 >= 3:
+            continue
+        prev, nxt = (live[a - 1].mn if a > 0 else ""), (live[b + 1].mn if b + 1 < len(live) else "")
+        if prev.startswith(mem) and nxt.startswith(mem):
+            continue
+        out.append(i)
+    return out
+
+
 def test_a_deleted_wait_state_is_noticed(objects):
-    """the deliberately broken copy: each s_nop of the hand-scheduled kernels deleted in turn from the parsed listing"""
+    """the deliberately broken copy: each hazard-padding s_nop of the hand-scheduled kernels deleted in turn from the parsed listing"""
     hz, objs = objects
     for obj, name, body in _asm_kernels(objs):
-        nops = [i for i in body if i.mn == "s_nop"]
+        nops = _owned_nops(body)
         caught = 0
         for i in nops:
             i.dead = True
@@ -123,5 +151,5 @@ def test_a_deleted_wait_state_is_noticed(objects):
                 caught += 1
             i.dead = False
         print("%s %s: %d instructions, %d of %d single s_nop deletions caught" % (obj, name[:60], len(body), caught, len(nops)))
-        assert nops and caught >= 0.6 * len(nops), (name, caught, len(nops))
+        assert nops and caught >= 0.9 * len(nops), (name, caught, len(nops))
         assert not hz.check(body)                             # and the untouched listing is clean again
