@@ -1044,21 +1044,24 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     const int lane = cx.lane;
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
 #if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING)
-    // The hand-scheduled loops (hnsw_hop_asm.hip.h), same results.  ASM_B8: the headline shape (d <= 128 byte rows, byte query,
-    // L2; ef <= 64 / 65..128 / 129..256); ASM_F32: float32 rows of 65..128 dimensions (17..32 chunks), either metric.
+    // The hand-scheduled loops (hnsw_hop_asm.hip.h), same results.  ASM_B8: d <= 128 byte rows and a byte-valued query (L2: the
+    // headline shape; inner product), ef <= 64 / 65..128 / 129..256; ASM_F32: float32 rows of 65..128 dimensions (17..32 chunks), either metric.
     // (The blocks form the byte offset (id + 1) * S0 * 4 + lane * 4 of an adjacency row in 32 bits, one row ahead of the node
     // they fetch: the row AFTER the last node's must still be below 2^32 bytes whatever S0 is; and they restore EXEC with
     // s_mov_b64 exec, -1: they are entered with all 64 lanes on -- the kernel runs one full wave per query and reaches this
     // point through wave-uniform branches only.  A query whose tie list went to the global slab keeps the C++ loop.)
     constexpr bool ASM_SLOTS = NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4);
-    constexpr bool ASM_B8 = ASM_SLOTS && METRIC == 0 && ROWS == 2;
+    constexpr bool ASM_B8 = ASM_SLOTS && ROWS == 2;
     constexpr bool ASM_F32 = HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1);
     bool asm_ok = false;
     if constexpr (ASM_B8 || ASM_F32) {
         asm_ok = layer == 0 && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30) &&
                  (ASM_B8 ? cx.qint != 0 : iv.nchunks > 16);
     }
-    if constexpr (ASM_B8 && SEM == 0) {
+    if constexpr (ASM_B8 && SEM == 0 && METRIC == 1) {
+        if (asm_ok) { search_layer0_bytes_ip_asm<NSLOT>(iv, w, cx, n_dist, n_hops, status); return; }
+    }
+    if constexpr (ASM_B8 && SEM == 0 && METRIC == 0) {
         if (asm_ok) {
             if constexpr (NSLOT == 1) { search_layer0_bytes_l2_asm1(iv, w, cx, n_dist, n_hops, status); return; }
             if constexpr (NSLOT == 4) { search_layer0_bytes_l2_asm4(iv, w, cx, n_dist, n_hops, status); return; }
@@ -1098,7 +1101,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             if (asm_ok && w.ovf_cnt == 0) {
                 HopResume rs;
                 bool left;
-                if constexpr (ASM_B8) left = search_layer0_bytes_sem1_asm<NSLOT>(iv, w, cx, rs, n_dist, n_hops, status);
+                if constexpr (ASM_B8) left = search_layer0_bytes_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
                 else left = search_layer0_f32_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
                 if (!left) break;
                 pref_id = -1;

@@ -129,6 +129,20 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_dot4_u32_u8 " TA ", " DB ", %[qb1], " TA "\n\t"                                   \
     "v_dot4_u32_u8 " DA ", " DB ", " DB ", " DA "\n\t"
 #define HNSW_COMBINE(DA, TA) "v_mad_i32_i24 " DA ", " TA ", -2, " DA "\n\t"
+// the same for the inner product (hop_round: METRIC 1 on byte rows): x.q alone -> DA; the combine's slot stays a wait state, so
+// that the rounds' hand-counted distances are those of the L2 text
+#define HNSW_DOTS_IP(DA, DB, TA)                                                         \
+    "v_dot4_u32_u8 " TA ", " DA ", %[qb0], 0\n\t"                                        \
+    "v_dot4_u32_u8 " DA ", " DB ", %[qb1], " TA "\n\t"
+#define HNSW_COMBINE_IP(DA, TA) "s_nop 0\n\t"
+// the group's integer sum SRC -> key (dist_to_key of (float)sum): L2 the float's bits; inner product 1 - sum, sign-flipped
+#define HNSW_B8_KEY_L2(SRC) "v_cvt_f32_i32_e32 %[ckey], " SRC "\n\t"
+#define HNSW_B8_KEY_IP(SRC)                                                              \
+    "v_cvt_f32_i32_e32 %[t1], " SRC "\n\t"                                               \
+    "v_sub_f32_e32 %[t1], 1.0, %[t1]\n\t"                                                \
+    "v_ashrrev_i32_e32 %[t0], 31, %[t1]\n\t"                                             \
+    "v_or_b32_e32 %[t0], 0x80000000, %[t0]\n\t"                                          \
+    "v_xor_b32_e32 %[ckey], %[t1], %[t0]\n\t"
 
 // The entry that falls off W is at the new maximum's distance (label LBL; BACK: the way on; LASTLO: the top slot's low halves).
 // A dummy: nothing happens.  Ohnsw rule (HNSW_EVICT_TIE_PUSH): a real, unexpanded one stays in the candidate queue
@@ -365,12 +379,12 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")                                                                           \
         "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"                                                                        \
         "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
-        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
+        HNSW_B8_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
         "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
-        HNSW_DOTS("%[d2]", "%[d3]", "%[tb]")                                                                                          \
-        HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        HNSW_B8_DOTS("%[d2]", "%[d3]", "%[tb]")                                                                                          \
+        HNSW_B8_COMBINE("%[d0]", "%[ta]")                                                                                                \
         "s_nop 2\n\t"                                                                                                                 \
-        HNSW_COMBINE("%[d2]", "%[tb]")                                                                                                \
+        HNSW_B8_COMBINE("%[d2]", "%[tb]")                                                                                                \
         "v_cndmask_b32_e64 %[ta], %[d0], %[d2], %[b3m]\n\t"  /* keep: the sum this half of the group is for */                        \
         "v_cndmask_b32_e64 %[tb], %[d2], %[d0], %[b3m]\n\t"  /* give: the other half's */                                             \
         HNSW_ACCEPT_EARLY(1)                                                                                                               \
@@ -381,7 +395,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"                                                    \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
-        "v_cvt_f32_i32_e32 %[ckey], %[ta]\n\t"                                                                                        \
+        HNSW_B8_KEY("%[ta]")                                                                                        \
         HNSW_ACCEPT_LATE                                                                                                              \
         "s_sub_u32 %[cnt], %[cnt], 8\n"
 
@@ -392,10 +406,10 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
         HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
         "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
-        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
+        HNSW_B8_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
         "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
         "s_nop 2\n\t"                                                                                                                 \
-        HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        HNSW_B8_COMBINE("%[d0]", "%[ta]")                                                                                                \
         HNSW_ACCEPT_EARLY(0)                                                                                                   \
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
         "s_nop 1\n\t"                                                                                                                 \
@@ -404,7 +418,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:2" HNSW_DPP_BC "\n\t"                                                              \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:1" HNSW_DPP_BC "\n\t"                                                              \
-        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"                                                                                        \
+        HNSW_B8_KEY("%[d0]")                                                                                        \
         HNSW_ACCEPT_LATE                                                                                                              \
         "s_sub_u32 %[cnt], %[cnt], 4\n\t"                                                                                           \
         "s_branch 50b\n"                                                                                                              \
@@ -426,18 +440,18 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"                                                                        \
         "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"                                                                        \
         "s_waitcnt vmcnt(6)\n\t"                                                                                                      \
-        HNSW_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
+        HNSW_B8_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
         "s_waitcnt vmcnt(4)\n\t"                                                                                                      \
-        HNSW_DOTS("%[d2]", "%[d3]", "%[tb]")                                                                                          \
+        HNSW_B8_DOTS("%[d2]", "%[d3]", "%[tb]")                                                                                          \
         "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
-        HNSW_COMBINE("%[d0]", "%[ta]")                                                                                                \
-        HNSW_DOTS("%[d4]", "%[d5]", "%[ta]")                                                                                          \
+        HNSW_B8_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        HNSW_B8_DOTS("%[d4]", "%[d5]", "%[ta]")                                                                                          \
         "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
-        HNSW_COMBINE("%[d2]", "%[tb]")                                                                                                \
-        HNSW_DOTS("%[d6]", "%[d7]", "%[tb]")                                                                                          \
-        HNSW_COMBINE("%[d4]", "%[ta]")                                                                                                \
+        HNSW_B8_COMBINE("%[d2]", "%[tb]")                                                                                                \
+        HNSW_B8_DOTS("%[d6]", "%[d7]", "%[tb]")                                                                                          \
+        HNSW_B8_COMBINE("%[d4]", "%[ta]")                                                                                                \
         "s_nop 2\n\t"                                                                                                                 \
-        HNSW_COMBINE("%[d6]", "%[tb]")                                                                                                \
+        HNSW_B8_COMBINE("%[d6]", "%[tb]")                                                                                                \
   /* sums of candidates 0..3 of the group in d0, d2, d4, d6 -> quads of the group's 16 lanes */                                       \
         "v_cndmask_b32_e64 %[ta], %[d0], %[d4], %[b3m]\n\t"                                                                           \
         "v_cndmask_b32_e64 %[d1], %[d4], %[d0], %[b3m]\n\t"                                                                           \
@@ -454,7 +468,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"                                                    \
         "s_nop 1\n\t"                                                                                                                 \
         "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
-        "v_cvt_f32_i32_e32 %[ckey], %[d0]\n\t"                                                                                        \
+        HNSW_B8_KEY("%[d0]")                                                                                        \
         HNSW_ACCEPT_LATE                                                                                                              \
         "s_sub_u32 %[cnt], %[cnt], 16\n\t"                                                                                            \
         "s_branch 50b\n"
@@ -537,6 +551,17 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_NSLOT 2
 #define HNSW_LOOP_ROWS 2
 #define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
 
@@ -790,6 +815,17 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_METRIC 0
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
 
 // ---- one slot (ef <= 64): no cascade; the same steps as the two-slot loop's upper slot --------------------------------
 #define HNSW_INSERT_LOOP1                                                                                                   \
@@ -849,6 +885,17 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_NSLOT 1
 #define HNSW_LOOP_ROWS 2
 #define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
 
@@ -1165,12 +1212,26 @@ __device__ __forceinline__ void search_layer0_f32_asm(const IndexView &iv, WList
 }
 
 // ... and for the functor rule: true when the loop was left in the middle of a hop (HopResume), false when the search is done
-template <int NSLOT>
+template <int NSLOT, int METRIC>
 __device__ __forceinline__ bool search_layer0_bytes_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
                                                              uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-    if constexpr (NSLOT == 1) return search_layer0_bytes_l2_sem1_asm1(iv, w, cx, rs, n_dist, n_hops, status);
-    else if constexpr (NSLOT == 2) return search_layer0_bytes_l2_sem1_asm2(iv, w, cx, rs, n_dist, n_hops, status);
-    else return search_layer0_bytes_l2_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+    if constexpr (METRIC == 0) {
+        if constexpr (NSLOT == 1) return search_layer0_bytes_l2_sem1_asm1(iv, w, cx, rs, n_dist, n_hops, status);
+        else if constexpr (NSLOT == 2) return search_layer0_bytes_l2_sem1_asm2(iv, w, cx, rs, n_dist, n_hops, status);
+        else return search_layer0_bytes_l2_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+    } else {
+        if constexpr (NSLOT == 1) return search_layer0_bytes_ip_sem1_asm1(iv, w, cx, rs, n_dist, n_hops, status);
+        else if constexpr (NSLOT == 2) return search_layer0_bytes_ip_sem1_asm2(iv, w, cx, rs, n_dist, n_hops, status);
+        else return search_layer0_bytes_ip_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+    }
+}
+// byte rows under the inner product, Ohnsw rule (the L2 instantiations are called by name in search_layer)
+template <int NSLOT>
+__device__ __forceinline__ void search_layer0_bytes_ip_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx,
+                                                           uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+    if constexpr (NSLOT == 1) search_layer0_bytes_ip_asm1(iv, w, cx, n_dist, n_hops, status);
+    else if constexpr (NSLOT == 2) search_layer0_bytes_ip_asm2(iv, w, cx, n_dist, n_hops, status);
+    else search_layer0_bytes_ip_asm4(iv, w, cx, n_dist, n_hops, status);
 }
 template <int NSLOT, int METRIC, int ROWS>
 __device__ __forceinline__ bool search_layer0_f32_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,

@@ -79,6 +79,27 @@ def test_functor_rule_through_the_loops(H, oracle, levels, d):
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor levels %d d %d ef %d" % (levels, d, ef))
 
 
+@pytest.mark.parametrize("levels", [2, 6, 40])
+@pytest.mark.parametrize("d", [70, 128])
+def test_inner_product_on_byte_rows_through_the_loops(H, oracle, levels, d):
+    """byte rows under the inner product (distance 1 - <x, q>: large negative integers here): the dot-product block without the
+    x.x term and the sign-flipped key, both accept rules, every slot count"""
+    rng = np.random.default_rng(500 * levels + d)
+    n = 5000
+    X = rng.integers(0, levels, size=(n, d)).astype(np.float32)
+    X[rng.integers(0, n, 300)] = X[rng.integers(0, n, 300)]
+    Q = rng.integers(0, levels, size=(150, d)).astype(np.float32)
+    Q[:10] = X[:10]
+    Q[10] = 0.0                                                            # every distance 1.0: one huge tie
+    sp = oracle.Space.ip(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 12, 60, seed=3)
+    hg = H.Hgraph(X, g.deg0, g.nbr0, g.upper, entry_point=g.entry_point, id_base=0, max_degree=12, metric=1)
+    assert hg.to_device(0).row_bytes() == d
+    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (128, 10), (129, 20), (256, 256)):
+        _check(H, oracle, hg, g, sp, Q, ef, k, "ip levels %d d %d ef %d" % (levels, d, ef))
+        _check_functor(H, oracle, hg, g, sp, Q, ef, k, "ip functor levels %d d %d ef %d" % (levels, d, ef))
+
+
 def test_wide_rows_and_long_lists(H, oracle):
     """M = 32: layer-0 rows of 64 neighbours, fresh lists longer than one 16-row round, all four batch shapes."""
     rng = np.random.default_rng(7)
