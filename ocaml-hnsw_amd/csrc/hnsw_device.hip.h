@@ -1012,9 +1012,9 @@ __device__ __forceinline__ void hop_eval(const IndexView &iv, const float4 (&qv)
 }
 
 // What a hand-scheduled loop instantiated for the functor rule (hnsw_hop_loop.inc, HNSW_LOOP_SEM 1) hands back when it leaves a
-// hop in the middle: the candidates of the current round not yet dealt with (`pass`: lanes of ckey / cid1 = id + 1), and how
-// many of the hop's `total` fresh neighbours have not been evaluated yet.
-struct HopResume { uint64_t pass; uint32_t ckey, cid1; int total, remaining; };
+// hop in the middle: the candidates of the current round not yet dealt with (`pass`: lanes of ckey / cid1 = id + 1), how
+// many of the hop's `total` fresh neighbours have not been evaluated yet, and (split rows) the node being expanded.
+struct HopResume { uint64_t pass; uint32_t ckey, cid1; int total, remaining, node; };
 
 } // namespace hnsw_dev
 #include "hnsw_hop_asm.hip.h"
@@ -1045,14 +1045,14 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
 #if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING)
     // The hand-scheduled loops (hnsw_hop_asm.hip.h), same results.  ASM_B8: d <= 128 byte rows and a byte-valued query (L2: the
-    // headline shape; inner product), ef <= 64 / 65..128 / 129..256; ASM_F32: float32 rows of 65..128 dimensions (17..32 chunks), either metric.
+    // headline shape; inner product), ef <= 64 / 65..128 / 129..256; ASM_F32: float32 rows of 65..128 dimensions (17..32 chunks), full, ragged or split, either metric.
     // (The blocks form the byte offset (id + 1) * S0 * 4 + lane * 4 of an adjacency row in 32 bits, one row ahead of the node
     // they fetch: the row AFTER the last node's must still be below 2^32 bytes whatever S0 is; and they restore EXEC with
     // s_mov_b64 exec, -1: they are entered with all 64 lanes on -- the kernel runs one full wave per query and reaches this
     // point through wave-uniform branches only.  A query whose tie list went to the global slab keeps the C++ loop.)
     constexpr bool ASM_SLOTS = NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4);
     constexpr bool ASM_B8 = ASM_SLOTS && ROWS == 2;
-    constexpr bool ASM_F32 = HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1);
+    constexpr bool ASM_F32 = HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT));
     bool asm_ok = false;
     if constexpr (ASM_B8 || ASM_F32) {
         asm_ok = layer == 0 && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30) &&
@@ -1114,7 +1114,10 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
                     }
                 }
                 accept_candidates<NSLOT, SEM>(w, cx, rs.pass, rs.ckey, rs.cid1 - 1u, status, pc);
-                hop_eval<NCH, RB, NSLOT, METRIC, SEM, ROWS>(iv, qv, w, cx, rs.total, status, pc, nullptr, rs.total - rs.remaining);
+                const char *tail_row = nullptr;
+                if constexpr (ROWS == 3)
+                    tail_row = reinterpret_cast<const char *>(iv.tail0) + (uint64_t)(uint32_t)rs.node * (uint32_t)(iv.S0 * 16 * iv.tail_chunks);
+                hop_eval<NCH, RB, NSLOT, METRIC, SEM, ROWS>(iv, qv, w, cx, rs.total, status, pc, tail_row, rs.total - rs.remaining);
                 continue;
             }
         }

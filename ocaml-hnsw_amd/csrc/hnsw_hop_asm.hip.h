@@ -31,6 +31,9 @@ namespace hnsw_dev {
 #ifndef HNSW_ASM_LOOP_F32       /* the float32-row instantiations (0: those shapes keep search_layer's C++ loop) */
 #define HNSW_ASM_LOOP_F32 1
 #endif
+#ifndef HNSW_ASM_LOOP_SPLIT     /* ... and the split-row ones */
+#define HNSW_ASM_LOOP_SPLIT 1
+#endif
 #ifndef HNSW_ASM_LOOP_SEM1      /* the instantiations for the functor accept rule (0: that rule keeps the C++ loop) */
 #define HNSW_ASM_LOOP_SEM1 1
 #endif
@@ -303,6 +306,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_HOP_ADJACENCY \
         "4:\n\t"                            \
         "s_add_u32 %[nh], %[nh], 1\n\t"     \
+        HNSW_SPLIT_HOP                      \
         "s_cmp_lg_u32 %[kd], %[pref]\n\t"   \
         "s_cbranch_scc1 44f\n\t"            \
         HNSW_ASM_COUNT_HIT                  \
@@ -348,6 +352,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "ds_write_b32 %[va], %[vw]\n\t"                                                \
         "v_lshl_add_u32 %[t0], %[t0], 2, %[cand]\n\t"                                  \
         "ds_write_b32 %[t0], %[nb]\n\t"                                                \
+        HNSW_SPLIT_COMPACT                                                             \
         "s_mov_b64 exec, -1\n\t"                                                       \
         "s_add_u32 %[nd], %[nd], %[cnt]\n\t"                                           \
         "s_lshl2_add_u32 %[lastad], %[cnt], %[candm4]\n\t"                             \
@@ -925,12 +930,42 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_FX4(B, C) "v[" HNSW_STR(HNSW_F32_BASE) "+" #B "*8+" #C "*4:" HNSW_STR(HNSW_F32_BASE) "+" #B "*8+" #C "*4+3]"
 #define HNSW_F32_CONSTANTS HNSW_HOP_CONSTANTS_X(HNSW_FX(0, 0, 0), HNSW_FX(0, 0, 1), HNSW_FX(0, 0, 2), "")
 // row address (one 64-bit multiply-add) and the row's two float4 per lane
-#define HNSW_F32_ROW_LOAD(ID, AD, B)                                                     \
+#define HNSW_F32_ROW_LOAD_PLAIN(ID, PJ, AD, B)                                           \
     "v_mad_u64_u32 " AD ", vcc, " ID ", %[st8], %[xl]\n\t"                               \
     "global_load_dwordx4 " HNSW_FX4(B, 0) ", " AD ", off\n\t"                            \
     HNSW_F32_RAG_ON                                                                      \
     "global_load_dwordx4 " HNSW_FX4(B, 1) ", " AD ", off offset:256\n\t"                 \
     HNSW_F32_RAG_OFF
+// Split rows (hnsw_rows_split.hip: whole-line main rows in Xm, the last one or two chunks of node nbr0[c][j] beside slot (c, j)
+// of the layer-0 adjacency): chunk 0 always lies in the main row; of chunk 1 the lanes below the main row's end read it at
+// +256, the one or two tail lanes read the expanded node's tail row at the candidate's slot PJ (trow = that row's address per
+// lane, less the 256 of the shared offset; computed once per hop, HNSW_SPLIT_HOP_ON), the rest are off.  The address pair is
+// switched per lane between the two tables AFTER the first load has been issued (a load has read its address by then); the
+// pairs are registers named by number (v32..v37: two alternating main pairs and the tail pair), because inline assembly cannot
+// name the halves of a 64-bit operand.
+#define HNSW_SPLIT_AD(B) "v[32+(" #B "&1)*2:33+(" #B "&1)*2]"
+#define HNSW_SPLIT_AD_LO(B) "v[32+(" #B "&1)*2]"
+#define HNSW_SPLIT_AD_HI(B) "v[33+(" #B "&1)*2]"
+#define HNSW_F32_ROW_LOAD_SPLIT(ID, PJ, AD, B)                                           \
+    "v_mad_u64_u32 " HNSW_SPLIT_AD(B) ", vcc, " ID ", %[st8], %[xl]\n\t"                 \
+    "global_load_dwordx4 " HNSW_FX4(B, 0) ", " HNSW_SPLIT_AD(B) ", off\n\t"              \
+    "v_mad_u64_u32 v[36:37], vcc, " PJ ", %[c16t], %[trow]\n\t"                          \
+    "v_cndmask_b32_e64 " HNSW_SPLIT_AD_LO(B) ", " HNSW_SPLIT_AD_LO(B) ", v36, %[tlm]\n\t" \
+    "v_cndmask_b32_e64 " HNSW_SPLIT_AD_HI(B) ", " HNSW_SPLIT_AD_HI(B) ", v37, %[tlm]\n\t" \
+    "s_mov_b64 exec, %[cvm]\n\t"                                                         \
+    "global_load_dwordx4 " HNSW_FX4(B, 1) ", " HNSW_SPLIT_AD(B) ", off offset:256\n\t"   \
+    "s_mov_b64 exec, -1\n\t"
+#define HNSW_SPLIT_CLOBBER , "v32", "v33", "v34", "v35", "v36", "v37"
+// the hop's node (kd = its id + 1) -> the address of its tail row per lane; kept for the hand-over of the functor rule
+#define HNSW_SPLIT_HOP_ON                                                                \
+    "v_mad_u64_u32 %[trow], vcc, %[kd], %[s0tv], %[tbase]\n\t"                           \
+    "s_mov_b32 %[hopn], %[kd]\n\t"
+#define HNSW_SPLIT_COMPACT_ON "ds_write_b32 %[t0], %[lane] offset:256\n\t"   /* cand_key[]: the candidate's slot in the node's row */
+// ids (and, split rows, slots) of a round's batches; lgkmcnt values: one LDS read per batch, two with the slots
+#define HNSW_F32_ID_READ0_PLAIN(ID, PJ, SH) HNSW_ID_READ0(ID, SH)
+#define HNSW_F32_ID_READN_PLAIN(ID, PJ) HNSW_ID_READN(ID)
+#define HNSW_F32_ID_READ0_SPLIT(ID, PJ, SH) HNSW_ID_READ0(ID, SH) "ds_read_b32 " PJ ", %[t0] offset:256\n\t"
+#define HNSW_F32_ID_READN_SPLIT(ID, PJ) HNSW_ID_READN(ID) "ds_read_b32 " PJ ", %[t0] offset:256\n\t"
 // the lane's share of batch B's distance -> HNSW_FX(B, 0, 0)
 #define HNSW_F32_SUB(B, C, K, Q) "v_sub_f32_e32 " HNSW_FX(B, C, K) ", " HNSW_FX(B, C, K) ", " Q "\n\t"
 #define HNSW_F32_SQ(B, C, K) "v_fmac_f32_e32 " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, C, K) ", " HNSW_FX(B, C, K) "\n\t"
@@ -973,12 +1008,12 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_cbranch_scc1 25f\n\t"                                                                                                      \
   /* ---- 8 rows: two batches */                                                                                                      \
         "30:\n\t"                                                                                                                     \
-        HNSW_ID_READ0("%[id0]", 1)                                                                                                    \
-        HNSW_ID_READN("%[id1]")                                                                                                       \
-        "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id0]", "%[ad0]", 0)                                                                                      \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id1]", "%[ad1]", 1)                                                                                      \
+        HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 1)                                                                                                    \
+        HNSW_F32_ID_READN("%[id1]", "%[pj1]")                                                                                                       \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG1 ")\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id0]", "%[pj0]", "%[ad0]", 0)                                                                                      \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id1]", "%[pj1]", "%[ad1]", 1)                                                                                      \
         "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"                                                                        \
         "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
         HNSW_F32_DIST(0)                                                                                                              \
@@ -1001,9 +1036,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_F32_ROUNDS_RARE \
         "25:\n\t"                                                                                                                     \
   /* ---- 4 rows: one batch */                                                                                                        \
-        HNSW_ID_READ0("%[id0]", 0)                                                                                                    \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id0]", "%[ad0]", 0)                                                                                      \
+        HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 0)                                                                                                    \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id0]", "%[pj0]", "%[ad0]", 0)                                                                                      \
         "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
         HNSW_F32_DIST(0)                                                                                                              \
         "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
@@ -1021,18 +1056,18 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_branch 50b\n"                                                                                                              \
   /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
         "40:\n\t"                                                                                                                     \
-        HNSW_ID_READ0("%[id0]", 2)                                                                                                    \
-        HNSW_ID_READN("%[id1]")                                                                                                       \
-        HNSW_ID_READN("%[id2]")                                                                                                       \
-        HNSW_ID_READN("%[id3]")                                                                                                       \
-        "s_waitcnt lgkmcnt(3)\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id0]", "%[ad0]", 0)                                                                                      \
-        "s_waitcnt lgkmcnt(2)\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id1]", "%[ad1]", 1)                                                                                      \
-        "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id2]", "%[ad0]", 2)                                                                                      \
-        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id3]", "%[ad1]", 3)                                                                                      \
+        HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 2)                                                                                                    \
+        HNSW_F32_ID_READN("%[id1]", "%[pj1]")                                                                                                       \
+        HNSW_F32_ID_READN("%[id2]", "%[pj2]")                                                                                                       \
+        HNSW_F32_ID_READN("%[id3]", "%[pj3]")                                                                                                       \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG3 ")\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id0]", "%[pj0]", "%[ad0]", 0)                                                                                      \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG2 ")\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id1]", "%[pj1]", "%[ad1]", 1)                                                                                      \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG1 ")\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id2]", "%[pj2]", "%[ad0]", 2)                                                                                      \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t"                                                                                                    \
+        HNSW_F32_ROW_LOAD("%[id3]", "%[pj3]", "%[ad1]", 3)                                                                                      \
         "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"                                                                        \
         "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"                                                                        \
         "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"                                                                        \
@@ -1198,6 +1233,72 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
 
 // the instantiation for a kernel variant's (slots, metric, row shape)
 template <int NSLOT, int METRIC, int ROWS>
@@ -1208,6 +1309,8 @@ __device__ __forceinline__ void search_layer0_f32_asm(const IndexView &iv, WList
     HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_asm4)
     HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_asm4)
     HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_asm4)
+    HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_asm4)
+    HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_asm4)
 #undef HNSW_F32_CALL
 }
 
@@ -1241,6 +1344,8 @@ __device__ __forceinline__ bool search_layer0_f32_sem1_asm(const IndexView &iv, 
     HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_sem1_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_sem1_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_sem1_asm4)
     HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_sem1_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_sem1_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_sem1_asm4)
     HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_sem1_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_sem1_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_sem1_asm4)
+    HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_sem1_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_sem1_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_sem1_asm4)
+    HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_sem1_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_sem1_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_sem1_asm4)
 #undef HNSW_F32_CALL
     return false;
 }

@@ -1,5 +1,5 @@
 """The hand-scheduled layer-0 loops over FLOAT32 rows (csrc/hnsw_hop_asm.hip.h, "The same loops over FLOAT32 rows": 65..128
-dimensions, L2 and inner product, the Ohnsw accept rule, ef <= 256; full rows d = 125..128 and ragged rows) against the
+dimensions, L2 and inner product, both accept rules, ef <= 256; full rows d = 125..128, ragged rows and split rows) against the
 oracle.  The round of these loops is new text -- row loads, the distance in hop_round's operation order, a reduction that
 pairs lane l with lane l ^ 8, 4, 2, 1 while folding the round's candidates into one register -- so the data here is chosen
 for the arithmetic (values whose sums depend on the order of the additions, squares that underflow, negative zeros,
@@ -92,6 +92,32 @@ def test_ties_everywhere_float_rows(H, oracle, levels, d, metric):
     for ef, k in EFS:
         _check(H, oracle, hg, g, sp, Q, ef, k, "levels %d d %d metric %d ef %d" % (levels, d, metric, ef))
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor levels %d d %d metric %d ef %d" % (levels, d, metric, ef))
+    hg.release()
+
+
+# split rows (csrc/hnsw_rows_split.hip): d = 66 -> 17 chunks (16 in the main row + 1 tail chunk), 70 -> 18 (16 + 2), 100 -> 25 (24 + 1),
+# 104 -> 26 (24 + 2): the loops read the tail chunks from the expanded node's tail row at the candidate's slot
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d", [66, 70, 100, 104])
+@pytest.mark.parametrize("kind", ["ties", "spread"])
+def test_split_rows_through_the_loops(H, oracle, d, metric, kind):
+    rng = np.random.default_rng(7000 + 10 * d + metric)
+    n = 4000
+    if kind == "ties":
+        X = rng.integers(0, 3, size=(n, d)).astype(np.float32) * 0.5
+        Q = rng.integers(0, 3, size=(120, d)).astype(np.float32) * 0.5
+        X[rng.integers(0, n, 200)] = X[rng.integers(0, n, 200)]
+    else:
+        X = (rng.normal(size=(n, d)) * np.exp2(rng.integers(-5, 5, size=(n, d)))).astype(np.float32)
+        Q = (rng.normal(size=(120, d)) * np.exp2(rng.integers(-5, 5, size=(120, d)))).astype(np.float32)
+    Q[:5] = X[:5]
+    sp = _space(oracle, X, metric)
+    g = oracle.build_ohnsw(sp, 12, 60, seed=5)
+    hg = _hgraph(H, X, g, 12, metric, split=1)
+    assert hg.info().row_format == 3                                       # HNSW_ROWS_SPLIT: the format under test is in use
+    for ef, k in EFS:
+        _check(H, oracle, hg, g, sp, Q, ef, k, "split %s metric %d d %d ef %d" % (kind, metric, d, ef))
+        _check_functor(H, oracle, hg, g, sp, Q, ef, k, "split functor %s metric %d d %d ef %d" % (kind, metric, d, ef))
     hg.release()
 
 
