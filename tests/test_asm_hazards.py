@@ -105,6 +105,7 @@ def _asm_kernels(objs):
     want += [("hnsw_search_variants_0_1_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi1ELi2E" % s) for s in (1, 2, 4)]     # the functor rule's instantiations
     want += [("hnsw_search_variants_1_1_0.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi1ELi0E" % s) for s in (2,)]
     want += [("hnsw_search_variants_1_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi2E" % s) for s in (2, 4)]              # byte rows, inner product
+    want += [("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi3E" % s) for s in (4,)]               # split rows (C3's kernel)
     want += [("hnsw_order.hip.o", "hnsw_descent_kernelILi2ELi8ELi0ELi2E")]
     out = []
     for obj, frag in want:

@@ -301,8 +301,8 @@ def check(body, report_limit=50):
 def default_objects():
     b = os.path.join(ROOT, "ocaml-hnsw_amd", "build")
     # the translation units with hand-scheduled code: per accept rule (0 Ohnsw, 1 functor) byte rows L2 / inner product (0_s_2, 1_s_2), float32 rows L2
-    # full / ragged (0_s_1, 0_s_0) and inner product full / ragged (1_s_1, 1_s_0); the descent pre-pass
-    names = ["hnsw_search_variants_%d_%d_%d.o" % (m, sem, r) for sem in (0, 1) for (m, r) in ((0, 2), (1, 2), (0, 1), (0, 0), (1, 1), (1, 0))]
+    # full / ragged / split (0_s_1, 0_s_0, 0_s_3) and inner product (1_s_1, 1_s_0, 1_s_3); the descent pre-pass
+    names = ["hnsw_search_variants_%d_%d_%d.o" % (m, sem, r) for sem in (0, 1) for (m, r) in ((0, 2), (1, 2), (0, 1), (0, 0), (0, 3), (1, 1), (1, 0), (1, 3))]
     return [os.path.join(b, f) for f in names + ["hnsw_order.hip.o"]]
 
 
