@@ -1045,12 +1045,12 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
 #if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING)
     // The hand-scheduled loops (hnsw_hop_asm.hip.h), same results.  ASM_B8: d <= 128 byte rows and a byte-valued query (L2: the
-    // headline shape; inner product), ef <= 64 / 65..128 / 129..256; ASM_F32: float32 rows of 65..128 dimensions (17..32 chunks), full, ragged or split, either metric.
+    // headline shape; inner product), ef <= 64 / 65..128 / 129..256 / 257..512; ASM_F32: float32 rows of 65..128 dimensions (17..32 chunks), full, ragged or split, either metric.
     // (The blocks form the byte offset (id + 1) * S0 * 4 + lane * 4 of an adjacency row in 32 bits, one row ahead of the node
     // they fetch: the row AFTER the last node's must still be below 2^32 bytes whatever S0 is; and they restore EXEC with
     // s_mov_b64 exec, -1: they are entered with all 64 lanes on -- the kernel runs one full wave per query and reaches this
     // point through wave-uniform branches only.  A query whose tie list went to the global slab keeps the C++ loop.)
-    constexpr bool ASM_SLOTS = NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4);
+    constexpr bool ASM_SLOTS = NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4 || (NSLOT == 8 && HNSW_ASM_LOOP_8SLOTS));
     constexpr bool ASM_B8 = ASM_SLOTS && ROWS == 2;
     constexpr bool ASM_F32 = HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT));
     bool asm_ok = false;
@@ -1065,6 +1065,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         if (asm_ok) {
             if constexpr (NSLOT == 1) { search_layer0_bytes_l2_asm1(iv, w, cx, n_dist, n_hops, status); return; }
             if constexpr (NSLOT == 4) { search_layer0_bytes_l2_asm4(iv, w, cx, n_dist, n_hops, status); return; }
+            if constexpr (NSLOT == 8) { search_layer0_bytes_l2_asm8(iv, w, cx, n_dist, n_hops, status); return; }
             if constexpr (NSLOT == 2) {
 #ifdef HNSW_ASM_DEBUG
 #ifdef HNSW_ASM_DEBUG_HOPS

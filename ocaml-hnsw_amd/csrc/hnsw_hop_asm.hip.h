@@ -34,6 +34,9 @@ namespace hnsw_dev {
 #ifndef HNSW_ASM_LOOP_SPLIT     /* ... and the split-row ones */
 #define HNSW_ASM_LOOP_SPLIT 1
 #endif
+#ifndef HNSW_ASM_LOOP_8SLOTS    /* ... and W in eight registers (ef 257..512) */
+#define HNSW_ASM_LOOP_8SLOTS 1
+#endif
 #ifndef HNSW_ASM_LOOP_SEM1      /* the instantiations for the functor accept rule (0: that rule keeps the C++ loop) */
 #define HNSW_ASM_LOOP_SEM1 1
 #endif
@@ -809,6 +812,13 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     HNSW_EVICT_TIE("150", "801b", "%[l3]", "160")                                                                                                       \
     HNSW_EVICT_TIE("154", "141b", "%[l3]", "164")
 
+// Eight slots (ef 257..512): the same structure, written by tools/gen_hop_slots.py (the generator reproduces the four-slot text
+// above instruction for instruction; a test compares them)
+#include "hnsw_hop_slots8.inc"
+#ifndef HNSW_ASM_ALIGN_PAD8
+#define HNSW_ASM_ALIGN_PAD8 6
+#endif
+
 #define HNSW_LOOP_NAME search_layer0_bytes_l2_asm4
 #define HNSW_LOOP_NSLOT 4
 #define HNSW_LOOP_ROWS 2
@@ -827,6 +837,28 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #include "hnsw_hop_loop.inc"
 #define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm4
 #define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
 #define HNSW_LOOP_ROWS 2
 #define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
@@ -1299,18 +1331,84 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
 
 // the instantiation for a kernel variant's (slots, metric, row shape)
 template <int NSLOT, int METRIC, int ROWS>
 __device__ __forceinline__ void search_layer0_f32_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[2],
                                                       uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
 #define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
-    HNSW_F32_CALL(1, 0, 1, search_layer0_f32_l2_full_asm1)   HNSW_F32_CALL(2, 0, 1, search_layer0_f32_l2_full_asm2)   HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_asm4)
-    HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_asm4)
-    HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_asm4)
-    HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_asm4)
-    HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_asm4)
-    HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_asm4)
+    HNSW_F32_CALL(1, 0, 1, search_layer0_f32_l2_full_asm1)   HNSW_F32_CALL(2, 0, 1, search_layer0_f32_l2_full_asm2)   HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_asm4) HNSW_F32_CALL(8, 0, 1, search_layer0_f32_l2_full_asm8)
+    HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_asm4) HNSW_F32_CALL(8, 0, 0, search_layer0_f32_l2_ragged_asm8)
+    HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_asm4) HNSW_F32_CALL(8, 1, 1, search_layer0_f32_ip_full_asm8)
+    HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_asm4) HNSW_F32_CALL(8, 1, 0, search_layer0_f32_ip_ragged_asm8)
+    HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_asm4) HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_asm8)
+    HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_asm4) HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_asm8)
 #undef HNSW_F32_CALL
 }
 
@@ -1321,11 +1419,13 @@ __device__ __forceinline__ bool search_layer0_bytes_sem1_asm(const IndexView &iv
     if constexpr (METRIC == 0) {
         if constexpr (NSLOT == 1) return search_layer0_bytes_l2_sem1_asm1(iv, w, cx, rs, n_dist, n_hops, status);
         else if constexpr (NSLOT == 2) return search_layer0_bytes_l2_sem1_asm2(iv, w, cx, rs, n_dist, n_hops, status);
-        else return search_layer0_bytes_l2_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+        else if constexpr (NSLOT == 4) return search_layer0_bytes_l2_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+        else return search_layer0_bytes_l2_sem1_asm8(iv, w, cx, rs, n_dist, n_hops, status);
     } else {
         if constexpr (NSLOT == 1) return search_layer0_bytes_ip_sem1_asm1(iv, w, cx, rs, n_dist, n_hops, status);
         else if constexpr (NSLOT == 2) return search_layer0_bytes_ip_sem1_asm2(iv, w, cx, rs, n_dist, n_hops, status);
-        else return search_layer0_bytes_ip_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+        else if constexpr (NSLOT == 4) return search_layer0_bytes_ip_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+        else return search_layer0_bytes_ip_sem1_asm8(iv, w, cx, rs, n_dist, n_hops, status);
     }
 }
 // byte rows under the inner product, Ohnsw rule (the L2 instantiations are called by name in search_layer)
@@ -1334,18 +1434,19 @@ __device__ __forceinline__ void search_layer0_bytes_ip_asm(const IndexView &iv, 
                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
     if constexpr (NSLOT == 1) search_layer0_bytes_ip_asm1(iv, w, cx, n_dist, n_hops, status);
     else if constexpr (NSLOT == 2) search_layer0_bytes_ip_asm2(iv, w, cx, n_dist, n_hops, status);
-    else search_layer0_bytes_ip_asm4(iv, w, cx, n_dist, n_hops, status);
+    else if constexpr (NSLOT == 4) search_layer0_bytes_ip_asm4(iv, w, cx, n_dist, n_hops, status);
+    else search_layer0_bytes_ip_asm8(iv, w, cx, n_dist, n_hops, status);
 }
 template <int NSLOT, int METRIC, int ROWS>
 __device__ __forceinline__ bool search_layer0_f32_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
                                                            const float4 (&qv)[2], uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
 #define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
-    HNSW_F32_CALL(1, 0, 1, search_layer0_f32_l2_full_sem1_asm1)   HNSW_F32_CALL(2, 0, 1, search_layer0_f32_l2_full_sem1_asm2)   HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_sem1_asm4)
-    HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_sem1_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_sem1_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_sem1_asm4)
-    HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_sem1_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_sem1_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_sem1_asm4)
-    HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_sem1_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_sem1_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_sem1_asm4)
-    HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_sem1_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_sem1_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_sem1_asm4)
-    HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_sem1_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_sem1_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_sem1_asm4)
+    HNSW_F32_CALL(1, 0, 1, search_layer0_f32_l2_full_sem1_asm1)   HNSW_F32_CALL(2, 0, 1, search_layer0_f32_l2_full_sem1_asm2)   HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_sem1_asm4) HNSW_F32_CALL(8, 0, 1, search_layer0_f32_l2_full_sem1_asm8)
+    HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_sem1_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_sem1_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_sem1_asm4) HNSW_F32_CALL(8, 0, 0, search_layer0_f32_l2_ragged_sem1_asm8)
+    HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_sem1_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_sem1_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_sem1_asm4) HNSW_F32_CALL(8, 1, 1, search_layer0_f32_ip_full_sem1_asm8)
+    HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_sem1_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_sem1_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_sem1_asm4) HNSW_F32_CALL(8, 1, 0, search_layer0_f32_ip_ragged_sem1_asm8)
+    HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_sem1_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_sem1_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_sem1_asm4) HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_sem1_asm8)
+    HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_sem1_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_sem1_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_sem1_asm4) HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_sem1_asm8)
 #undef HNSW_F32_CALL
     return false;
 }

@@ -46,7 +46,7 @@ def test_ties_everywhere_every_slot_count(H, oracle, levels, d):
     g = oracle.build_ohnsw(sp, 12, 60, seed=3)
     hg = _hgraph(H, X, g, 12)
     assert hg.to_device(0).row_bytes() == d                                # byte rows: the loops under test run
-    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256)):
+    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256), (257, 10), (400, 400), (512, 64)):
         _check(H, oracle, hg, g, sp, Q, ef, k, "levels %d d %d ef %d" % (levels, d, ef))
 
 
@@ -75,7 +75,7 @@ def test_functor_rule_through_the_loops(H, oracle, levels, d):
     g = oracle.build_ohnsw(sp, 12, 60, seed=3)
     hg = _hgraph(H, X, g, 12)
     assert hg.to_device(0).row_bytes() == d
-    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256)):
+    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256), (257, 10), (400, 400), (512, 64)):
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor levels %d d %d ef %d" % (levels, d, ef))
 
 
@@ -95,7 +95,7 @@ def test_inner_product_on_byte_rows_through_the_loops(H, oracle, levels, d):
     g = oracle.build_ohnsw(sp, 12, 60, seed=3)
     hg = H.Hgraph(X, g.deg0, g.nbr0, g.upper, entry_point=g.entry_point, id_base=0, max_degree=12, metric=1)
     assert hg.to_device(0).row_bytes() == d
-    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (128, 10), (129, 20), (256, 256)):
+    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (128, 10), (129, 20), (256, 256), (300, 300), (512, 10)):
         _check(H, oracle, hg, g, sp, Q, ef, k, "ip levels %d d %d ef %d" % (levels, d, ef))
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "ip functor levels %d d %d ef %d" % (levels, d, ef))
 
@@ -110,12 +110,12 @@ def test_wide_rows_and_long_lists(H, oracle):
     sp = oracle.Space.l2(X, arith=oracle.TREE16)
     g = oracle.build_ohnsw(sp, 32, 80, seed=1)
     hg = _hgraph(H, X, g, 32)
-    for ef, k in ((48, 10), (128, 10), (250, 50)):
+    for ef, k in ((48, 10), (128, 10), (250, 50), (500, 100)):
         _check(H, oracle, hg, g, sp, Q, ef, k, "M 32 ef %d" % ef)
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor M 32 ef %d" % ef)
 
 
-@pytest.mark.parametrize("ef", [64, 128, 256])
+@pytest.mark.parametrize("ef", [64, 128, 256, 512])
 def test_tie_list_overflow_through_the_loops(H, oracle, ef):
     """The scenario of test_tie_overflow_beyond_lds_stack with byte-valued 128-dimensional vectors, sized per slot
     count: ef - 1 identical "shell" points fill W behind the far entry node; a chain of ever closer points then evicts
@@ -188,7 +188,7 @@ def test_random_configurations_of_the_loop_shapes(H, oracle):
         d = int(rng.integers(65, 129))
         M = int(rng.choice([2, 4, 8, 16, 32]))
         levels = int(rng.choice([2, 4, 16, 219]))
-        ef = int(rng.choice([1, 3, 30, 63, 64, 65, 90, 127, 128, 129, 191, 255, 256]))
+        ef = int(rng.choice([1, 3, 30, 63, 64, 65, 90, 127, 128, 129, 191, 255, 256, 257, 300, 511, 512]))
         k = int(rng.integers(1, min(ef, 100) + 1))
         X = rng.integers(0, levels, size=(n, d)).astype(np.float32)
         Q = rng.integers(0, levels, size=(20, d)).astype(np.float32)

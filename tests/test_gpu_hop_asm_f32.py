@@ -50,7 +50,7 @@ def _check_functor(H, oracle, hg, g, sp, Q, ef, k, ctx=""):
     assert (gnd > 0).all() and (gnh > 0).all(), ctx
 
 
-EFS = ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256))
+EFS = ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256), (257, 10), (400, 400), (512, 64))
 
 
 # d: 68 = 17 chunks (one lane of the second chunk), 76 = 19, 100 = 25, 123 = 31 chunks with a partial last one, 125 = full rows
@@ -148,13 +148,13 @@ def test_wide_rows_and_long_lists_float_rows(H, oracle, metric):
     sp = _space(oracle, X, metric)
     g = oracle.build_ohnsw(sp, 32, 80, seed=1)
     hg = _hgraph(H, X, g, 32, metric)
-    for ef, k in ((48, 10), (128, 10), (250, 50)):
+    for ef, k in ((48, 10), (128, 10), (250, 50), (500, 100)):
         _check(H, oracle, hg, g, sp, Q, ef, k, "M 32 metric %d ef %d" % (metric, ef))
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor M 32 metric %d ef %d" % (metric, ef))
     hg.release()
 
 
-@pytest.mark.parametrize("ef", [64, 128, 256])
+@pytest.mark.parametrize("ef", [64, 128, 256, 512])
 def test_tie_list_overflow_through_the_float_loops(H, oracle, ef):
     """test_gpu_hop_asm.py::test_tie_list_overflow_through_the_loops on float32 rows: shells tied at the maximum are evicted
     unexpanded one by one; beyond 64 of them the query is flagged and the host entry point searches it again."""
@@ -211,7 +211,7 @@ def test_random_configurations_of_the_float_loop_shapes(H, oracle):
         M = int(rng.choice([2, 4, 8, 16, 32]))
         metric = int(rng.integers(0, 2))
         kind = int(rng.integers(0, 3))
-        ef = int(rng.choice([1, 3, 30, 63, 64, 65, 90, 127, 128, 129, 191, 255, 256]))
+        ef = int(rng.choice([1, 3, 30, 63, 64, 65, 90, 127, 128, 129, 191, 255, 256, 257, 300, 511, 512]))
         k = int(rng.integers(1, min(ef, 100) + 1))
         if kind == 0:
             X = rng.normal(size=(n, d)).astype(np.float32); Q = rng.normal(size=(20, d)).astype(np.float32)
