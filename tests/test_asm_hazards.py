@@ -106,6 +106,7 @@ def _asm_kernels(objs):
     want += [("hnsw_search_variants_1_1_0.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi1ELi0E" % s) for s in (2,)]
     want += [("hnsw_search_variants_1_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi2E" % s) for s in (2, 4)]              # byte rows, inner product
     want += [("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi3E" % s) for s in (4,)]               # split rows (C3's kernel)
+    want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi8ELi0ELi0ELi0E")]                                    # eight slots (C5's kernel)
     want += [("hnsw_order.hip.o", "hnsw_descent_kernelILi2ELi8ELi0ELi2E")]
     out = []
     for obj, frag in want:
@@ -139,6 +140,46 @@ def _owned_nops(body):
             continue
         out.append(i)
     return out
+
+
+def test_generated_insertion_is_current_and_equals_the_hand_written_one():
+    """csrc/hnsw_hop_slots8.inc is what tools/gen_hop_slots.py writes, and the generator, asked for FOUR slots, reproduces the
+    hand-written HNSW_INSERT_LOOP4 / HNSW_INSERT_RARE4 of hnsw_hop_asm.hip.h instruction for instruction"""
+    import re
+    spec = importlib.util.spec_from_file_location("gen_hop_slots", os.path.join(ROOT, "tools", "gen_hop_slots.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.main(["--check"]) == 0
+
+    def body(text, name):
+        i = text.index("#define %s " % name)
+        out = []
+        for ln in text[i:].split("\n"):
+            out.append(ln)
+            if not ln.rstrip().endswith("\\"):
+                break
+        b = "\n".join(out)
+        b = re.sub(r"/\*.*?\*/", "", b[b.index(name) + len(name):], flags=re.S)
+        return b.replace("\\\n", "\n")
+
+    def instructions(b):
+        text = ""
+        for t in re.findall(r'"(?:[^"\\]|\\.)*"|HNSW_[A-Z0-9_]+(?:\([^)]*\))?', b):
+            if t.startswith('"'):
+                text += bytes(t[1:-1], "utf-8").decode("unicode_escape")
+            elif t == "HNSW_DPP_ALL":
+                text += " row_mask:0xf bank_mask:0xf"
+            elif t == "HNSW_SEM_REJECT":
+                text += "18f"
+            else:
+                text += "\n" + re.sub(r"\s+", " ", t) + "\n"
+        return [x.strip() for x in text.split("\n") if x.strip()]
+
+    hand = open(os.path.join(ROOT, "ocaml-hnsw_amd", "csrc", "hnsw_hop_asm.hip.h")).read()
+    four = gen.text(4)
+    for name in ("HNSW_INSERT_LOOP4", "HNSW_INSERT_RARE4"):
+        a, b = instructions(body(hand, name)), instructions(body(four, name))
+        assert len(a) > 20 and a == b, name
 
 
 def test_a_deleted_wait_state_is_noticed(objects):
