@@ -926,6 +926,13 @@ def main():
                                                                     "waves/SIMD and 1-8 batches in flight: tools/gather_ceiling.hip, profiles/r04_gather_ceiling.txt"})
             except Exception as e:
                 others["C5"] = {"skipped": "failed: %r" % (e,)}
+            try:     # ... and C5's shape on clustered vectors (recall at ef 512 then means something for the L2 path at 10 M too)
+                if args.no_clustered:
+                    raise RuntimeError("--no-clustered")
+                others["C5_clustered"] = other_config("C5 DEEP10M shape, clustered", 10_000_000, 96, 0, 32, 200, 512, 10, 13, 100,
+                                                      {"TBps": 6.44, "what": "as C5"}, kind="clustered")
+            except Exception as e:
+                others["C5_clustered"] = {"skipped": "failed: %r" % (e,)}
 
     # ---- C1 (BASELINE.json configs[0]: the reference's own CPU-runnable case -- 10 k random fp32 vectors, d = 32, M 8,
     #      efConstruction 100, ef 32, k 10, 1000 queries): the CPU restatement does the whole of it, build included (the
