@@ -531,11 +531,15 @@ __device__ __forceinline__ void wlist_mark_expanded(WList<NSLOT> &w, int index, 
 // bits spread as well as a hash would, and no multiply sits in front of the LDS read).  The host
 // sizes the cache so that (n-1) div #sets < 0xFFFF: the value 0xFFFF marks an empty way and never
 // equals a real tag.  A miss for a node already evaluated is harmless -- see the header comment.
+#ifndef HNSW_VT_THREE_WAYS
+#define HNSW_VT_THREE_WAYS 1
+#endif
 struct WaveCtx {
     int lane, r, l16;
     uint32_t *vt;        // visited cache, 1 << (vt_bits - 1) words
     uint32_t set_mask;   // #sets - 1
     int set_bits;        // vt_bits - 1
+    uint32_t tag_shift;  // 16: two 16-bit tags per word; 10: three 10-bit tags (visited_three_ways)
     int vt_words;
     int32_t *cand_id;    // [64]
     uint32_t *cand_key;  // [64]
@@ -554,6 +558,7 @@ __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane
     cx.lane = lane; cx.r = lane >> 4; cx.l16 = lane & 15;
     cx.vt = lds;
     cx.set_bits = vt_bits - 1;
+    cx.tag_shift = 16;
     cx.set_mask = (1u << (vt_bits - 1)) - 1u;
     cx.vt_words = 1 << (vt_bits - 1);
     uint32_t *rest = lds + cx.vt_words;
@@ -570,13 +575,23 @@ __device__ __forceinline__ void visited_clear(const WaveCtx &cx) { // Visited.cl
 __device__ __forceinline__ bool visited_mem(const WaveCtx &cx, uint32_t id, uint32_t &word) {
     word = cx.vt[id & cx.set_mask];
     const uint32_t tag = id >> cx.set_bits;
-    return (word & 0xFFFFu) == tag || (word >> 16) == tag;
+    if (cx.tag_shift == 16) return (word & 0xFFFFu) == tag || (word >> 16) == tag;
+    return (word & 0x3FFu) == tag || ((word >> 10) & 0x3FFu) == tag || ((word >> 20) & 0x3FFu) == tag;
+}
+// Three ways per set where the tags are short enough: with n nodes and 2^set_bits sets a tag has bits(n - 1) - set_bits bits; at most
+// 10 of them (and never the all-ones value, which marks an empty way) -> three tags per word, the same LDS holds half as many
+// tags again.  Worth it where a walk visits several times the cache's capacity (large ef): on clustered data a 2-way cache of
+// 2^12 tags re-evaluates 31 % (ef 256, 5 k nodes visited; tools/visited_cache_sim.py), three ways 12 %.  The knn kernels with
+// W in four or eight registers switch it on when the index is small enough; everything else keeps two ways (one SDWA compare
+// per way in the hand-scheduled loops).
+__device__ __forceinline__ void visited_three_ways(WaveCtx &cx, int32_t n) {
+    if (n > 0 && ((uint32_t)(n - 1) >> cx.set_bits) < 0x3FFu) cx.tag_shift = 10;
 }
 // Visited.add (lib/ohnsw.ml:260) for all lanes at once: the new tag enters way 0, way 0 moves to
 // way 1; lanes with on == false store to the scratch sink (no branch)
 __device__ __forceinline__ void visited_add_masked(const WaveCtx &cx, uint32_t id, uint32_t word, bool on) {
     uint32_t *slot = on ? &cx.vt[id & cx.set_mask] : &cx.trash[cx.lane];
-    *slot = (word << 16) | (id >> cx.set_bits);
+    *slot = (word << cx.tag_shift) | (id >> cx.set_bits);
 }
 
 // neighbour row of node c on `layer` (Graph.adjacent, lib/ohnsw.ml:171); -1 = hole / padding
@@ -1181,7 +1196,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
             __syncthreads();
             if (fresh) {                                                 // Visited.add, :572
-                cx.vt[(uint32_t)nb & cx.set_mask] = (vword << 16) | ((uint32_t)nb >> cx.set_bits);
+                cx.vt[(uint32_t)nb & cx.set_mask] = (vword << cx.tag_shift) | ((uint32_t)nb >> cx.set_bits);
                 cx.cand_id[pos] = nb;
                 if (ROWS == 3) cx.cand_key[pos] = (uint32_t)lane;        // split rows: where in c's row (= in its tail row) the candidate sits
             }
@@ -1294,6 +1309,9 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     if (a.q_limit && (q < 0 || q >= a.q_limit)) return;     // never follow a bad map entry into memory
     WaveCtx cx = make_ctx(lds, a.vt_bits, lane);
     if (a.ovf_g) { cx.ovf.g = a.ovf_g + (int64_t)blockIdx.x * a.ovf_gcap; cx.ovf.gcap = a.ovf_gcap; }
+#if HNSW_VT_THREE_WAYS
+    if constexpr (NSLOT >= 4) visited_three_ways(cx, iv.n);      // ef > 128: the walk visits several times what the cache holds
+#endif
     // Issue priority inside an ordered launch (blocks run the walks predicted longest first): the launch ends with its
     // longest walk or with the last of the late starters (the blocks that had to wait for a free slot), so those two ends
     // of the order are issued ahead of the waves they share a SIMD with; the middle has slack (C2, 10 k queries: 0.38 ->

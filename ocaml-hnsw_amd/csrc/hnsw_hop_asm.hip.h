@@ -337,13 +337,38 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_lshrrev_b32_e32 %[tag], %[setb], %[nb]\n\t"                         \
         "v_cmp_lt_i32_e32 vcc, -1, %[nb]\n\t"                                  
 
+// The cache's ways (visited_three_ways, hnsw_device.hip.h): the one- and two-slot loops always run two 16-bit ways; the four- and
+// eight-slot loops (ef > 128) take three 10-bit ways when the index is small enough -- a uniform branch on the shift (16 | 10) to
+// the three-field compare behind the loop (label 96, HNSW_VT_RUNTIME_RARE), which comes back at 97
+#define HNSW_VT_TWO_WAYS_TEST
+#define HNSW_VT_TWO_WAYS_JOIN "\t"
+#define HNSW_VT_TWO_WAYS_SHIFT "16"
+#define HNSW_VT_TWO_WAYS_RARE
+#define HNSW_VT_RUNTIME_TEST                                                             \
+        "s_cmp_lg_u32 %[tsh], 16\n\t"                                                    \
+        "s_cbranch_scc1 96f\n\t"
+#define HNSW_VT_RUNTIME_JOIN "97:\n\t"
+#define HNSW_VT_RUNTIME_SHIFT "%[tsh]"
+#define HNSW_VT_RUNTIME_RARE                                                             \
+        "96:\n\t"                                                                        \
+        "v_bfe_u32 %[t0], %[vw], 0, 10\n\t"                                              \
+        "v_cmp_ne_u32_e64 %[um0], %[t0], %[tag]\n\t"                                     \
+        "v_bfe_u32 %[t0], %[vw], 10, 10\n\t"                                             \
+        "v_cmp_ne_u32_e64 %[um1], %[t0], %[tag]\n\t"                                     \
+        "s_and_b64 %[fresh], %[um0], %[um1]\n\t"                                         \
+        "v_bfe_u32 %[t0], %[vw], 20, 10\n\t"                                             \
+        "v_cmp_ne_u32_e64 %[um0], %[t0], %[tag]\n\t"                                     \
+        "s_and_b64 %[fresh], %[fresh], %[um0]\n\t"                                       \
+        "s_branch 97b\n"
 // visited filter, second half: 2-way compare -> fresh; nothing fresh: next hop (1b); Visited.add (:572) and the list of
 // fresh neighbours in row order; the round variables
 #define HNSW_HOP_FILTER_COMPACT \
         "s_waitcnt lgkmcnt(0)\n\t"                                                     \
+        HNSW_VT_WAYS_TEST                                                              \
         "v_cmp_ne_u32_sdwa %[um0], %[vw], %[tag] src0_sel:WORD_0 src1_sel:DWORD\n\t"   \
         "v_cmp_ne_u32_sdwa %[um1], %[vw], %[tag] src0_sel:WORD_1 src1_sel:DWORD\n\t"   \
-        "s_and_b64 %[fresh], %[um0], %[um1]\n\t"                                       \
+        "s_and_b64 %[fresh], %[um0], %[um1]\n"                                         \
+        HNSW_VT_WAYS_JOIN                                                              \
         "s_and_b64 %[fresh], %[fresh], vcc\n\t"                                        \
         "s_cbranch_scc0 1b\n\t"  /* nothing fresh: next hop */                         \
   /* Visited.add (:572) and the list of fresh neighbours, in row order */              \
@@ -351,7 +376,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_mov_b64 exec, %[fresh]\n\t"                                                 \
         "v_mbcnt_lo_u32_b32 %[t0], exec_lo, 0\n\t"  /* exec is the fresh mask here */  \
         "v_mbcnt_hi_u32_b32 %[t0], exec_hi, %[t0]\n\t"                                 \
-        "v_lshl_or_b32 %[vw], %[vw], 16, %[tag]\n\t"                                   \
+        "v_lshl_or_b32 %[vw], %[vw], " HNSW_VT_SHIFT ", %[tag]\n\t"                     \
         "ds_write_b32 %[va], %[vw]\n\t"                                                \
         "v_lshl_add_u32 %[t0], %[t0], 2, %[cand]\n\t"                                  \
         "ds_write_b32 %[t0], %[nb]\n\t"                                                \

@@ -142,6 +142,38 @@ def _owned_nops(body):
     return out
 
 
+def test_labels_are_unique_within_every_block(tmp_path):
+    """The blocks use numeric local labels and assume each is defined once per asm statement ("66f" must mean THE 66): the
+    preprocessed text of one translation unit holds every instantiation (they are inline functions of a header); a label
+    defined twice in one statement -- an eight-slot pop label reused by a later addition, say -- fails here, not on the GPU."""
+    import re
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "pp.ii")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-DHNSW_V_METRIC=0", "-DHNSW_V_SEMF=0",
+                    "-DHNSW_V_FULL=0", "--cuda-device-only", "-E", "-P", os.path.join(ROOT, "ocaml-hnsw_amd", "csrc", "hnsw_search_variants.hip"),
+                    "-o", out], check=True, capture_output=True)
+    text = open(out).read()
+    blocks = []
+    for m in re.finditer(r"asm volatile\(", text):
+        j, body = m.end(), ""
+        while True:
+            mm = re.match(r'\s*"((?:[^"\\]|\\.)*)"', text[j:])
+            if not mm:
+                break
+            body += bytes(mm.group(1), "utf-8").decode("unicode_escape")
+            j += mm.end()
+        if re.search(r"^\s*\d+:", body, flags=re.M):
+            blocks.append(body)
+    assert len(blocks) >= 60, len(blocks)            # 3 x 2 byte-row + 3 x 2 x 2 x 3 float32-row loops per slot count ..., the descent, the island
+    for body in blocks:
+        labels = re.findall(r"^\s*(\d+):", body, flags=re.M)
+        dup = sorted({x for x in labels if labels.count(x) > 1})
+        assert not dup, "labels defined twice in one block: %s" % dup
+
+
 def test_generated_insertion_is_current_and_equals_the_hand_written_one():
     """csrc/hnsw_hop_slots8.inc is what tools/gen_hop_slots.py writes, and the generator, asked for FOUR slots, reproduces the
     hand-written HNSW_INSERT_LOOP4 / HNSW_INSERT_RARE4 of hnsw_hop_asm.hip.h instruction for instruction"""
