@@ -1,10 +1,12 @@
 // hnsw_hop_asm.hip.h -- the layer-0 loop of Ohnsw.search_k (lib/ohnsw.ml:543-588) and the descent above it
 // (Ohnsw.search_one, :492-508), written instruction by instruction for gfx950.
 //
-// Shapes: rows of 65..128 dimensions (NCH = 2), ef <= 64 / 65..128 / 129..256 (W in one / two / four key registers per
-// lane; one loop body per slot count in hnsw_hop_loop.inc, included once per shape):
-//   * byte rows and a byte-valued query (exact integer arithmetic, see hop_round), L2 -- the headline shape; its descent too;
-//   * float32 rows, L2 and inner product, full and ragged rows ("The same loops over FLOAT32 rows" below);
+// Shapes: rows of 65..128 dimensions (NCH = 2), ef <= 64 / 65..128 / 129..256 / 257..512 (W in one / two / four / eight key
+// registers per lane; one loop body per slot count in hnsw_hop_loop.inc, included once per shape; the eight-slot insertion is
+// generated: hnsw_hop_slots8.inc):
+//   * byte rows and a byte-valued query (exact integer arithmetic, see hop_round), L2 -- the headline shape; its descent too --
+//     and inner product;
+//   * float32 rows, L2 and inner product: full, ragged and split rows ("The same loops over FLOAT32 rows" below);
 //   * each of them for the Ohnsw accept rule and for the functor rule (Hnsw_algo.Search: the loop then leaves a hop when an
 //     entry would enter the tie set, see HNSW_LOOP_SEM in hnsw_hop_loop.inc and search_layer).
 // Everything else takes search_layer's C++ loop; the blocks compute exactly what that loop computes (same pops, same
