@@ -1065,18 +1065,23 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     // they fetch: the row AFTER the last node's must still be below 2^32 bytes whatever S0 is; and they restore EXEC with
     // s_mov_b64 exec, -1: they are entered with all 64 lanes on -- the kernel runs one full wave per query and reaches this
     // point through wave-uniform branches only.  A query whose tie list went to the global slab keeps the C++ loop.)
-    constexpr bool ASM_SLOTS = NCH == 2 && (NSLOT == 1 || NSLOT == 2 || NSLOT == 4 || (NSLOT == 8 && HNSW_ASM_LOOP_8SLOTS));
-    constexpr bool ASM_B8 = ASM_SLOTS && ROWS == 2;
+    constexpr bool ASM_NSLOT = NSLOT == 1 || NSLOT == 2 || NSLOT == 4 || (NSLOT == 8 && HNSW_ASM_LOOP_8SLOTS);
+    constexpr bool ASM_SLOTS = NCH == 2 && ASM_NSLOT;
+    constexpr bool ASM_B8N4 = HNSW_ASM_LOOP_BYTES4 && NCH == 4 && ASM_NSLOT && ROWS == 2;      // byte rows of 129..256 dimensions
+    constexpr bool ASM_B8 = (ASM_SLOTS && ROWS == 2) || ASM_B8N4;
     constexpr bool ASM_F32 = HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT));
     bool asm_ok = false;
     if constexpr (ASM_B8 || ASM_F32) {
         asm_ok = layer == 0 && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30) &&
                  (ASM_B8 ? cx.qint != 0 : iv.nchunks > 16);
     }
-    if constexpr (ASM_B8 && SEM == 0 && METRIC == 1) {
+    if constexpr (ASM_B8N4 && SEM == 0) {
+        if (asm_ok) { search_layer0_bytes4_asm<NSLOT, METRIC>(iv, w, cx, n_dist, n_hops, status); return; }
+    }
+    if constexpr (ASM_B8 && !ASM_B8N4 && SEM == 0 && METRIC == 1) {
         if (asm_ok) { search_layer0_bytes_ip_asm<NSLOT>(iv, w, cx, n_dist, n_hops, status); return; }
     }
-    if constexpr (ASM_B8 && SEM == 0 && METRIC == 0) {
+    if constexpr (ASM_B8 && !ASM_B8N4 && SEM == 0 && METRIC == 0) {
         if (asm_ok) {
             if constexpr (NSLOT == 1) { search_layer0_bytes_l2_asm1(iv, w, cx, n_dist, n_hops, status); return; }
             if constexpr (NSLOT == 4) { search_layer0_bytes_l2_asm4(iv, w, cx, n_dist, n_hops, status); return; }
@@ -1117,7 +1122,8 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             if (asm_ok && w.ovf_cnt == 0) {
                 HopResume rs;
                 bool left;
-                if constexpr (ASM_B8) left = search_layer0_bytes_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
+                if constexpr (ASM_B8N4) left = search_layer0_bytes4_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
+                else if constexpr (ASM_B8) left = search_layer0_bytes_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
                 else left = search_layer0_f32_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
                 if (!left) break;
                 pref_id = -1;

@@ -39,6 +39,9 @@ namespace hnsw_dev {
 #ifndef HNSW_ASM_LOOP_8SLOTS    /* ... and W in eight registers (ef 257..512) */
 #define HNSW_ASM_LOOP_8SLOTS 1
 #endif
+#ifndef HNSW_ASM_LOOP_BYTES4    /* ... and byte rows of 129..256 dimensions */
+#define HNSW_ASM_LOOP_BYTES4 1
+#endif
 #ifndef HNSW_ASM_LOOP_SEM1      /* the instantiations for the functor accept rule (0: that rule keeps the C++ loop) */
 #define HNSW_ASM_LOOP_SEM1 1
 #endif
@@ -508,6 +511,138 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_sub_u32 %[cnt], %[cnt], 16\n\t"                                                                                            \
         "s_branch 50b\n"
 
+// ---- the rounds of byte rows of 129..256 dimensions (NCH = 4: four dwords per lane and row at +0, +64, +128, +192; batch b in
+// d[4b .. 4b+3], its sum in d[4b]): the text above with twice the loads and dot products per batch (derived from it mechanically)
+#define HNSW_ROW_LOAD_N4(ID, AD, DA, DB, DC, DD)                                         \
+    "v_mad_u64_u32 " AD ", vcc, " ID ", %[st8], %[xl]\n\t"                               \
+    "global_load_dword " DA ", " AD ", off\n\t"                                          \
+    "global_load_dword " DB ", " AD ", off offset:64\n\t"                                \
+    "global_load_dword " DC ", " AD ", off offset:128\n\t"                               \
+    "global_load_dword " DD ", " AD ", off offset:192\n\t"
+#define HNSW_DOTS_N4(DA, DB, DC, DD, TA)                                                 \
+    "v_dot4_u32_u8 " TA ", " DA ", %[qb0], 0\n\t"                                        \
+    "v_dot4_u32_u8 " DA ", " DA ", " DA ", %[q2v]\n\t"                                   \
+    "v_dot4_u32_u8 " TA ", " DB ", %[qb1], " TA "\n\t"                                   \
+    "v_dot4_u32_u8 " DA ", " DB ", " DB ", " DA "\n\t"                                   \
+    "v_dot4_u32_u8 " TA ", " DC ", %[qb2], " TA "\n\t"                                   \
+    "v_dot4_u32_u8 " DA ", " DC ", " DC ", " DA "\n\t"                                   \
+    "v_dot4_u32_u8 " TA ", " DD ", %[qb3], " TA "\n\t"                                   \
+    "v_dot4_u32_u8 " DA ", " DD ", " DD ", " DA "\n\t"
+#define HNSW_DOTS_IP_N4(DA, DB, DC, DD, TA)                                              \
+    "v_dot4_u32_u8 " TA ", " DA ", %[qb0], 0\n\t"                                        \
+    "v_dot4_u32_u8 " TA ", " DB ", %[qb1], " TA "\n\t"                                   \
+    "v_dot4_u32_u8 " TA ", " DC ", %[qb2], " TA "\n\t"                                   \
+    "v_dot4_u32_u8 " DA ", " DD ", %[qb3], " TA "\n\t"
+#define HNSW_HOP_ROUND_COMMON_N4 \
+        "20:\n\t"                                                                                                                     \
+        "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
+        "s_cbranch_scc1 40f\n\t"                                                                                                      \
+        "s_cmp_lt_u32 %[cnt], 5\n\t"                                                                                                  \
+        "s_cbranch_scc1 25f\n\t"                                                                                                      \
+  /* ---- 8 rows: two batches */                                                                                                      \
+        "30:\n\t"                                                                                                                     \
+        HNSW_ID_READ0("%[id0]", 1)                                                                                                  \
+        HNSW_ID_READN("%[id1]")                                                                                                  \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD_N4("%[id0]", "%[ad0]", "%[d0]", "%[d1]", "%[d2]", "%[d3]")                                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD_N4("%[id1]", "%[ad1]", "%[d4]", "%[d5]", "%[d6]", "%[d7]")                                                                           \
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"                                                                        \
+        "s_waitcnt vmcnt(4)\n\t"                                                                                                      \
+        HNSW_B8_DOTS_N4("%[d0]", "%[d1]", "%[d2]", "%[d3]", "%[ta]")                                                                                          \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_B8_DOTS_N4("%[d4]", "%[d5]", "%[d6]", "%[d7]", "%[tb]")                                                                                          \
+        HNSW_B8_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        "s_nop 2\n\t"                                                                                                                 \
+        HNSW_B8_COMBINE("%[d4]", "%[tb]")                                                                                                \
+        "v_cndmask_b32_e64 %[ta], %[d0], %[d4], %[b3m]\n\t"  /* keep: the sum this half of the group is for */                        \
+        "v_cndmask_b32_e64 %[tb], %[d4], %[d0], %[b3m]\n\t"  /* give: the other half's */                                             \
+        HNSW_ACCEPT_EARLY(1)                                                                                                               \
+        "v_add_u32_dpp %[ta], %[tb], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[ta], %[ta], %[ta] row_half_mirror" HNSW_DPP_BC "\n\t"                                                        \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"                                                    \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[ta], %[ta], %[ta] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
+        HNSW_B8_KEY("%[ta]")                                                                                        \
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 8\n"
+
+#define HNSW_HOP_ROUNDS_RARE_N4 \
+        "25:\n\t"                                                                                                                     \
+  /* ---- 4 rows: one batch */                                                                                                        \
+        HNSW_ID_READ0("%[id0]", 0)                                                                                                  \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD_N4("%[id0]", "%[ad0]", "%[d0]", "%[d1]", "%[d2]", "%[d3]")                                                                           \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_B8_DOTS_N4("%[d0]", "%[d1]", "%[d2]", "%[d3]", "%[ta]")                                                                                          \
+        "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
+        "s_nop 2\n\t"                                                                                                                 \
+        HNSW_B8_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        HNSW_ACCEPT_EARLY(0)                                                                                                   \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:8" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:4" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:2" HNSW_DPP_BC "\n\t"                                                              \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:1" HNSW_DPP_BC "\n\t"                                                              \
+        HNSW_B8_KEY("%[d0]")                                                                                        \
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 4\n\t"                                                                                           \
+        "s_branch 50b\n"                                                                                                              \
+  /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
+        "40:\n\t"                                                                                                                     \
+        HNSW_ID_READ0("%[id0]", 2)                                                                                                  \
+        HNSW_ID_READN("%[id1]")                                                                                                  \
+        HNSW_ID_READN("%[id2]")                                                                                                  \
+        HNSW_ID_READN("%[id3]")                                                                                                  \
+        "s_waitcnt lgkmcnt(3)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD_N4("%[id0]", "%[ad0]", "%[d0]", "%[d1]", "%[d2]", "%[d3]")                                                                           \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD_N4("%[id1]", "%[ad1]", "%[d4]", "%[d5]", "%[d6]", "%[d7]")                                                                           \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD_N4("%[id2]", "%[ad0]", "%[d8]", "%[d9]", "%[d10]", "%[d11]")                                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
+        HNSW_ROW_LOAD_N4("%[id3]", "%[ad1]", "%[d12]", "%[d13]", "%[d14]", "%[d15]")                                                                           \
+        "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"                                                                        \
+        "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"                                                                        \
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"                                                                        \
+        "s_waitcnt vmcnt(12)\n\t"                                                                                                      \
+        HNSW_B8_DOTS_N4("%[d0]", "%[d1]", "%[d2]", "%[d3]", "%[ta]")                                                                                          \
+        "s_waitcnt vmcnt(8)\n\t"                                                                                                      \
+        HNSW_B8_DOTS_N4("%[d4]", "%[d5]", "%[d6]", "%[d7]", "%[tb]")                                                                                          \
+        "s_waitcnt vmcnt(4)\n\t"                                                                                                      \
+        HNSW_B8_COMBINE("%[d0]", "%[ta]")                                                                                                \
+        HNSW_B8_DOTS_N4("%[d8]", "%[d9]", "%[d10]", "%[d11]", "%[ta]")                                                                                          \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
+        HNSW_B8_COMBINE("%[d4]", "%[tb]")                                                                                                \
+        HNSW_B8_DOTS_N4("%[d12]", "%[d13]", "%[d14]", "%[d15]", "%[tb]")                                                                                          \
+        HNSW_B8_COMBINE("%[d8]", "%[ta]")                                                                                                \
+        "s_nop 2\n\t"                                                                                                                 \
+        HNSW_B8_COMBINE("%[d12]", "%[tb]")                                                                                                \
+  /* sums of candidates 0..3 of the group in d0, d2, d4, d6 -> quads of the group's 16 lanes */                                       \
+        "v_cndmask_b32_e64 %[ta], %[d0], %[d8], %[b3m]\n\t"                                                                           \
+        "v_cndmask_b32_e64 %[d1], %[d8], %[d0], %[b3m]\n\t"                                                                           \
+        "v_cndmask_b32_e64 %[tb], %[d4], %[d12], %[b3m]\n\t"                                                                           \
+        "v_cndmask_b32_e64 %[d5], %[d12], %[d4], %[b3m]\n\t"                                                                           \
+        "v_add_u32_dpp %[ta], %[d1], %[ta] row_ror:8" HNSW_DPP_BC "\n\t"  /* candidates 0 | 2 (d1 written three instructions ago) */  \
+        "s_nop 0\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[tb], %[d5], %[tb] row_ror:8" HNSW_DPP_BC "\n\t"  /* candidates 1 | 3 */                                      \
+        "v_cndmask_b32_e64 %[d0], %[ta], %[tb], %[b2m]\n\t"                                                                           \
+        "v_cndmask_b32_e64 %[d1], %[tb], %[ta], %[b2m]\n\t"                                                                           \
+        HNSW_ACCEPT_EARLY(2)                                                                                                                \
+        "v_add_u32_dpp %[d0], %[d1], %[d0] row_half_mirror" HNSW_DPP_BC "\n\t"                                                        \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[1,0,3,2]" HNSW_DPP_BC "\n\t"                                                    \
+        "s_nop 1\n\t"                                                                                                                 \
+        "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
+        HNSW_B8_KEY("%[d0]")                                                                                        \
+        HNSW_ACCEPT_LATE                                                                                                              \
+        "s_sub_u32 %[cnt], %[cnt], 16\n\t"                                                                                            \
+        "s_branch 50b\n"
+
 // labels 90 / 99: no unexpanded member of W: entries evicted while tied with max(W) are still candidates (:568), else done
 #define HNSW_HOP_TAIL \
         "90:\n\t"                                                                   \
@@ -958,6 +1093,112 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #include "hnsw_hop_loop.inc"
 #define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm1
 #define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+
+// byte rows of 129..256 dimensions (NCH = 4)
+#define HNSW_LOOP_NAME search_layer0_bytes4_l2_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_l2_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_l2_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_l2_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_l2_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_l2_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_l2_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_l2_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_ip_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_ip_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_ip_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_ip_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_ip_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_ip_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_ip_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes4_ip_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
 #define HNSW_LOOP_ROWS 2
 #define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
@@ -1437,6 +1678,25 @@ __device__ __forceinline__ void search_layer0_f32_asm(const IndexView &iv, WList
     HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_asm4) HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_asm8)
     HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_asm4) HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_asm8)
 #undef HNSW_F32_CALL
+}
+
+// byte rows of 129..256 dimensions (NCH = 4), both metrics, both rules
+template <int NSLOT, int METRIC>
+__device__ __forceinline__ void search_layer0_bytes4_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx,
+                                                         uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_B4_CALL(NS, M, NAME) if constexpr (NSLOT == NS && METRIC == M) NAME(iv, w, cx, n_dist, n_hops, status);
+    HNSW_B4_CALL(1, 0, search_layer0_bytes4_l2_asm1) HNSW_B4_CALL(2, 0, search_layer0_bytes4_l2_asm2) HNSW_B4_CALL(4, 0, search_layer0_bytes4_l2_asm4) HNSW_B4_CALL(8, 0, search_layer0_bytes4_l2_asm8)
+    HNSW_B4_CALL(1, 1, search_layer0_bytes4_ip_asm1) HNSW_B4_CALL(2, 1, search_layer0_bytes4_ip_asm2) HNSW_B4_CALL(4, 1, search_layer0_bytes4_ip_asm4) HNSW_B4_CALL(8, 1, search_layer0_bytes4_ip_asm8)
+#undef HNSW_B4_CALL
+}
+template <int NSLOT, int METRIC>
+__device__ __forceinline__ bool search_layer0_bytes4_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
+                                                              uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_B4_CALL(NS, M, NAME) if constexpr (NSLOT == NS && METRIC == M) return NAME(iv, w, cx, rs, n_dist, n_hops, status);
+    HNSW_B4_CALL(1, 0, search_layer0_bytes4_l2_sem1_asm1) HNSW_B4_CALL(2, 0, search_layer0_bytes4_l2_sem1_asm2) HNSW_B4_CALL(4, 0, search_layer0_bytes4_l2_sem1_asm4) HNSW_B4_CALL(8, 0, search_layer0_bytes4_l2_sem1_asm8)
+    HNSW_B4_CALL(1, 1, search_layer0_bytes4_ip_sem1_asm1) HNSW_B4_CALL(2, 1, search_layer0_bytes4_ip_sem1_asm2) HNSW_B4_CALL(4, 1, search_layer0_bytes4_ip_sem1_asm4) HNSW_B4_CALL(8, 1, search_layer0_bytes4_ip_sem1_asm8)
+#undef HNSW_B4_CALL
+    return false;
 }
 
 // ... and for the functor rule: true when the loop was left in the middle of a hop (HopResume), false when the search is done

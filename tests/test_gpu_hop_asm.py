@@ -1,5 +1,6 @@
-"""The hand-scheduled layer-0 loops (csrc/hnsw_hop_asm.hip.h: byte rows of 65..128 dimensions, byte-valued queries, L2,
-the Ohnsw accept rule; W in one / two / four key registers per lane = ef <= 64 / 65..128 / 129..256) against the oracle on
+"""The hand-scheduled layer-0 loops (csrc/hnsw_hop_asm.hip.h: byte rows of 65..128 and of 129..256 dimensions, byte-valued
+queries, L2 and inner product, both accept rules; W in one / two / four / eight key registers per lane = ef <= 64 / 65..128 /
+129..256 / 257..512) against the oracle on
 data chosen to drive their seldom-taken paths: exact distance ties everywhere (the general rank with id comparison, the
 "node already in W" check), entries evicted while tied with the new maximum (the tie list in LDS, its pop when W has no
 unexpanded member left, its overflow and the host's exactness fallback), rounds of 1 / 2 / 4 batches and lists longer
@@ -98,6 +99,31 @@ def test_inner_product_on_byte_rows_through_the_loops(H, oracle, levels, d):
     for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (128, 10), (129, 20), (256, 256), (300, 300), (512, 10)):
         _check(H, oracle, hg, g, sp, Q, ef, k, "ip levels %d d %d ef %d" % (levels, d, ef))
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "ip functor levels %d d %d ef %d" % (levels, d, ef))
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("levels", [2, 6, 256])
+@pytest.mark.parametrize("d", [129, 200, 256])
+def test_byte_rows_of_129_to_256_dimensions_through_the_loops(H, oracle, levels, d, metric):
+    """four dwords per lane and row (NCH = 4): twice the loads and dot products per batch, the same loop otherwise; d = 256 with
+    every value 255 against a query of zeros is the largest sum the integer arithmetic may meet (256 * 255^2 < 2^24)"""
+    rng = np.random.default_rng(900 * levels + d + metric)
+    n = 4000
+    X = rng.integers(0, levels, size=(n, d)).astype(np.float32)
+    X[rng.integers(0, n, 200)] = X[rng.integers(0, n, 200)]
+    X[1, :] = float(levels - 1)
+    Q = rng.integers(0, levels, size=(120, d)).astype(np.float32)
+    Q[:8] = X[:8]
+    Q[8] = 0.0
+    Q[9] = float(levels - 1)
+    sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
+    g = oracle.build_ohnsw(sp, 12, 60, seed=3)
+    hg = H.Hgraph(X, g.deg0, g.nbr0, g.upper, entry_point=g.entry_point, id_base=0, max_degree=12, metric=metric)
+    assert hg.to_device(0).row_bytes() == d
+    for ef, k in ((1, 1), (17, 5), (64, 64), (100, 10), (128, 128), (192, 10), (256, 50), (400, 20), (512, 512)):
+        _check(H, oracle, hg, g, sp, Q, ef, k, "n4 metric %d levels %d d %d ef %d" % (metric, levels, d, ef))
+        if ef in (17, 100, 192, 400):
+            _check_functor(H, oracle, hg, g, sp, Q, ef, k, "n4 functor metric %d levels %d d %d ef %d" % (metric, levels, d, ef))
 
 
 def test_wide_rows_and_long_lists(H, oracle):
