@@ -1069,11 +1069,12 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     constexpr bool ASM_SLOTS = NCH == 2 && ASM_NSLOT;
     constexpr bool ASM_B8N4 = HNSW_ASM_LOOP_BYTES4 && NCH == 4 && ASM_NSLOT && ROWS == 2;      // byte rows of 129..256 dimensions
     constexpr bool ASM_B8 = (ASM_SLOTS && ROWS == 2) || ASM_B8N4;
-    constexpr bool ASM_F32 = HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT));
+    constexpr bool ASM_F32N4 = HNSW_ASM_LOOP_F32 && HNSW_ASM_LOOP_F32N4 && NCH == 4 && ASM_NSLOT && (ROWS == 0 || ROWS == 1);   // float32 rows of 129..256 dimensions
+    constexpr bool ASM_F32 = (HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT))) || ASM_F32N4;
     bool asm_ok = false;
     if constexpr (ASM_B8 || ASM_F32) {
         asm_ok = layer == 0 && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30) &&
-                 (ASM_B8 ? cx.qint != 0 : iv.nchunks > 16);
+                 (ASM_B8 ? cx.qint != 0 : iv.nchunks > (ASM_F32N4 ? 32 : 16));
     }
     if constexpr (ASM_B8N4 && SEM == 0) {
         if (asm_ok) { search_layer0_bytes4_asm<NSLOT, METRIC>(iv, w, cx, n_dist, n_hops, status); return; }
@@ -1102,7 +1103,8 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     }
     if constexpr (ASM_F32 && SEM == 0) {
         if (asm_ok) {
-            search_layer0_f32_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status);
+            if constexpr (ASM_F32N4) search_layer0_f32n4_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status);
+            else search_layer0_f32_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status);
             return;
         }
     }
@@ -1124,6 +1126,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
                 bool left;
                 if constexpr (ASM_B8N4) left = search_layer0_bytes4_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
                 else if constexpr (ASM_B8) left = search_layer0_bytes_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
+                else if constexpr (ASM_F32N4) left = search_layer0_f32n4_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
                 else left = search_layer0_f32_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
                 if (!left) break;
                 pref_id = -1;

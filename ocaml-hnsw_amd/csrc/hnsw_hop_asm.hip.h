@@ -42,6 +42,9 @@ namespace hnsw_dev {
 #ifndef HNSW_ASM_LOOP_BYTES4    /* ... and byte rows of 129..256 dimensions */
 #define HNSW_ASM_LOOP_BYTES4 1
 #endif
+#ifndef HNSW_ASM_LOOP_F32N4      /* ... and float32 rows of 129..256 dimensions */
+#define HNSW_ASM_LOOP_F32N4 1
+#endif
 #ifndef HNSW_ASM_LOOP_SEM1      /* the instantiations for the functor accept rule (0: that rule keeps the C++ loop) */
 #define HNSW_ASM_LOOP_SEM1 1
 #endif
@@ -1226,8 +1229,9 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_F32_BASE 40
 #define HNSW_F32_CLOBBER , "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", \
                            "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71"
-#define HNSW_FX(B, C, K) "v[" HNSW_STR(HNSW_F32_BASE) "+" #B "*8+" #C "*4+" #K "]"
-#define HNSW_FX4(B, C) "v[" HNSW_STR(HNSW_F32_BASE) "+" #B "*8+" #C "*4:" HNSW_STR(HNSW_F32_BASE) "+" #B "*8+" #C "*4+3]"
+// (HNSW_FX_BS: registers per batch, "8" for rows of two chunks per lane, "16" for four: set per instantiation in hnsw_hop_loop.inc)
+#define HNSW_FX(B, C, K) "v[" HNSW_STR(HNSW_F32_BASE) "+" #B "*" HNSW_FX_BS "+" #C "*4+" #K "]"
+#define HNSW_FX4(B, C) "v[" HNSW_STR(HNSW_F32_BASE) "+" #B "*" HNSW_FX_BS "+" #C "*4:" HNSW_STR(HNSW_F32_BASE) "+" #B "*" HNSW_FX_BS "+" #C "*4+3]"
 #define HNSW_F32_CONSTANTS HNSW_HOP_CONSTANTS_X(HNSW_FX(0, 0, 0), HNSW_FX(0, 0, 1), HNSW_FX(0, 0, 2), "")
 // row address (one 64-bit multiply-add) and the row's two float4 per lane
 #define HNSW_F32_ROW_LOAD_PLAIN(ID, PJ, AD, B)                                           \
@@ -1266,6 +1270,17 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_F32_ID_READN_PLAIN(ID, PJ) HNSW_ID_READN(ID)
 #define HNSW_F32_ID_READ0_SPLIT(ID, PJ, SH) HNSW_ID_READ0(ID, SH) "ds_read_b32 " PJ ", %[t0] offset:256\n\t"
 #define HNSW_F32_ID_READN_SPLIT(ID, PJ) HNSW_ID_READN(ID) "ds_read_b32 " PJ ", %[t0] offset:256\n\t"
+// ... and for rows of 129..256 dimensions (four float4 per lane: +0, +256, +512, +768; the third and the fourth chunk may lie
+// past a ragged row's end: cvm2 / cvm3)
+#define HNSW_F32_ROW_LOAD_N4(ID, PJ, AD, B)                                              \
+    "v_mad_u64_u32 " AD ", vcc, " ID ", %[st8], %[xl]\n\t"                               \
+    "global_load_dwordx4 " HNSW_FX4(B, 0) ", " AD ", off\n\t"                            \
+    "global_load_dwordx4 " HNSW_FX4(B, 1) ", " AD ", off offset:256\n\t"                 \
+    HNSW_F32_RAG2_ON                                                                     \
+    "global_load_dwordx4 " HNSW_FX4(B, 2) ", " AD ", off offset:512\n\t"                 \
+    HNSW_F32_RAG3_ON                                                                     \
+    "global_load_dwordx4 " HNSW_FX4(B, 3) ", " AD ", off offset:768\n\t"                 \
+    HNSW_F32_RAG_OFF
 // the lane's share of batch B's distance -> HNSW_FX(B, 0, 0)
 #define HNSW_F32_SUB(B, C, K, Q) "v_sub_f32_e32 " HNSW_FX(B, C, K) ", " HNSW_FX(B, C, K) ", " Q "\n\t"
 #define HNSW_F32_SQ(B, C, K) "v_fmac_f32_e32 " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, C, K) ", " HNSW_FX(B, C, K) "\n\t"
@@ -1284,6 +1299,28 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     HNSW_F32_RAG_ON                                                                      \
     HNSW_F32_MAC(B, 1, 0, "%[qf4]") HNSW_F32_MAC(B, 1, 1, "%[qf5]") HNSW_F32_MAC(B, 1, 2, "%[qf6]") HNSW_F32_MAC(B, 1, 3, "%[qf7]") \
     HNSW_F32_RAG_OFF
+#define HNSW_F32_DIST_L2_N4(B)                                                           \
+    HNSW_F32_SUB(B, 0, 0, "%[qf0]") HNSW_F32_SUB(B, 0, 1, "%[qf1]") HNSW_F32_SUB(B, 0, 2, "%[qf2]") HNSW_F32_SUB(B, 0, 3, "%[qf3]") \
+    "v_mul_f32_e32 " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, 0, 0) "\n\t" \
+    HNSW_F32_SQ(B, 0, 1) HNSW_F32_SQ(B, 0, 2) HNSW_F32_SQ(B, 0, 3)                       \
+    HNSW_F32_SUB(B, 1, 0, "%[qf4]") HNSW_F32_SUB(B, 1, 1, "%[qf5]") HNSW_F32_SUB(B, 1, 2, "%[qf6]") HNSW_F32_SUB(B, 1, 3, "%[qf7]") \
+    HNSW_F32_SQ(B, 1, 0) HNSW_F32_SQ(B, 1, 1) HNSW_F32_SQ(B, 1, 2) HNSW_F32_SQ(B, 1, 3)  \
+    HNSW_F32_RAG2_ON                                                                     \
+    HNSW_F32_SUB(B, 2, 0, "%[qf8]") HNSW_F32_SUB(B, 2, 1, "%[qf9]") HNSW_F32_SUB(B, 2, 2, "%[qf10]") HNSW_F32_SUB(B, 2, 3, "%[qf11]") \
+    HNSW_F32_SQ(B, 2, 0) HNSW_F32_SQ(B, 2, 1) HNSW_F32_SQ(B, 2, 2) HNSW_F32_SQ(B, 2, 3)  \
+    HNSW_F32_RAG3_ON                                                                     \
+    HNSW_F32_SUB(B, 3, 0, "%[qf12]") HNSW_F32_SUB(B, 3, 1, "%[qf13]") HNSW_F32_SUB(B, 3, 2, "%[qf14]") HNSW_F32_SUB(B, 3, 3, "%[qf15]") \
+    HNSW_F32_SQ(B, 3, 0) HNSW_F32_SQ(B, 3, 1) HNSW_F32_SQ(B, 3, 2) HNSW_F32_SQ(B, 3, 3)  \
+    HNSW_F32_RAG_OFF
+#define HNSW_F32_DIST_IP_N4(B)                                                           \
+    "v_fma_f32 " HNSW_FX(B, 0, 0) ", " HNSW_FX(B, 0, 0) ", %[qf0], 0\n\t"                \
+    HNSW_F32_MAC(B, 0, 1, "%[qf1]") HNSW_F32_MAC(B, 0, 2, "%[qf2]") HNSW_F32_MAC(B, 0, 3, "%[qf3]") \
+    HNSW_F32_MAC(B, 1, 0, "%[qf4]") HNSW_F32_MAC(B, 1, 1, "%[qf5]") HNSW_F32_MAC(B, 1, 2, "%[qf6]") HNSW_F32_MAC(B, 1, 3, "%[qf7]") \
+    HNSW_F32_RAG2_ON                                                                     \
+    HNSW_F32_MAC(B, 2, 0, "%[qf8]") HNSW_F32_MAC(B, 2, 1, "%[qf9]") HNSW_F32_MAC(B, 2, 2, "%[qf10]") HNSW_F32_MAC(B, 2, 3, "%[qf11]") \
+    HNSW_F32_RAG3_ON                                                                     \
+    HNSW_F32_MAC(B, 3, 0, "%[qf12]") HNSW_F32_MAC(B, 3, 1, "%[qf13]") HNSW_F32_MAC(B, 3, 2, "%[qf14]") HNSW_F32_MAC(B, 3, 3, "%[qf15]") \
+    HNSW_F32_RAG_OFF
 // lane l <- KEEP[l] + GIVE[l ^ 4] (DST may be KEEP; TMP is scratch).  Both rotations are computed for every lane and the lane's
 // bit 2 picks: merging them under bank masks instead would make the second instruction read what the first has just written
 // (gfx950 wants two wait states in front of ANY register a DPP instruction reads)
@@ -1300,10 +1337,12 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "v_or_b32_e32 %[t0], 0x80000000, %[t0]\n\t"                                          \
     "v_xor_b32_e32 %[ckey], %[t1], %[t0]\n\t"
 
+#define HNSW_F32_ROUND_PICK16                                                                                                         \
+        "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
+        "s_cbranch_scc1 40f\n\t"
 #define HNSW_F32_ROUND_COMMON \
         "20:\n\t"                                                                                                                     \
-        "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
-        "s_cbranch_scc1 40f\n\t"                                                                                                      \
+        HNSW_F32_ROUND_PICK                                                                                                           \
         "s_cmp_lt_u32 %[cnt], 5\n\t"                                                                                                  \
         "s_cbranch_scc1 25f\n\t"                                                                                                      \
   /* ---- 8 rows: two batches */                                                                                                      \
@@ -1315,7 +1354,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t"                                                                                                    \
         HNSW_F32_ROW_LOAD("%[id1]", "%[pj1]", "%[ad1]", 1)                                                                                      \
         "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"                                                                        \
-        "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
+        "s_waitcnt vmcnt(" HNSW_F32_VM1B ")\n\t"                                                                                                      \
         HNSW_F32_DIST(0)                                                                                                              \
         "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
         HNSW_F32_DIST(1)                                                                                                              \
@@ -1333,7 +1372,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         HNSW_ACCEPT_LATE                                                                                                              \
         "s_sub_u32 %[cnt], %[cnt], 8\n"
 
-#define HNSW_F32_ROUNDS_RARE \
+#define HNSW_F32_ROUND_4ROWS \
         "25:\n\t"                                                                                                                     \
   /* ---- 4 rows: one batch */                                                                                                        \
         HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 0)                                                                                                    \
@@ -1353,7 +1392,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         HNSW_F32_KEY                                                                                                                  \
         HNSW_ACCEPT_LATE                                                                                                              \
         "s_sub_u32 %[cnt], %[cnt], 4\n\t"                                                                                             \
-        "s_branch 50b\n"                                                                                                              \
+        "s_branch 50b\n"
+#define HNSW_F32_ROUND_16ROWS \
   /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
         "40:\n\t"                                                                                                                     \
         HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 2)                                                                                                    \
@@ -1400,6 +1440,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         HNSW_ACCEPT_LATE                                                                                                              \
         "s_sub_u32 %[cnt], %[cnt], 16\n\t"                                                                                            \
         "s_branch 50b\n"
+#define HNSW_F32_ROUNDS_RARE HNSW_F32_ROUND_4ROWS HNSW_F32_ROUND_16ROWS
+
 
 #define HNSW_LOOP_NAME search_layer0_f32_l2_full_asm2
 #define HNSW_LOOP_NSLOT 2
@@ -1665,6 +1707,215 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
+// float32 rows of 129..256 dimensions (NCH = 4), full and ragged
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
 
 // the instantiation for a kernel variant's (slots, metric, row shape)
 template <int NSLOT, int METRIC, int ROWS>
@@ -1678,6 +1929,30 @@ __device__ __forceinline__ void search_layer0_f32_asm(const IndexView &iv, WList
     HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_asm4) HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_asm8)
     HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_asm4) HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_asm8)
 #undef HNSW_F32_CALL
+}
+
+// float32 rows of 129..256 dimensions (NCH = 4)
+template <int NSLOT, int METRIC, int ROWS>
+__device__ __forceinline__ void search_layer0_f32n4_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[4],
+                                                        uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
+    HNSW_F4_CALL(1, 0, 1, search_layer0_f32n4_l2_full_asm1) HNSW_F4_CALL(2, 0, 1, search_layer0_f32n4_l2_full_asm2) HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_asm4) HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_asm8)
+    HNSW_F4_CALL(1, 0, 0, search_layer0_f32n4_l2_ragged_asm1) HNSW_F4_CALL(2, 0, 0, search_layer0_f32n4_l2_ragged_asm2) HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_asm8)
+    HNSW_F4_CALL(1, 1, 1, search_layer0_f32n4_ip_full_asm1) HNSW_F4_CALL(2, 1, 1, search_layer0_f32n4_ip_full_asm2) HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_asm4) HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_asm8)
+    HNSW_F4_CALL(1, 1, 0, search_layer0_f32n4_ip_ragged_asm1) HNSW_F4_CALL(2, 1, 0, search_layer0_f32n4_ip_ragged_asm2) HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_asm8)
+#undef HNSW_F4_CALL
+}
+
+template <int NSLOT, int METRIC, int ROWS>
+__device__ __forceinline__ bool search_layer0_f32n4_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
+                                                             const float4 (&qv)[4], uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
+    HNSW_F4_CALL(1, 0, 1, search_layer0_f32n4_l2_full_sem1_asm1) HNSW_F4_CALL(2, 0, 1, search_layer0_f32n4_l2_full_sem1_asm2) HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_sem1_asm4) HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_sem1_asm8)
+    HNSW_F4_CALL(1, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm1) HNSW_F4_CALL(2, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm2) HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm8)
+    HNSW_F4_CALL(1, 1, 1, search_layer0_f32n4_ip_full_sem1_asm1) HNSW_F4_CALL(2, 1, 1, search_layer0_f32n4_ip_full_sem1_asm2) HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_sem1_asm4) HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_sem1_asm8)
+    HNSW_F4_CALL(1, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm1) HNSW_F4_CALL(2, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm2) HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm8)
+#undef HNSW_F4_CALL
+    return false;
 }
 
 // byte rows of 129..256 dimensions (NCH = 4), both metrics, both rules

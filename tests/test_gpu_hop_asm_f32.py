@@ -1,5 +1,5 @@
-"""The hand-scheduled layer-0 loops over FLOAT32 rows (csrc/hnsw_hop_asm.hip.h, "The same loops over FLOAT32 rows": 65..128
-dimensions, L2 and inner product, both accept rules, ef <= 256; full rows d = 125..128, ragged rows and split rows) against the
+"""The hand-scheduled layer-0 loops over FLOAT32 rows (csrc/hnsw_hop_asm.hip.h, "The same loops over FLOAT32 rows": 65..128 and
+129..256 dimensions, L2 and inner product, both accept rules, ef <= 256; full rows d = 125..128, ragged rows and split rows) against the
 oracle.  The round of these loops is new text -- row loads, the distance in hop_round's operation order, a reduction that
 pairs lane l with lane l ^ 8, 4, 2, 1 while folding the round's candidates into one register -- so the data here is chosen
 for the arithmetic (values whose sums depend on the order of the additions, squares that underflow, negative zeros,
@@ -118,6 +118,37 @@ def test_split_rows_through_the_loops(H, oracle, d, metric, kind):
     for ef, k in EFS:
         _check(H, oracle, hg, g, sp, Q, ef, k, "split %s metric %d d %d ef %d" % (kind, metric, d, ef))
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "split functor %s metric %d d %d ef %d" % (kind, metric, d, ef))
+    hg.release()
+
+
+# rows of 129..256 dimensions (four chunks per lane): d = 132 -> 33 chunks (one lane of the third chunk), 200 -> 50, 250 -> 63 (the
+# last chunk partial), 253 -> full rows whose last chunk is padded, 256 -> full
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d", [132, 200, 250, 253, 256])
+def test_rows_of_129_to_256_dimensions_through_the_loops(H, oracle, d, metric):
+    rng = np.random.default_rng(8000 + 10 * d + metric)
+    n = 3000
+    X = (rng.normal(size=(n, d)) * np.exp2(rng.integers(-5, 5, size=(n, d)))).astype(np.float32)
+    Q = (rng.normal(size=(100, d)) * np.exp2(rng.integers(-5, 5, size=(100, d)))).astype(np.float32)
+    X[5, ::3] = -0.0
+    Q[4] = X[7]
+    sp = _space(oracle, X, metric)
+    g = oracle.build_ohnsw(sp, 12, 60, seed=3)
+    hg = _hgraph(H, X, g, 12, metric)
+    for ef, k in EFS:
+        _check(H, oracle, hg, g, sp, Q, ef, k, "n4 metric %d d %d ef %d" % (metric, d, ef))
+        if ef in (17, 100, 192, 400):
+            _check_functor(H, oracle, hg, g, sp, Q, ef, k, "n4 functor metric %d d %d ef %d" % (metric, d, ef))
+    hg.release()
+    # ties everywhere on the same shapes
+    Xt = rng.integers(0, 3, size=(n, d)).astype(np.float32) * 0.5
+    Qt = rng.integers(0, 3, size=(60, d)).astype(np.float32) * 0.5
+    sp = _space(oracle, Xt, metric)
+    g = oracle.build_ohnsw(sp, 12, 60, seed=4)
+    hg = _hgraph(H, Xt, g, 12, metric)
+    for ef, k in ((30, 10), (128, 20), (256, 30), (512, 40)):
+        _check(H, oracle, hg, g, sp, Qt, ef, k, "n4 ties metric %d d %d ef %d" % (metric, d, ef))
+        _check_functor(H, oracle, hg, g, sp, Qt, ef, k, "n4 ties functor metric %d d %d ef %d" % (metric, d, ef))
     hg.release()
 
 
