@@ -1,7 +1,8 @@
 // hnsw_hop_asm.hip.h -- the layer-0 loop of Ohnsw.search_k (lib/ohnsw.ml:543-588) and the descent above it
 // (Ohnsw.search_one, :492-508), written instruction by instruction for gfx950.
 //
-// Shapes: rows of 65..128 dimensions (NCH = 2), ef <= 64 / 65..128 / 129..256 / 257..512 (W in one / two / four / eight key
+// Shapes: rows of 65..128 dimensions (NCH = 2) -- and, for byte rows and for full / ragged float32 rows, of 129..256 (NCH = 4:
+// the rounds with twice the loads and arithmetic per batch) --, ef <= 64 / 65..128 / 129..256 / 257..512 (W in one / two / four / eight key
 // registers per lane; one loop body per slot count in hnsw_hop_loop.inc, included once per shape; the eight-slot insertion is
 // generated: hnsw_hop_slots8.inc):
 //   * byte rows and a byte-valued query (exact integer arithmetic, see hop_round), L2 -- the headline shape; its descent too --
