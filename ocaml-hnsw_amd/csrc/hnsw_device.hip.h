@@ -1069,7 +1069,8 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     constexpr bool ASM_SLOTS = NCH == 2 && ASM_NSLOT;
     constexpr bool ASM_B8N4 = HNSW_ASM_LOOP_BYTES4 && NCH == 4 && ASM_NSLOT && ROWS == 2;      // byte rows of 129..256 dimensions
     constexpr bool ASM_B8 = (ASM_SLOTS && ROWS == 2) || ASM_B8N4;
-    constexpr bool ASM_F32N4 = HNSW_ASM_LOOP_F32 && HNSW_ASM_LOOP_F32N4 && NCH == 4 && ASM_NSLOT && (ROWS == 0 || ROWS == 1);   // float32 rows of 129..256 dimensions
+    constexpr bool ASM_F32N4 = HNSW_ASM_LOOP_F32 && HNSW_ASM_LOOP_F32N4 && NCH == 4 && ASM_NSLOT &&
+                               (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT));                            // float32 rows of 129..256 dimensions
     constexpr bool ASM_F32 = (HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT))) || ASM_F32N4;
     bool asm_ok = false;
     if constexpr (ASM_B8 || ASM_F32) {

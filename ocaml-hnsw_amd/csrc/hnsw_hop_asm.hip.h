@@ -1260,6 +1260,25 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_mov_b64 exec, %[cvm]\n\t"                                                         \
     "global_load_dwordx4 " HNSW_FX4(B, 1) ", " HNSW_SPLIT_AD(B) ", off offset:256\n\t"   \
     "s_mov_b64 exec, -1\n\t"
+// ... split rows of 129..256 dimensions: chunks 0 and 1 always lie in the main row; the one or two tail chunks are the last of
+// the row, so they fall into ONE of the chunk columns 2 and 3 -- tlm2 / tlm3 are the tail lanes of either (one of them empty);
+// a lane may be a main lane of column 2 and a tail lane of column 3, so its address is switched in front of the column it is a
+// tail lane of (trow already contains the lane's chunk offset less 512 or 768)
+#define HNSW_F32_ROW_LOAD_N4_SPLIT(ID, PJ, AD, B)                                        \
+    "v_mad_u64_u32 " HNSW_SPLIT_AD(B) ", vcc, " ID ", %[st8], %[xl]\n\t"                 \
+    "global_load_dwordx4 " HNSW_FX4(B, 0) ", " HNSW_SPLIT_AD(B) ", off\n\t"              \
+    "global_load_dwordx4 " HNSW_FX4(B, 1) ", " HNSW_SPLIT_AD(B) ", off offset:256\n\t"   \
+    "v_mad_u64_u32 v[36:37], vcc, " PJ ", %[c16t], %[trow]\n\t"                          \
+    "v_cndmask_b32_e64 " HNSW_SPLIT_AD_LO(B) ", " HNSW_SPLIT_AD_LO(B) ", v36, %[tlm2]\n\t" \
+    "v_cndmask_b32_e64 " HNSW_SPLIT_AD_HI(B) ", " HNSW_SPLIT_AD_HI(B) ", v37, %[tlm2]\n\t" \
+    "s_mov_b64 exec, %[cvm2]\n\t"                                                        \
+    "global_load_dwordx4 " HNSW_FX4(B, 2) ", " HNSW_SPLIT_AD(B) ", off offset:512\n\t"   \
+    "s_mov_b64 exec, -1\n\t"                                                             \
+    "v_cndmask_b32_e64 " HNSW_SPLIT_AD_LO(B) ", " HNSW_SPLIT_AD_LO(B) ", v36, %[tlm3]\n\t" \
+    "v_cndmask_b32_e64 " HNSW_SPLIT_AD_HI(B) ", " HNSW_SPLIT_AD_HI(B) ", v37, %[tlm3]\n\t" \
+    "s_mov_b64 exec, %[cvm3]\n\t"                                                        \
+    "global_load_dwordx4 " HNSW_FX4(B, 3) ", " HNSW_SPLIT_AD(B) ", off offset:768\n\t"   \
+    "s_mov_b64 exec, -1\n\t"
 #define HNSW_SPLIT_CLOBBER , "v32", "v33", "v34", "v35", "v36", "v37"
 // the hop's node (kd = its id + 1) -> the address of its tail row per lane; kept for the hand-over of the functor rule
 #define HNSW_SPLIT_HOP_ON                                                                \
@@ -1917,6 +1936,111 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
+// split float32 rows of 129..256 dimensions (NCH = 4)
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_asm1
+#define HNSW_LOOP_NSLOT 1
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_asm2
+#define HNSW_LOOP_NSLOT 2
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#include "hnsw_hop_loop.inc"
 
 // the instantiation for a kernel variant's (slots, metric, row shape)
 template <int NSLOT, int METRIC, int ROWS>
@@ -1939,8 +2063,10 @@ __device__ __forceinline__ void search_layer0_f32n4_asm(const IndexView &iv, WLi
 #define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
     HNSW_F4_CALL(1, 0, 1, search_layer0_f32n4_l2_full_asm1) HNSW_F4_CALL(2, 0, 1, search_layer0_f32n4_l2_full_asm2) HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_asm4) HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_asm8)
     HNSW_F4_CALL(1, 0, 0, search_layer0_f32n4_l2_ragged_asm1) HNSW_F4_CALL(2, 0, 0, search_layer0_f32n4_l2_ragged_asm2) HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_asm8)
+    HNSW_F4_CALL(1, 0, 3, search_layer0_f32n4_l2_split_asm1) HNSW_F4_CALL(2, 0, 3, search_layer0_f32n4_l2_split_asm2) HNSW_F4_CALL(4, 0, 3, search_layer0_f32n4_l2_split_asm4) HNSW_F4_CALL(8, 0, 3, search_layer0_f32n4_l2_split_asm8)
     HNSW_F4_CALL(1, 1, 1, search_layer0_f32n4_ip_full_asm1) HNSW_F4_CALL(2, 1, 1, search_layer0_f32n4_ip_full_asm2) HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_asm4) HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_asm8)
     HNSW_F4_CALL(1, 1, 0, search_layer0_f32n4_ip_ragged_asm1) HNSW_F4_CALL(2, 1, 0, search_layer0_f32n4_ip_ragged_asm2) HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_asm8)
+    HNSW_F4_CALL(1, 1, 3, search_layer0_f32n4_ip_split_asm1) HNSW_F4_CALL(2, 1, 3, search_layer0_f32n4_ip_split_asm2) HNSW_F4_CALL(4, 1, 3, search_layer0_f32n4_ip_split_asm4) HNSW_F4_CALL(8, 1, 3, search_layer0_f32n4_ip_split_asm8)
 #undef HNSW_F4_CALL
 }
 
@@ -1950,8 +2076,10 @@ __device__ __forceinline__ bool search_layer0_f32n4_sem1_asm(const IndexView &iv
 #define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
     HNSW_F4_CALL(1, 0, 1, search_layer0_f32n4_l2_full_sem1_asm1) HNSW_F4_CALL(2, 0, 1, search_layer0_f32n4_l2_full_sem1_asm2) HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_sem1_asm4) HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_sem1_asm8)
     HNSW_F4_CALL(1, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm1) HNSW_F4_CALL(2, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm2) HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm8)
+    HNSW_F4_CALL(1, 0, 3, search_layer0_f32n4_l2_split_sem1_asm1) HNSW_F4_CALL(2, 0, 3, search_layer0_f32n4_l2_split_sem1_asm2) HNSW_F4_CALL(4, 0, 3, search_layer0_f32n4_l2_split_sem1_asm4) HNSW_F4_CALL(8, 0, 3, search_layer0_f32n4_l2_split_sem1_asm8)
     HNSW_F4_CALL(1, 1, 1, search_layer0_f32n4_ip_full_sem1_asm1) HNSW_F4_CALL(2, 1, 1, search_layer0_f32n4_ip_full_sem1_asm2) HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_sem1_asm4) HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_sem1_asm8)
     HNSW_F4_CALL(1, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm1) HNSW_F4_CALL(2, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm2) HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm8)
+    HNSW_F4_CALL(1, 1, 3, search_layer0_f32n4_ip_split_sem1_asm1) HNSW_F4_CALL(2, 1, 3, search_layer0_f32n4_ip_split_sem1_asm2) HNSW_F4_CALL(4, 1, 3, search_layer0_f32n4_ip_split_sem1_asm4) HNSW_F4_CALL(8, 1, 3, search_layer0_f32n4_ip_split_sem1_asm8)
 #undef HNSW_F4_CALL
     return false;
 }

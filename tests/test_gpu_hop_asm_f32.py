@@ -96,9 +96,11 @@ def test_ties_everywhere_float_rows(H, oracle, levels, d, metric):
 
 
 # split rows (csrc/hnsw_rows_split.hip): d = 66 -> 17 chunks (16 in the main row + 1 tail chunk), 70 -> 18 (16 + 2), 100 -> 25 (24 + 1),
-# 104 -> 26 (24 + 2): the loops read the tail chunks from the expanded node's tail row at the candidate's slot
+# 104 -> 26 (24 + 2): the loops read the tail chunks from the expanded node's tail row at the candidate's slot; rows of four
+# chunk columns: 130 -> 33 (32 + 1: the tail in column 2), 136 -> 34, 164 -> 41 (40 + 1: column 2 half main), 200 -> 50 (48 + 2: the tail
+# in column 3), 228 -> 57 (56 + 1: column 3 half main), 232 -> 58
 @pytest.mark.parametrize("metric", [0, 1])
-@pytest.mark.parametrize("d", [66, 70, 100, 104])
+@pytest.mark.parametrize("d", [66, 70, 100, 104, 130, 136, 164, 200, 228, 232])
 @pytest.mark.parametrize("kind", ["ties", "spread"])
 def test_split_rows_through_the_loops(H, oracle, d, metric, kind):
     rng = np.random.default_rng(7000 + 10 * d + metric)
