@@ -582,8 +582,8 @@ __device__ __forceinline__ bool visited_mem(const WaveCtx &cx, uint32_t id, uint
 // 10 of them (and never the all-ones value, which marks an empty way) -> three tags per word, the same LDS holds half as many
 // tags again.  Worth it where a walk visits several times the cache's capacity (large ef): on clustered data a 2-way cache of
 // 2^12 tags re-evaluates 31 % (ef 256, 5 k nodes visited; tools/visited_cache_sim.py), three ways 12 %.  The knn kernels with
-// W in four or eight registers switch it on when the index is small enough; everything else keeps two ways (one SDWA compare
-// per way in the hand-scheduled loops).
+// W in four or eight registers -- on float32 rows also those with two -- switch it on when the index is small enough; everything
+// else keeps two ways (one SDWA compare per way in the hand-scheduled loops).
 __device__ __forceinline__ void visited_three_ways(WaveCtx &cx, int32_t n) {
     if (n > 0 && ((uint32_t)(n - 1) >> cx.set_bits) < 0x3FFu) cx.tag_shift = 10;
 }
@@ -1320,7 +1320,9 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     WaveCtx cx = make_ctx(lds, a.vt_bits, lane);
     if (a.ovf_g) { cx.ovf.g = a.ovf_g + (int64_t)blockIdx.x * a.ovf_gcap; cx.ovf.gcap = a.ovf_gcap; }
 #if HNSW_VT_THREE_WAYS
-    if constexpr (NSLOT >= 4) visited_three_ways(cx, iv.n);      // ef > 128: the walk visits several times what the cache holds
+    // ef > 128: the walk visits several times what the cache holds; float32 rows from ef 65 on (a re-evaluation costs four times a
+    // byte row's bytes there, and the two-slot byte-row loop -- the headline -- keeps its branch-free two-way filter)
+    if constexpr (NSLOT >= 4 || (NSLOT == 2 && ROWS != 2)) visited_three_ways(cx, iv.n);
 #endif
     // Issue priority inside an ordered launch (blocks run the walks predicted longest first): the launch ends with its
     // longest walk or with the last of the late starters (the blocks that had to wait for a free slot), so those two ends

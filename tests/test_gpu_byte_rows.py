@@ -31,6 +31,7 @@ def _bytes_data(n, d, seed, hi=255):
 def _both_ways(H, hg, fn):
     # evaluation counts include re-evaluations, which depend on the visited cache's size; the library sizes that cache per
     # kernel variant (as large as the variant's residency allows), so the two formats are compared at one explicit size
+    # (and see _same_results: the formats may still differ in the number of tags per word)
     hg.set_option("vt_bits", 12)
     assert hg.row_bytes() == hg.info().d
     a = fn()
@@ -41,6 +42,18 @@ def _both_ways(H, hg, fn):
     assert hg.row_bytes() == hg.info().d
     hg.set_option("vt_bits", 0)
     return a, b
+
+
+def _same_results(a, b):
+    """(ids, distances, evaluations, hops) of the two row formats: ids, distance bits and hop counts are the search's and must be equal;
+    the evaluation counts include what the lossy visited cache re-evaluates, and the float32-row kernels keep three tags per word
+    from ef 65 on where the byte-row kernels keep two (visited_three_ways): equal only where nothing is forgotten"""
+    for i, (x, y) in enumerate(zip(a, b)):
+        if len(a) == 4 and i == 2:
+            assert (np.asarray(x) > 0).all() and (np.asarray(y) > 0).all()
+            continue
+        np.testing.assert_array_equal(np.asarray(x).view(np.uint32) if np.asarray(x).dtype == np.float32 else x,
+                                      np.asarray(y).view(np.uint32) if np.asarray(y).dtype == np.float32 else y)
 
 
 # d: 20 -> 1 chunk column (ragged), 64 -> 1 (full), 100 -> 2 (ragged), 128 -> 2 (full), 130 -> 4 (ragged, d % 4 != 0),
@@ -64,9 +77,7 @@ def test_byte_rows_equal_float_rows_and_oracle(H, oracle, d, metric, queries):
     hg = H.Ohnsw.build_batch_bigarray(X, M, efc, seed=3, metric=metric)
     for ef, k in ((16, 5), (100, 10), (300, 64)):
         a, b = _both_ways(H, hg, lambda: H.Ohnsw.knn_batch_bigarray(hg, k, Q, ef=ef, counters=True))
-        for x, y in zip(a, b):
-            np.testing.assert_array_equal(np.asarray(x).view(np.uint32) if np.asarray(x).dtype == np.float32 else x,
-                                          np.asarray(y).view(np.uint32) if np.asarray(y).dtype == np.float32 else y)
+        _same_results(a, b)
     hg.export()
     g = oracle.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, hg.upper)
     sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
@@ -86,9 +97,7 @@ def test_byte_rows_functor_rule_and_ordered_launch(H):
     hg = H.Ohnsw.build_batch_bigarray(X, 16, 100, seed=1)
     hg.set_option("order_queries", 1)
     a, b = _both_ways(H, hg, lambda: H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=128, counters=True))
-    for x, y in zip(a, b):
-        np.testing.assert_array_equal(np.asarray(x).view(np.uint32) if np.asarray(x).dtype == np.float32 else x,
-                                      np.asarray(y).view(np.uint32) if np.asarray(y).dtype == np.float32 else y)
+    _same_results(a, b)
     a, b = _both_ways(H, hg, lambda: H.Ba.knn_batch(hg, Q[:500], 64, 10))
     for x, y in zip(a, b):
         np.testing.assert_array_equal(np.asarray(x).view(np.uint32) if np.asarray(x).dtype == np.float32 else x,
@@ -132,8 +141,9 @@ def test_save_load_and_flattened_create_rebuild_the_copy(H, tmp_path):
 
 
 def test_launch_options_change_nothing_but_the_launch(H):
-    """lds_pad (how many queries a CU holds at once), order_queries and byte_rows are launch policy: per-query
-    results and counters must not move, whatever they are set to (including LDS requests near the 64 KiB limit)."""
+    """lds_pad (how many queries a CU holds at once) and order_queries are launch policy: per-query results and counters must
+    not move, whatever they are set to (including LDS requests near the 64 KiB limit); byte_rows picks another kernel: same
+    results and hop counts, evaluation counts of its own."""
     n, d = 30000, 128
     X = _bytes_data(n, d, 31, hi=218)
     Q = _bytes_data(9000, d, 32, hi=218)
@@ -141,11 +151,15 @@ def test_launch_options_change_nothing_but_the_launch(H):
     ref = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=128, counters=True)
     for rows in (1, 0):
         hg.set_option("byte_rows", rows)
+        hg.set_option("order_queries", -1)
+        hg.set_option("lds_pad", -1)
+        ref_rows = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=128, counters=True)
+        _same_results(ref, ref_rows)                 # the row format moves the evaluation counts only (tags per word of the visited cache)
         for order in (-1, 0, 1):
             hg.set_option("order_queries", order)
             for pad in (-1, 0, 1280, 2560, 7000, 30000, 60000):
                 hg.set_option("lds_pad", pad)
                 got = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=128, counters=True)
-                for x, y in zip(ref, got):
+                for x, y in zip(ref_rows, got):
                     np.testing.assert_array_equal(x, y)
     hg.release()
