@@ -55,7 +55,14 @@
 extern "C" {
 #endif
 
-#define HNSW_ABI_VERSION 1
+/* Bumped whenever an entry point, a structure or a documented behaviour changes; the Python and OCaml loaders refuse a library
+ * that answers another number (hnsw_abi_version).
+ *   2  (round 5) hnsw_index_locality_codes and the option "visited_blocks"; hnsw_host_unregister / hnsw_host_free wait for
+ *      asynchronous readers and refuse pointers that are not theirs (HNSW_ERR_BAD_ARG); and, since version 1 was first cut:
+ *      hnsw_search_batch_h2d, hnsw_host_alloc / hnsw_host_free, hnsw_index_layer_isolated, hnsw_multi_debug_counters,
+ *      hnsw_index_info.row_format (was `reserved`), hnsw_index_layer_stats' values for a layer without nodes
+ *      (min 1000000, max -1, mean nan: the reference's fold), Hgraph.stats()['isolated'] a list of ids */
+#define HNSW_ABI_VERSION 2
 
 typedef struct hnsw_index hnsw_index;
 
@@ -180,14 +187,31 @@ int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info);
  *                   and the 16 / 32 remaining bytes of node nbr0[c][j] beside slot (c, j) of the layer-0 adjacency,
  *                   where one hop finds all its candidates' tails in a few contiguous lines; the knn searches read
  *                   those on layer 0 (same lanes, operands and order of arithmetic: bit-identical results).
- *                   1 = use the copy where it exists (default), 0 = read the plain rows.  (Environment
- *                   HNSW_SPLIT_ROWS=0 at creation: do not build it.)
+ *                   1 = use the copy where it exists (default), 0 = read the plain rows, -1 = read the plain rows and FREE
+ *                   the copy (it cannot come back).  The copy is not small: n * (128-byte lines of a row) + n * max_degree0 *
+ *                   (16 or 32) bytes -- for a GloVe-shaped index (1.18 M x 100, M 32) 0.45 + 1.2 GB beside 0.47 GB of
+ *                   vectors; hnsw_index_info.device_bytes counts it.  (Environment HNSW_SPLIT_ROWS=0 at creation: do not
+ *                   build it.)
+ *   "visited_blocks" how the knn kernels with W in four or more registers (ef > 128) remember visited nodes
+ *                   (Visited, lib/ohnsw.ml:256-268): 0 = an LDS cache of node tags (all that rounds 1-4 had); 1 = an LDS
+ *                   cache of BITMAP BLOCKS over "locality codes" -- a second numbering of the nodes, derived from the
+ *                   index's own upper layers, under which graph-close nodes are consecutive, so that the nodes a walk
+ *                   visits share blocks and cost one bit each (ocaml-hnsw_amd/csrc/hnsw_locality.hip); -1 (default) = the
+ *                   handle decides per kernel shape by searching 256 of the index's own vectors both ways and counting
+ *                   evaluations, inside the first search call that needs the answer (which then also builds the codes: one
+ *                   small layer search per node, n * (1 + max_degree0) * 4 bytes of tables, a device synchronisation --
+ *                   1.2 s for 10 M nodes; indices below 200 000 nodes are not measured).  Clustered / embedding-like data:
+ *                   the blocks end the repeated evaluations of forgotten nodes (DEEP10M shape, ef 512: 40 % -> 5 % of all
+ *                   evaluations); structureless data: the tags win and are kept.  Results are the same bits either way.
  * and one that buys exactness for the device-pointer entry point:
  *   "device_fallback_slab_bytes"  the library allocates a slab of this many bytes (0 frees it); hnsw_search_batch_device
  *                   then lists the queries its launch flagged (d_status bit 0: tie list outgrew its LDS slots) ON THE
  *                   DEVICE and searches them again with the slab on the caller's stream -- no host round trip, two small
  *                   extra launches per call.  One flagged query needs 4 n bytes (a slot per node), so a slab repairs
- *                   bytes / (4 n) queries per call; those it could not take keep their flag.  Needs d_status. */
+ *                   bytes / (4 n) queries per call; those it could not take keep their flag.  Needs d_status.  The list and
+ *                   the slab belong to the handle: with this option ONE hnsw_search_batch_device / hnsw_search_batch_h2d call
+ *                   in flight per handle (calls on one stream are ordered and therefore fine; calls on different streams
+ *                   must not overlap). */
 int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value);
 /* Bytes of one vector as the knn searches read it: d for byte rows, 4 * d for float32 rows. */
 int32_t hnsw_index_row_bytes(const hnsw_index *idx, int64_t *row_bytes);
@@ -215,8 +239,16 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
  *                                           the lifetime: the array stays allocated (a Bigarray: reachable) until
  *                                           hnsw_host_unregister; the library never registers anything behind the caller's
  *                                           back.  Registering an array twice is not an error; an array of which only a
- *                                           part is registered already is refused.
- * Only ranges obtained through these four calls are accessed directly; any other pointer is staged through copies. */
+ *                                           part is registered already is refused (HNSW_ERR_BAD_ARG); an array somebody else
+ *                                           has page-locked is accepted, left to its owner and never accessed in place.
+ * Only ranges obtained through these four calls are accessed directly; any other pointer is staged through copies.
+ * LIFETIME.  A range may be unregistered / freed at any time after the call that used it has RETURNED: hnsw_host_unregister and
+ * hnsw_host_free wait for the asynchronous work that still reads it (hnsw_search_batch_h2d's kernels read a registered query
+ * matrix in place after the call has returned; hnsw_search_submit's upload is a DMA out of it) -- the library keeps an event
+ * behind the last such reader per range and stream.  What the library cannot defend against is the memory itself going away
+ * while registered (munmap / free of an array that was never unregistered): unregister first.  Both calls answer
+ * HNSW_ERR_BAD_ARG for a pointer that is not the start of a range THEY handed out (hnsw_host_unregister: registered through
+ * hnsw_host_register; hnsw_host_free: allocated by hnsw_host_alloc). */
 int32_t hnsw_host_register(void *p, int64_t bytes);
 int32_t hnsw_host_unregister(void *p);
 int32_t hnsw_host_alloc(void **out, int64_t bytes);
@@ -240,8 +272,9 @@ int32_t hnsw_search_batch_device(hnsw_index *idx, const float *d_queries, int64_
  * them: read by the device directly when the caller registered the matrix with hnsw_host_register, staged through the
  * handle's scratch otherwise), the results are left in DEVICE buffers, everything asynchronous on `stream` -- for a caller
  * that exchanges per-shard results between devices (one process per GPU and an RCCL all-gather: bench.py --gpus N,
- * ocaml-hnsw_amd/sharding.py) before anything goes back to the host.  The queries must stay valid until the stream has
- * passed the call; one such call in flight per handle (it uses the handle's query scratch).  As hnsw_search_batch_device:
+ * ocaml-hnsw_amd/sharding.py) before anything goes back to the host.  The query matrix must stay ALLOCATED until the stream has
+ * passed the call (unregistering it earlier is safe: hnsw_host_unregister waits, see LIFETIME above); one such call in flight
+ * per handle (it uses the handle's query scratch).  As hnsw_search_batch_device:
  * flags only (d_status), unless the option "device_fallback_slab_bytes" is set. */
 int32_t hnsw_search_batch_h2d(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
                               const hnsw_search_params *params, int32_t *d_ids, float *d_dist,
@@ -377,6 +410,12 @@ int32_t hnsw_index_export_layer0(const hnsw_index *idx, int32_t *deg0, int32_t *
 int32_t hnsw_index_export_upper_count(const hnsw_index *idx, int32_t layer, int64_t *n_nodes);
 int32_t hnsw_index_export_upper(const hnsw_index *idx, int32_t layer, int64_t *nodes, int32_t *deg,
                                 int32_t *nbr);
+
+/* The locality codes behind the option "visited_blocks" (built on first use or by this call): out[v] = position of node v
+ * (0-based, whatever id_base is) in an order that keeps graph-close nodes together -- a permutation of 0 .. n-1 derived
+ * from the index's own upper layers (ocaml-hnsw_amd/csrc/hnsw_locality.hip).  Introspection and tests; the search never
+ * hands codes out.  HNSW_ERR_UNSUPPORTED when the index has no upper layer to derive an order from. */
+int32_t hnsw_index_locality_codes(hnsw_index *idx, int32_t *out);
 
 /* Per-layer degree statistics: Hgraph.Stats.compute (lib/hnsw.ml:353-375; printed by
  * benchmark/benchmark.ml:70-71): layer size (layer_sizes) and the layer's mima record -- min / max / mean of the

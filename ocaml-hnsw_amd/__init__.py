@@ -28,12 +28,14 @@ FILL_OHNSW, FILL_BA = 0, 1
 SEM_OHNSW, SEM_FUNCTOR, SEM_FUNCTOR_NEAREST_K = 0, 1, 2
 
 # every symbol include/hnsw_mi355x.h declares (tests check the .so exports all of them)
+ABI_VERSION = 2          # HNSW_ABI_VERSION of include/hnsw_mi355x.h this mirror was written against
+
 ABI_SYMBOLS = [
     "hnsw_abi_version", "hnsw_last_error", "hnsw_device_count", "hnsw_index_create",
     "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_index_row_bytes", "hnsw_search_batch",
     "hnsw_search_batch_device", "hnsw_search_batch_h2d", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
-    "hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_save", "hnsw_index_load",
+    "hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_locality_codes", "hnsw_index_save", "hnsw_index_load",
     "hnsw_search_layer_batch", "hnsw_search_one_batch",
     "hnsw_search_submit", "hnsw_search_wait", "hnsw_index_kernel_times",
     "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
@@ -99,6 +101,8 @@ def load():
     L = _C.CDLL(LIB_PATH)
     vp, i32, i64 = _C.c_void_p, _C.c_int32, _C.c_int64
     L.hnsw_abi_version.restype = i32
+    if L.hnsw_abi_version() != ABI_VERSION:
+        raise Failure("%s speaks ABI version %d, this binding %d: rebuild it (python __graft_entry__.py)" % (LIB_PATH, L.hnsw_abi_version(), ABI_VERSION))
     L.hnsw_last_error.restype = _C.c_char_p
     L.hnsw_device_count.argtypes = [vp]
     L.hnsw_index_create.argtypes = [vp, i32, vp]
@@ -118,6 +122,8 @@ def load():
     L.hnsw_select_neighbours_batch.restype = i32
     L.hnsw_index_layer_stats.argtypes = [vp, i32, vp]
     L.hnsw_index_layer_isolated.argtypes = [vp, i32, vp, i64, vp]
+    L.hnsw_index_locality_codes.argtypes = [vp, vp]
+    L.hnsw_index_locality_codes.restype = i32
     L.hnsw_index_save.argtypes = [vp, _C.c_char_p]
     L.hnsw_index_load.argtypes = [_C.c_char_p, i32, vp]
     for f in ("hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_save", "hnsw_index_load"):
@@ -260,6 +266,12 @@ class Hgraph:
             _check(L.hnsw_index_export_upper(self.handle, l, _ptr(nodes), _ptr(deg), _ptr(nbr)))
             self.upper.append((nodes, deg, nbr))
         return self
+
+    def locality_codes(self):
+        """hnsw_index_locality_codes: the permutation of 0 .. n-1 that keys the visited set's bitmap blocks (introspection)."""
+        out = _np.empty(self.n, _np.int32)
+        _check(load().hnsw_index_locality_codes(self.handle, _ptr(out)))
+        return out
 
     def stats(self):
         """Hgraph.Stats.compute (lib/hnsw.ml:353-375): {num_nodes, layer_sizes, layer_connectivity}; a layer's

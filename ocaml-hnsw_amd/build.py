@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libhnsw_mi355x.so")
 SOURCES = ["hnsw_capi.hip", "hnsw_build.hip", "hnsw_layer_ops.hip", "hnsw_multi.hip", "hnsw_order.hip", "hnsw_rows8.hip",
-           "hnsw_rows_split.hip"]
+           "hnsw_rows_split.hip", "hnsw_locality.hip"]
 # the knn kernel's variants: one object per (metric, accept rule, row shape), see hnsw_search_variants.hip
 VARIANT_SOURCE = "hnsw_search_variants.hip"
 VARIANTS = [(m, s, f) for m in (0, 1) for s in (0, 1) for f in (0, 1, 2, 3)]   # f: rows ragged fp32 / full fp32 / bytes / split fp32

@@ -16,19 +16,42 @@ namespace hnsw_host {
 
 thread_local std::string g_last_error;
 
-// Host ranges registered through hnsw_host_register, with the device address the runtime gave them.  The host-buffer
-// entry points access a caller's matrix directly from the device (zero-copy) only when it lies inside one of THESE
-// ranges: what the runtime's pointer queries say about memory somebody else pinned (or pinned once and freed) is not
+// Host ranges obtained through hnsw_host_alloc / hnsw_host_register, with the device address the runtime gave them.  The
+// host-buffer entry points access a caller's matrix directly from the device (zero-copy) only when it lies inside one of
+// THESE ranges: what the runtime's pointer queries say about memory somebody else pinned (or pinned once and freed) is not
 // trusted with a kernel's loads and stores.
-struct HostRange { const char *p; size_t bytes; char *dev; };
+//
+// A range also remembers who may still be READING it: an entry point that returns before the device is done with the
+// caller's matrix (hnsw_search_batch_h2d: the kernels read it in place; hnsw_search_submit: the upload is a DMA out of it)
+// leaves an event behind its last reader on that stream (range_reader_enqueued).  hnsw_host_unregister / hnsw_host_free wait
+// for those events before the pages are unpinned or freed: unregistering early is slow, never a GPU page fault (round 4's
+// second suite abort was exactly that: DESIGN.md section 7).
+struct InFlight { hipStream_t st; hipEvent_t ev; };
+enum { RANGE_ALLOCATED = 0, RANGE_REGISTERED = 1, RANGE_FOREIGN = 2 };   // hipHostMalloc / hipHostRegister by this library / pinned by somebody else
+struct HostRange { const char *p; size_t bytes; char *dev; int kind; std::vector<InFlight> readers; };
 std::mutex g_ranges_mu;
 std::vector<HostRange> g_ranges;
 
 void *registered_device_address(const void *p, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_ranges_mu);
     for (const HostRange &r : g_ranges)
-        if ((const char *)p >= r.p && (const char *)p + bytes <= r.p + r.bytes) return r.dev + ((const char *)p - r.p);
+        if (r.dev && (const char *)p >= r.p && (const char *)p + bytes <= r.p + r.bytes) return r.dev + ((const char *)p - r.p);
     return nullptr;
+}
+
+// `st` (of the current device) has just been given work that reads [p, p + bytes) after the entry point returns
+void range_reader_enqueued(const void *p, size_t bytes, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_ranges_mu);
+    for (HostRange &r : g_ranges) {
+        if (!((const char *)p >= r.p && (const char *)p + bytes <= r.p + r.bytes)) continue;
+        for (InFlight &f : r.readers)
+            if (f.st == st) { (void)hipEventRecord(f.ev, st); return; }   // work on one stream is ordered: the later record covers the earlier reader
+        InFlight f{st, nullptr};
+        if (hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipEventRecord(f.ev, st) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(f.ev); return; }
+        r.readers.push_back(f);
+        return;
+    }
 }
 
 int fail(int code, const char *fmt, ...) {
@@ -79,7 +102,7 @@ int upload_upper_ref(const int32_t *off, const uint8_t *lvl, int64_t n, void **d
 #define HNSW_DECL_VARIANT(m, s, f)                                                                          \
     namespace hnsw_host {                                                                                    \
     hipError_t search_launch_##m##_##s##_##f(int nch, int nslot, const IndexView &iv, const SearchArgs &a, hipStream_t st); \
-    int search_occupancy_##m##_##s##_##f(int nch, int nslot, size_t lds);                                    \
+    int search_occupancy_##m##_##s##_##f(int nch, int nslot, size_t lds, int blk);                                    \
     }
 HNSW_DECL_VARIANT(0, 0, 0) HNSW_DECL_VARIANT(0, 0, 1) HNSW_DECL_VARIANT(0, 0, 2) HNSW_DECL_VARIANT(0, 0, 3)
 HNSW_DECL_VARIANT(0, 1, 0) HNSW_DECL_VARIANT(0, 1, 1) HNSW_DECL_VARIANT(0, 1, 2) HNSW_DECL_VARIANT(0, 1, 3)
@@ -90,7 +113,7 @@ HNSW_DECL_VARIANT(1, 1, 0) HNSW_DECL_VARIANT(1, 1, 1) HNSW_DECL_VARIANT(1, 1, 2)
 namespace {
 
 typedef hipError_t (*search_launch_fn)(int, int, const IndexView &, const SearchArgs &, hipStream_t);
-typedef int (*search_occupancy_fn)(int, int, size_t);
+typedef int (*search_occupancy_fn)(int, int, size_t, int);
 const search_launch_fn k_launch[2][2][4] = {
     {{search_launch_0_0_0, search_launch_0_0_1, search_launch_0_0_2, search_launch_0_0_3}, {search_launch_0_1_0, search_launch_0_1_1, search_launch_0_1_2, search_launch_0_1_3}},
     {{search_launch_1_0_0, search_launch_1_0_1, search_launch_1_0_2, search_launch_1_0_3}, {search_launch_1_1_0, search_launch_1_1_1, search_launch_1_1_2, search_launch_1_1_3}}};
@@ -134,21 +157,90 @@ int knn_vt_bits(hnsw_index *idx, int ef, int semf) {
     const int vkey = ((nslot * 2 + semf) * 4 + variant_full(idx)) * 32 + base;
     if (idx->vt_grow_key == vkey) return idx->vt_grow_bits;
     const search_occupancy_fn occ = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)];
-    const int occ0 = occ(nch, nslot, hnsw_dev::wave_lds_words(base) * sizeof(uint32_t));
+    const int occ0 = occ(nch, nslot, hnsw_dev::wave_lds_words(base) * sizeof(uint32_t), 0);
     int b = base;
-    while (occ0 > 0 && b < 14 && occ(nch, nslot, hnsw_dev::wave_lds_words(b + 1) * sizeof(uint32_t)) >= occ0) ++b;
+    while (occ0 > 0 && b < 14 && occ(nch, nslot, hnsw_dev::wave_lds_words(b + 1) * sizeof(uint32_t), 0) >= occ0) ++b;
     idx->vt_grow_key = vkey; idx->vt_grow_bits = b;
     return b;
+}
+
+int launch_search_args(hnsw_index *idx, SearchArgs &a, hipStream_t st);
+
+// Visited as bitmap blocks over the locality codes (visited_blocks_mem_add; hnsw_locality.hip) for the kernels with W in four
+// or more registers (ef > 128: the walks that visit several times what the tag cache holds): log2 of the block slots, or 0 =
+// the tag cache.  The slots are as many as fit the LDS of the waves per CU the variant reaches with the tag cache (C5's and
+// C3's kernels, 16 waves per CU: 2^8 blocks = 65 536 codes).
+// Which of the two forgets less depends on the DATA -- on clustered vectors the blocks end C5's shape's 40 % repeated
+// evaluations (1-4 % left); on structureless vectors no numbering has locality, a block holds one visited node and the tag
+// cache wins -- so unless the caller decides (option "visited_blocks" 0 / 1, HNSW_VISITED_BLOCKS), the handle MEASURES, once
+// per kernel shape: 256 of the index's own vectors are searched both ways and the evaluations counted; the blocks are taken
+// when they save at least 5 %.  The measurement (and building the codes: one descent per node per upper layer, a sort) runs
+// inside the first search call that needs the answer and synchronises the device; indices of fewer than 200 000 nodes are
+// not measured (a walk cannot visit much more than the tag cache holds).  Never changes results.
+int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
+    const int nslot = pick_nslot(ef);
+    int ls = 0;
+    while ((1 << ls) < nslot) ++ls;
+    if (ls > 4) return 0;
+    const int mode = idx->blk_mode >= 0 ? idx->blk_mode : env_int("HNSW_VISITED_BLOCKS", -1);
+    if (mode == 0 || nslot < 4 || idx->lcode_state < 0) return 0;
+    if (mode < 0 && idx->iv.n < env_int("HNSW_VISITED_BLOCKS_MIN_N", 200000)) return 0;
+    // left to itself the handle only considers the shapes whose hand-scheduled loop has the block filter (float32 rows of 65..128
+    // dimensions -- full, ragged or split --, W in four or eight registers: C3's and C5's kernels); an explicit "visited_blocks" 1
+    // also runs the other shapes' C++ loop with it
+    if (mode < 0 && !(variant_full(idx) != 2 && pick_nch(idx->iv.nchunks) == 2 && idx->iv.nchunks > 16 && nslot <= 8)) return 0;
+    int &choice = idx->blk_choice[ls][semf];
+    if (choice >= 0) return choice;
+    // the largest directory that keeps the variant's waves per CU
+    const int nch = pick_nch(idx->iv.nchunks), vt = knn_vt_bits(idx, ef, semf);
+    const search_occupancy_fn occ = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)];
+    // (the waves per CU of the tag-cache kernel, or of the block kernel at its smallest directory if its registers allow fewer)
+    const int occ0 = std::min(occ(nch, nslot, hnsw_dev::wave_lds_words(vt) * sizeof(uint32_t), 0),
+                              occ(nch, nslot, hnsw_dev::search_lds_words(vt, 6) * sizeof(uint32_t), 1));
+    int bits = 0;
+    for (int b = 6; b <= 10; ++b)
+        if (hnsw_dev::wave_lds_words_blocks(b) * sizeof(uint32_t) <= 65536 && occ0 > 0 &&
+            occ(nch, nslot, hnsw_dev::search_lds_words(vt, b) * sizeof(uint32_t), 1) >= occ0) bits = b;
+    if (bits == 0) return choice = 0;
+    if (build_locality_codes(idx) != HNSW_OK || idx->lcode_state != 1) return choice = 0;
+    if (mode == 1) return choice = bits;
+    // measure: every (n / 256)-th vector of the index as a query (a strided view of the vector table), k = 1
+    const int64_t nq = std::min<int64_t>(256, idx->iv.n), step = idx->iv.n / nq;
+    DevBuf out;
+    if (out.ensure((size_t)nq * 16) != HNSW_OK) return choice = 0;
+    uint64_t sum[2] = {0, 0};
+    bool ok = true;
+    for (int pass = 0; pass < 2 && ok; ++pass) {
+        SearchArgs a{};
+        a.Q = (const float *)idx->dX; a.q_stride = step * idx->iv.stride; a.nq = nq; a.ef = ef; a.k = 1; a.fill = HNSW_FILL_OHNSW; a.sem = semf;
+        a.vt_bits = vt; a.blk_bits = pass ? bits : 0; a.prio_tail = 0x7FFFFFFF;
+        a.out_ids = (int32_t *)out.p; a.out_dist = (float *)out.p + nq; a.out_ndist = (uint32_t *)out.p + 2 * nq; a.out_nhops = (uint32_t *)out.p + 3 * nq;
+        std::vector<uint32_t> nd((size_t)nq);
+        ok = launch_search_args(idx, a, nullptr) == HNSW_OK && hipDeviceSynchronize() == hipSuccess &&
+             hipMemcpy(nd.data(), a.out_ndist, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        for (uint32_t v : nd) sum[pass] += v;
+    }
+    out.release();
+    if (!ok) { (void)hipGetLastError(); return choice = 0; }
+    choice = (double)sum[1] <= 0.95 * (double)sum[0] ? bits : 0;
+    if (env_int("HNSW_DEBUG_VISITED", 0))
+        fprintf(stderr, "hnsw: visited set for ef %d (W in %d registers, rule %d): tag cache %.0f evaluations per sample query, 2^%d blocks %.0f -> %s\n",
+                ef, nslot, semf, (double)sum[0] / (double)nq, bits, (double)sum[1] / (double)nq, choice ? "blocks" : "tags");
+    return choice;
+}
+// LDS bytes of one search wave of this index at this ef (no padding)
+size_t knn_lds_bytes(hnsw_index *idx, int ef, int semf) {
+    return hnsw_dev::search_lds_words(knn_vt_bits(idx, ef, semf), knn_blk_bits(idx, ef, semf)) * sizeof(uint32_t);
 }
 
 // how many one-wave workgroups of the search kernel for this ef are resident on the device at once (no LDS padding)
 int64_t resident_queries(hnsw_index *idx, int ef, int semf) {
     // cached in the handle; the answer depends on the kernel variant's registers and LDS
     const int nslot = pick_nslot(ef), nch = pick_nch(idx->iv.nchunks);
-    const size_t lds = hnsw_dev::wave_lds_words(knn_vt_bits(idx, ef, semf)) * sizeof(uint32_t);
+    const size_t lds = knn_lds_bytes(idx, ef, semf);
     const int vkey = (nslot * 2 + semf) * 4 + variant_full(idx);
     if (idx->resident_queries && idx->resident_nslot == vkey && idx->resident_lds == lds) return idx->resident_queries;
-    const int per_cu = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)](nch, nslot, lds);
+    const int per_cu = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)](nch, nslot, lds, knn_blk_bits(idx, ef, semf) > 0);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, idx->device) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
     const int64_t v = (per_cu > 0 && cus > 0) ? (int64_t)per_cu * cus : (int64_t)1 << 40;   // unknown: never reorder
@@ -168,7 +260,7 @@ int64_t resident_queries(hnsw_index *idx, int ef, int semf) {
 int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
     const int forced = idx->lds_pad >= 0 ? idx->lds_pad : env_int("HNSW_LDS_PAD", -1);
     if (forced >= 0) {     // an explicit request is clamped to what a workgroup may ask for beside its own scratch
-        const int64_t base_f = (int64_t)(hnsw_dev::wave_lds_words(knn_vt_bits(idx, ef, semf)) * sizeof(uint32_t));
+        const int64_t base_f = (int64_t)knn_lds_bytes(idx, ef, semf);
         return (int)std::max<int64_t>(0, std::min<int64_t>(std::min(forced, 32768), 65536 - base_f));
     }
     const int64_t resident = resident_queries(idx, ef, semf);
@@ -177,7 +269,7 @@ int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
     // memory system, and holds as many queries as the registers allow (C2: 0.60 ms per call at 8192 held, 0.65 at 5376)
     if (idx->iv.X8) return 0;
     constexpr int64_t GRANULE = 1280, GRANULES_PER_CU = 128;
-    const int64_t base = (int64_t)(hnsw_dev::wave_lds_words(knn_vt_bits(idx, ef, semf)) * sizeof(uint32_t));
+    const int64_t base = (int64_t)knn_lds_bytes(idx, ef, semf);
     const int64_t passes = (nq + resident - 1) / resident;
     const int64_t want_per_cu = (nq + passes * idx->cus - 1) / (passes * idx->cus);
     const int64_t k0 = (base + GRANULE - 1) / GRANULE;
@@ -196,7 +288,7 @@ int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
         if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, idx->device) != hipSuccess) { (void)hipGetLastError(); max_lds = 65536; }
         const int nslot_ = pick_nslot(ef), nch_ = pick_nch(idx->iv.nchunks);
         const search_occupancy_fn occ = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)];
-        while (pad > 0 && (base + pad > max_lds || occ(nch_, nslot_, (size_t)(base + pad)) < want_per_cu)) pad = pad > GRANULE ? pad - GRANULE : 0;
+        while (pad > 0 && (base + pad > max_lds || occ(nch_, nslot_, (size_t)(base + pad), knn_blk_bits(idx, ef, semf) > 0) < want_per_cu)) pad = pad > GRANULE ? pad - GRANULE : 0;
     }
     if (idx->debug_last_nq != nq && env_int("HNSW_DEBUG_RESIDENT", 0) && ((idx->debug_last_nq = nq), true))
         fprintf(stderr, "hnsw: nq %lld, %d waves/CU x %d CUs resident, %lld passes -> want %lld waves/CU: LDS %lld + %lld B\n",
@@ -379,7 +471,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
 int32_t hnsw_index_destroy(hnsw_index *idx) {
     if (!idx) return HNSW_OK;
     if (idx->device >= 0) (void)hipSetDevice(idx->device);
-    for (void *p : {idx->dX, idx->dX8, idx->dXm, idx->dTail0, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl, idx->dRef}) if (p) (void)hipFree(p);
+    for (void *p : {idx->dX, idx->dX8, idx->dXm, idx->dTail0, idx->dLcode, idx->dLcode0, idx->dNbr0, idx->dNbrU, idx->dOff, idx->dLvl, idx->dRef}) if (p) (void)hipFree(p);
     idx->dFbSlab.release(); idx->dFbMap.release();
     idx->sQ.release(); idx->sIds.release(); idx->sDist.release(); idx->sNd.release(); idx->sNh.release(); idx->sSt.release(); idx->sFlag.release();
     (void)hipDeviceSynchronize();                      // requests never waited for
@@ -402,6 +494,15 @@ int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info) {
     return HNSW_OK;
 }
 
+int32_t hnsw_index_locality_codes(hnsw_index *idx, int32_t *out) {
+    if (!idx || !out) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    int rc = build_locality_codes(idx);
+    if (rc) return rc;
+    if (idx->lcode_state != 1) return fail(HNSW_ERR_UNSUPPORTED, "no locality codes: the index has no upper layer (or no room for the tables)");
+    HIP_TRY(hipMemcpy(out, idx->dLcode, (size_t)idx->iv.n * 4, hipMemcpyDeviceToHost));
+    return HNSW_OK;
+}
+
 int32_t hnsw_index_row_bytes(const hnsw_index *idx, int64_t *row_bytes) {
     if (!idx || !row_bytes) return fail(HNSW_ERR_BAD_ARG, "null argument");
     *row_bytes = idx->iv.X8 ? (int64_t)idx->iv.d : (int64_t)idx->iv.d * 4;
@@ -416,11 +517,26 @@ int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) 
         idx->iv.X8 = value != 0 ? (const uint8_t *)idx->dX8 : nullptr;
         return HNSW_OK;
     }
-    if (!strcmp(name, "split_rows")) {    // 0: search the plain fp32 rows even where a split copy exists; otherwise: use it where it exists
-        idx->iv.Xm = value != 0 ? (const float *)idx->dXm : nullptr;
+    if (!strcmp(name, "split_rows")) {    // 0: search the plain fp32 rows even where a split copy exists; -1: ... and free the copy; otherwise: use it where it exists
+        if (value < 0 && idx->dXm) {
+            HIP_TRY(hipSetDevice(idx->device));
+            HIP_TRY(hipDeviceSynchronize());             // launches that still read the copy
+            idx->info.device_bytes -= idx->iv.n * idx->iv.stride_m + idx->iv.n * idx->iv.S0 * 16 * idx->iv.tail_chunks;
+            (void)hipFree(idx->dXm); (void)hipFree(idx->dTail0);
+            idx->dXm = nullptr; idx->dTail0 = nullptr; idx->iv.tail0 = nullptr;
+        }
+        idx->iv.Xm = value > 0 ? (const float *)idx->dXm : nullptr;
+        idx->resident_queries = 0; idx->vt_grow_key = -1;
+        for (auto &c : idx->blk_choice) c[0] = c[1] = -1;
         return HNSW_OK;
     }
     if (!strcmp(name, "time_kernels")) { idx->time_kernels = value != 0; return HNSW_OK; }
+    if (!strcmp(name, "visited_blocks")) {   // -1: measured per kernel shape (default); 0: the tag cache; 1: bitmap blocks wherever the codes can be built
+        idx->blk_mode = value < 0 ? -1 : (value ? 1 : 0);
+        for (auto &c : idx->blk_choice) c[0] = c[1] = -1;
+        idx->resident_queries = 0;            // (the LDS per wave, hence the residency, may differ)
+        return HNSW_OK;
+    }
     if (!strcmp(name, "device_fallback_slab_bytes")) {
         // room for the tie lists of value / (4 n) flagged queries per call (a flagged query may need a slot per node)
         HIP_TRY(hipSetDevice(idx->device));
@@ -454,6 +570,7 @@ int search_rerun_device(hnsw_index *idx, const float *d_queries, int64_t nq, int
     a.Q = d_queries; a.q_stride = q_stride; a.nq = c; a.ef = p->ef; a.k = p->k;
     a.fill = p->fill; a.sem = p->semantics;
     a.vt_bits = knn_vt_bits(idx, p->ef, p->semantics ? 1 : 0);
+    a.blk_bits = knn_blk_bits(idx, p->ef, p->semantics ? 1 : 0);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_nd; a.out_nhops = d_nh; a.out_status = d_st;
     a.qmap = qmap; a.q_limit = nq; a.ovf_g = slab; a.ovf_gcap = cap; a.prio_tail = 0x7FFFFFFF;
     return launch_search_args(idx, a, st);
@@ -496,6 +613,7 @@ extern "C++" int hnsw_host::search_batch_device_flag(hnsw_index *idx, const floa
     SearchArgs a{};
     a.Q = d_queries; a.q_stride = q_stride; a.nq = nq; a.ef = params->ef; a.k = params->k; a.fill = params->fill; a.sem = params->semantics;
     a.vt_bits = knn_vt_bits(idx, params->ef, params->semantics ? 1 : 0);
+    a.blk_bits = knn_blk_bits(idx, params->ef, params->semantics ? 1 : 0);
     a.out_ids = d_ids; a.out_dist = d_dist; a.out_ndist = d_ndist; a.out_nhops = d_nhops; a.out_status = d_status;
     a.any_flag = d_any_flag;
     a.prio_tail = 0x7FFFFFFF;
@@ -534,8 +652,9 @@ extern "C++" int hnsw_host::search_batch_device_flag(hnsw_index *idx, const floa
         const int32_t cap = (int32_t)idx->fb_queries;
         hipLaunchKernelGGL(flagged_list_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint32_t *)d_status, nq, (int32_t *)idx->dFbMap.p, cap);
         if (hipGetLastError() != hipSuccess) return fail(HNSW_ERR_HIP, "flagged-query listing failed");
+        // (at most min(cap, nq) queries can be listed: no more blocks than that; the blocks past the count leave at once)
         rc = search_rerun_device(idx, a.Q, nq, q_stride, params, d_ids, d_dist, d_ndist, d_nhops, d_status, (const int32_t *)idx->dFbMap.p,
-                                 cap, (uint32_t *)idx->dFbSlab.p, (int32_t)std::min<int64_t>(idx->iv.n, 0x7FFFFFFF), (hipStream_t)stream);
+                                 std::min<int64_t>(cap, nq), (uint32_t *)idx->dFbSlab.p, (int32_t)std::min<int64_t>(idx->iv.n, 0x7FFFFFFF), (hipStream_t)stream);
     }
     if (ev && !rc) {
         HIP_TRY(hipEventRecord(ev[2], (hipStream_t)stream));
@@ -668,8 +787,12 @@ int32_t hnsw_search_batch_h2d(hnsw_index *idx, const float *queries, int64_t nq,
     const float *zq = zero_copy ? (const float *)registered_device_address(queries, qbytes) : nullptr;
     if (!zq) HIP_TRY(hipMemcpyAsync(idx->sQ.p, queries, qbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     // registered matrix: read by the device directly, the pre-pass (when there is one) leaves the device copy in sQ
-    return search_batch_device_flag(idx, zq ? zq : (const float *)idx->sQ.p, nq, q_stride, params, d_ids, d_dist, d_ndist, d_nhops, d_status,
-                                    nullptr, stream, zq ? (float *)idx->sQ.p : nullptr);
+    rc = search_batch_device_flag(idx, zq ? zq : (const float *)idx->sQ.p, nq, q_stride, params, d_ids, d_dist, d_ndist, d_nhops, d_status,
+                                  nullptr, stream, zq ? (float *)idx->sQ.p : nullptr);
+    // the call returns while the device still reads the caller's matrix (in place, or as the source of the DMA above): the
+    // range remembers it, so that hnsw_host_unregister / hnsw_host_free wait instead of pulling the pages from under a kernel
+    range_reader_enqueued(queries, qbytes, (hipStream_t)stream);
+    return rc;
 }
 
 int32_t hnsw_search_submit(hnsw_index *idx, const float *queries, int64_t nq, int64_t q_stride,
@@ -698,6 +821,7 @@ int32_t hnsw_search_submit(hnsw_index *idx, const float *queries, int64_t nq, in
     hipStream_t st = idx->hs[r->stream];
     if (hipMemcpyAsync(r->q.p, queries, qbytes, hipMemcpyHostToDevice, st) != hipSuccess)
         return give_back(fail(HNSW_ERR_HIP, "query upload failed"));
+    range_reader_enqueued(queries, qbytes, st);    // page-locked source: the DMA above outlives this call (see hnsw_host_unregister)
     if (hipMemsetAsync(r->flag.p, 0, 4, st) != hipSuccess) return give_back(fail(HNSW_ERR_HIP, "hipMemsetAsync failed"));
     rc = search_batch_device_flag(idx, (const float *)r->q.p, nq, q_stride, params, (int32_t *)r->ids.p, (float *)r->dist.p,
                                   (uint32_t *)r->nd.p, (uint32_t *)r->nh.p, (uint32_t *)r->st.p, (uint32_t *)r->flag.p, st);
@@ -750,42 +874,86 @@ int32_t hnsw_search_wait(hnsw_request *r, int32_t *out_ids, float *out_dist, uin
 }
 
 namespace {
-void remember_range(const void *p, size_t bytes, void *dev) {
+void remember_range(const void *p, size_t bytes, void *dev, int kind) {
     std::lock_guard<std::mutex> lk(g_ranges_mu);
-    for (HostRange &r : g_ranges) if (r.p == (const char *)p) { r.bytes = std::max(r.bytes, bytes); r.dev = (char *)dev; return; }
-    g_ranges.push_back({(const char *)p, bytes, (char *)dev});
+    g_ranges.push_back({(const char *)p, bytes, (char *)dev, kind, {}});
 }
-void forget_range(const void *p) {
-    std::lock_guard<std::mutex> lk(g_ranges_mu);
-    for (size_t i = 0; i < g_ranges.size(); ++i) if (g_ranges[i].p == (const char *)p) { g_ranges.erase(g_ranges.begin() + (long)i); return; }
+// takes the range that STARTS at p off the list (no launch can pick it for direct access any more) and waits for the
+// readers that earlier asynchronous calls left on it; false: no such range
+bool retire_range(const void *p, int *kind) {
+    std::vector<InFlight> readers;
+    {
+        std::lock_guard<std::mutex> lk(g_ranges_mu);
+        size_t i = 0;
+        while (i < g_ranges.size() && g_ranges[i].p != (const char *)p) ++i;
+        if (i == g_ranges.size()) return false;
+        *kind = g_ranges[i].kind;
+        readers.swap(g_ranges[i].readers);
+        g_ranges.erase(g_ranges.begin() + (long)i);
+    }
+    for (InFlight &f : readers) {
+        if (hipEventSynchronize(f.ev) != hipSuccess) (void)hipGetLastError();
+        (void)hipEventDestroy(f.ev);
+    }
+    return true;
 }
 } // namespace
 
 int32_t hnsw_host_register(void *p, int64_t bytes) {
     if (!p || bytes <= 0) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_register: null buffer or bytes <= 0");
+    const char *b = (const char *)p, *e_ = b + bytes;
+    {   // this library's own list decides about overlaps (the runtime answers "success" for an array that merely STARTS
+        // inside an existing registration and leaves the rest pageable: measured on ROCm 7.2)
+        std::lock_guard<std::mutex> lk(g_ranges_mu);
+        for (const HostRange &r : g_ranges) {
+            if (b >= r.p && e_ <= r.p + r.bytes) return HNSW_OK;          // registered already: twice is not an error
+            if (b < r.p + r.bytes && r.p < e_)
+                return fail(HNSW_ERR_BAD_ARG, "hnsw_host_register: part of the %lld-byte array is registered already, the rest is not "
+                            "(unregister the shorter range first)", (long long)bytes);
+        }
+    }
     hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
-    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); e = hipSuccess; }
+    if (e == hipErrorHostMemoryAlreadyRegistered) {
+        // pinned by somebody else (the application, another library): theirs to unpin.  Copies out of it run at pinned speed
+        // anyway; the library neither maps it for direct access nor ever unregisters it.
+        (void)hipGetLastError();
+        remember_range(p, (size_t)bytes, nullptr, RANGE_FOREIGN);
+        return HNSW_OK;
+    }
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostRegister(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); }
-    // The runtime answers "success" (or "already registered") for a range that merely STARTS inside an existing
-    // registration and leaves the rest pageable (measured on ROCm 7.2: a 1 MB prefix registered, then the 4 MB array:
-    // success, last byte still unregistered).  The whole array is registered only if both of its ends are.
+    // "success" is believed only if every page answers as page-locked host memory (at most 4096 probes: the step grows with
+    // the array) -- a foreign registration that covers only the array's beginning, or its two ends, leaves pageable pages
+    // that a kernel's loads would fault on
     auto locked = [](const void *q) {
         hipPointerAttribute_t a{};
         if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
         return a.type == hipMemoryTypeHost;
     };
-    if (!locked(p) || !locked((const char *)p + bytes - 1))
-        return fail(HNSW_ERR_BAD_ARG, "hnsw_host_register: part of the %lld-byte array is registered already, its end is not "
-                    "(unregister the shorter range first)", (long long)bytes);
+    const size_t step = std::max<size_t>(4096, (((size_t)bytes / 4096) + 4095) / 4096 * 4096);
+    bool whole = locked(e_ - 1);
+    for (size_t o = 0; whole && o < (size_t)bytes; o += step) whole = locked(b + o);
+    if (!whole) {
+        if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+        return fail(HNSW_ERR_BAD_ARG, "hnsw_host_register: part of the %lld-byte array is registered already (by someone else), the rest is not",
+                    (long long)bytes);
+    }
     void *dev = nullptr;
     if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }   // no mapping: copies only
-    if (dev) remember_range(p, (size_t)bytes, dev);
+    remember_range(p, (size_t)bytes, dev, RANGE_REGISTERED);
     return HNSW_OK;
 }
 
 int32_t hnsw_host_unregister(void *p) {
     if (!p) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_unregister: null buffer");
-    forget_range(p);
+    int kind = 0;
+    {   // a block of hnsw_host_alloc is freed with hnsw_host_free, not unregistered
+        std::lock_guard<std::mutex> lk(g_ranges_mu);
+        for (const HostRange &r : g_ranges)
+            if (r.p == (const char *)p && r.kind == RANGE_ALLOCATED) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_unregister: this block came from hnsw_host_alloc (hnsw_host_free releases it)");
+    }
+    if (!retire_range(p, &kind))       // (waits for the asynchronous calls that still read the range)
+        return fail(HNSW_ERR_BAD_ARG, "hnsw_host_unregister: no range registered through hnsw_host_register starts at %p", p);
+    if (kind == RANGE_FOREIGN) return HNSW_OK;                 // not this library's registration to undo
     hipError_t e = hipHostUnregister(p);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostUnregister failed: %s", hipGetErrorString(e)); }
     return HNSW_OK;
@@ -797,15 +965,22 @@ int32_t hnsw_host_alloc(void **out, int64_t bytes) {
     void *p = nullptr, *dev = nullptr;
     hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(e == hipErrorOutOfMemory ? HNSW_ERR_OOM : HNSW_ERR_HIP, "hipHostMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); }
-    if (hipHostGetDevicePointer(&dev, p, 0) == hipSuccess && dev) remember_range(p, (size_t)bytes, dev);
-    else (void)hipGetLastError();
+    if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }
+    remember_range(p, (size_t)bytes, dev, RANGE_ALLOCATED);
     *out = p;
     return HNSW_OK;
 }
 
 int32_t hnsw_host_free(void *p) {
     if (!p) return HNSW_OK;
-    forget_range(p);
+    int kind = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_ranges_mu);
+        bool mine = false;
+        for (const HostRange &r : g_ranges) mine = mine || (r.p == (const char *)p && r.kind == RANGE_ALLOCATED);
+        if (!mine) return fail(HNSW_ERR_BAD_ARG, "hnsw_host_free: %p is not a block of hnsw_host_alloc", p);
+    }
+    (void)retire_range(p, &kind);      // (waits for the asynchronous calls that still read the block)
     hipError_t e = hipHostFree(p);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostFree failed: %s", hipGetErrorString(e)); }
     return HNSW_OK;

@@ -70,6 +70,11 @@ struct IndexView {
     int32_t stride_m;        // bytes per main row = 16 * main_chunks
     int32_t main_chunks;     // multiple of 8
     int32_t tail_chunks;     // 1 or 2; main_chunks + tail_chunks == nchunks
+    // optional locality codes (hnsw_locality.hip): a bijection node -> position in an order that keeps graph-close nodes
+    // together, and the same for every slot of layer 0's adjacency (lcode0[c][j] = lcode[nbr0[c][j]]): what the visited
+    // set's bitmap blocks are keyed by (visited_blocks_*).  nullptr = not built
+    const int32_t *lcode;    // [n]
+    const int32_t *lcode0;   // [n][S0]
 };
 
 struct SearchArgs {
@@ -79,6 +84,7 @@ struct SearchArgs {
     int32_t ef, k, fill;
     int32_t sem;             // 0 = Ohnsw accept rule, 1 = functor (Nearest.insert_distance) rule, 2 = 1 + nearest_k's output
     int32_t vt_bits;         // log2 of the LDS visited-cache entries
+    int32_t blk_bits;        // 0: the visited set is the tag cache; else log2 of its bitmap-block slots (visited_blocks_*: needs iv.lcode0)
     int32_t lds_pad;         // bytes of LDS requested beyond wave_lds_words(vt_bits): never touched; the host uses it to choose how many waves a CU holds (balanced_lds_pad)
     int32_t *out_ids;
     float *out_dist;
@@ -541,6 +547,8 @@ struct WaveCtx {
     int set_bits;        // vt_bits - 1
     uint32_t tag_shift;  // 16: two 16-bit tags per word; 10: three 10-bit tags (visited_three_ways)
     int vt_words;
+    uint32_t blk_set_mask;   // visited as bitmap blocks (visited_blocks_*): #sets - 1 of the block directory ...
+    uint32_t *blk_bm;        // ... and the slots' bitmaps (BLK_WORDS words each); nullptr: the tag cache is in use
     int32_t *cand_id;    // [64]
     uint32_t *cand_key;  // [64]
     uint32_t *trash;     // [64] write-only sink shared by every masked-off store
@@ -552,7 +560,17 @@ struct WaveCtx {
 };
 // 4 KiB of tags at vt_bits = 11 plus 1 KiB: 28 waves per CU fit the 160 KiB LDS
 __host__ __device__ inline size_t wave_lds_words(int vt_bits) { return (((size_t)1 << vt_bits) >> 1) + 192 + OVF_CAP; }
-__device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane) {
+// Visited as a cache of BITMAP BLOCKS over the locality codes (IndexView::lcode0): 2^blk_bits slots, each a block of
+// 2^BLK_SHIFT consecutive codes = BLK_WORDS words of bits, in sets of BLK_WAYS slots; a slot's directory word is
+// (block number << 8) | stamp of its last use.  See visited_blocks_mem_add.
+constexpr int BLK_SHIFT = 8, BLK_WORDS = (1 << BLK_SHIFT) / 32, BLK_WAYS = 8;
+__host__ __device__ inline size_t wave_lds_words_blocks(int blk_bits) { return ((size_t)(1 + BLK_WORDS) << blk_bits) + 192 + OVF_CAP; }
+// LDS words of one search wave (the launch's dynamic LDS, before any padding)
+__host__ __device__ inline size_t search_lds_words(int vt_bits, int blk_bits) {
+    const size_t t = wave_lds_words(vt_bits), b = blk_bits > 0 ? wave_lds_words_blocks(blk_bits) : 0;
+    return t > b ? t : b;
+}
+__device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane, int blk_bits = 0) {
     WaveCtx cx;
     cx.qint = false; cx.q2 = 0;
     cx.lane = lane; cx.r = lane >> 4; cx.l16 = lane & 15;
@@ -561,6 +579,12 @@ __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane
     cx.tag_shift = 16;
     cx.set_mask = (1u << (vt_bits - 1)) - 1u;
     cx.vt_words = 1 << (vt_bits - 1);
+    cx.blk_set_mask = 0; cx.blk_bm = nullptr;
+    if (blk_bits > 0) {      // directory words first (what visited_clear resets), the bitmaps behind them
+        cx.blk_set_mask = ((1u << blk_bits) / BLK_WAYS) - 1u;
+        cx.blk_bm = lds + (1 << blk_bits);
+        cx.vt_words = (1 + BLK_WORDS) << blk_bits;
+    }
     uint32_t *rest = lds + cx.vt_words;
     cx.cand_id = reinterpret_cast<int32_t *>(rest);
     cx.cand_key = rest + 64;
@@ -569,7 +593,9 @@ __device__ __forceinline__ WaveCtx make_ctx(uint32_t *lds, int vt_bits, int lane
     return cx;
 }
 __device__ __forceinline__ void visited_clear(const WaveCtx &cx) { // Visited.clear, lib/ohnsw.ml:262
-    for (int i = cx.lane; i < cx.vt_words; i += 64) cx.vt[i] = 0xFFFFFFFFu;
+    const int words = cx.blk_bm ? (int)(cx.blk_bm - cx.vt) : cx.vt_words;   // blocks: empty directory words; a bitmap is cleared when its slot is claimed
+    const uint32_t empty = cx.blk_bm ? 0xFFFFFF00u : 0xFFFFFFFFu;
+    for (int i = cx.lane; i < words; i += 64) cx.vt[i] = empty;
 }
 // Visited.mem (lib/ohnsw.ml:259); `word` returns the set's current content for the add that follows
 __device__ __forceinline__ bool visited_mem(const WaveCtx &cx, uint32_t id, uint32_t &word) {
@@ -593,6 +619,72 @@ __device__ __forceinline__ void visited_add_masked(const WaveCtx &cx, uint32_t i
     uint32_t *slot = on ? &cx.vt[id & cx.set_mask] : &cx.trash[cx.lane];
     *slot = (word << cx.tag_shift) | (id >> cx.set_bits);
 }
+
+// ---- Visited as bitmap blocks over locality codes -------------------------------------------------------------------
+// The tag cache above remembers 2^12 nodes in 8 KiB; a walk at ef 512 visits four times that, and on clustered data (where
+// neighbourhoods overlap) a forgotten node comes back: 40 % of the evaluations of C5's shape were repeats (round 4).  No
+// replacement policy fixes that (tools/visited_policy_sim.py: anything implementable stays above 30 %), and 2 bytes per
+// remembered node is within a quarter of the information-theoretic minimum for an arbitrary subset of 10 M ids.  What the
+// ids lack is LOCALITY: they are insertion order.  Under a code that numbers graph-close nodes consecutively (lcode: nodes
+// grouped by the layer-2 node their own descent reaches, those groups by their layer-3 node, ... -- hnsw_locality.hip) the
+// nodes a walk visits fill a few hundred blocks of 256 consecutive codes, a third of each: one BIT per node.  The same
+// 9 KiB then hold 256 blocks = 65 536 codes and the walk's re-evaluations fall to 1-4 % (same simulator, same traces).
+// Exact as the tag cache is: (block number, bit) identifies the code, the code identifies the node (a bijection); a slot's
+// bits are cleared before its directory word can match anybody.  What is lost is lost in whole blocks (the least recently
+// touched of the set's eight), never invented.
+//
+// One call handles all 64 neighbours of a hop: `code` the lane's neighbour's code, `valid` whether the lane holds a
+// neighbour at all, `now` the hop's stamp.  Returns Visited.mem (lib/ohnsw.ml:259) and performs Visited.add (:260) for the
+// lanes that answer false.  LDS operations of one wave execute in order, lane conflicts inside one store are decided by
+// the hardware (one lane wins); the steps below only rely on that:
+//   1 read the set's eight directory words; a lane whose block is there (hit) reads its bit -> the answer;
+//   2 every valid lane writes (block, now) to its slot -- a hit refreshes the stamp, a miss claims the set's least recently
+//     used slot (several misses on one set claim the same slot: one wins);
+//   3 every lane reads its slot's word back: it OWNS the slot iff the word carries its block;
+//   4 owners that missed clear the slot's bitmap (all of them the same words, before any bit is set);
+//   5 owners whose answer was false set their bit (atomic OR: several lanes may share a word).
+// A lane that lost its slot in step 2 evaluates its neighbour without remembering it -- harmless, like any forgetting.
+__device__ __forceinline__ bool visited_blocks_mem_add(const WaveCtx &cx, bool valid, uint32_t code, uint32_t now) {
+    const uint32_t b = code >> BLK_SHIFT, bit = code & ((1u << BLK_SHIFT) - 1u);
+    const uint32_t set = b & cx.blk_set_mask;
+    uint32_t *dir = cx.vt + set * BLK_WAYS;
+    uint32_t wd[BLK_WAYS];
+    {
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(dir), a1 = *reinterpret_cast<const uint4 *>(dir + 4);
+        wd[0] = a0.x; wd[1] = a0.y; wd[2] = a0.z; wd[3] = a0.w; wd[4] = a1.x; wd[5] = a1.y; wd[6] = a1.z; wd[7] = a1.w;
+    }
+    int hit = -1;
+    uint32_t oldest = 0;
+#pragma unroll
+    for (int i = 0; i < BLK_WAYS; ++i) {
+        if ((wd[i] >> 8) == b) hit = i;
+        // age modulo 256 (a block untouched for 512 hops looks young again: a worse victim choice, nothing else); an empty
+        // way is block 0xFFFFFF (no code reaches it) last touched at stamp 0: the oldest there is while the stamps have not wrapped
+        const uint32_t age = (now - wd[i]) & 255u;
+        const uint32_t key = (age << 3) | (uint32_t)i;
+        oldest = key > oldest ? key : oldest;
+    }
+    const int way = hit >= 0 ? hit : (int)(oldest & 7u);
+    uint32_t *slot_dir = dir + way;
+    uint32_t *bm = cx.blk_bm + (set * BLK_WAYS + (uint32_t)way) * BLK_WORDS;
+    bool seen = false;
+    if (hit >= 0) seen = (bm[bit >> 5] >> (bit & 31u)) & 1u;                       // 1
+    __syncthreads();
+    *(valid ? slot_dir : &cx.trash[cx.lane]) = (b << 8) | (now & 255u);            // 2
+    __syncthreads();
+    const bool own = valid && (*slot_dir >> 8) == b;                                // 3
+    __syncthreads();
+    if (own && hit < 0) {                                                           // 4
+        *reinterpret_cast<uint4 *>(bm) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(bm + 4) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    if (own && !seen) atomicOr(&bm[bit >> 5], 1u << (bit & 31u));                   // 5
+    __syncthreads();
+    return seen;
+}
+// the stamp of a hop (one step per two hops: 512 hops before it wraps)
+__device__ __forceinline__ uint32_t visited_blocks_stamp(uint32_t n_hops) { return (n_hops >> 1) & 255u; }
 
 // neighbour row of node c on `layer` (Graph.adjacent, lib/ohnsw.ml:171); -1 = hole / padding
 __device__ __forceinline__ int adj_entry(const IndexView &iv, int layer, int c, int lane) {
@@ -1052,7 +1144,9 @@ namespace hnsw_dev {
 // ROWS: 1 = every float4 chunk of the 16 x NCH lane grid lies inside a row (d in 64*NCH-3 .. 64*NCH: no
 // masking), 0 = ragged rows, 2 = byte rows (see hop_round), -1 = fp32 rows, shape decided at run time (the builder and
 // the layer operators; the knn kernel is instantiated per case so that neither pays for the other's registers).
-template <int NCH, int RB, int NSLOT, int METRIC, int SEM = 0, int ROWS = -1>
+// BLK 1 (the knn kernel's layer-0 search only): Visited is the bitmap-block cache over the neighbours' locality codes
+// (visited_blocks_mem_add) instead of the tag cache.
+template <int NCH, int RB, int NSLOT, int METRIC, int SEM = 0, int ROWS = -1, int BLK = 0>
 __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (&qv)[NCH], int layer,
                                              WList<NSLOT> &w, int ef, const WaveCtx &cx,
                                              uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
@@ -1072,18 +1166,24 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     constexpr bool ASM_F32N4 = HNSW_ASM_LOOP_F32 && HNSW_ASM_LOOP_F32N4 && NCH == 4 && ASM_NSLOT &&
                                (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT));                            // float32 rows of 129..256 dimensions
     constexpr bool ASM_F32 = (HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT))) || ASM_F32N4;
+    constexpr bool ASM_BLK = BLK != 0 && ASM_F32 && !ASM_F32N4 && NSLOT >= 4 && NSLOT <= 8;
     bool asm_ok = false;
     if constexpr (ASM_B8 || ASM_F32) {
         asm_ok = layer == 0 && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30) &&
                  (ASM_B8 ? cx.qint != 0 : iv.nchunks > (ASM_F32N4 ? 32 : 16));
+        // Visited as bitmap blocks: the loops over float32 rows of 65..128 dimensions with W in four / eight registers have it
+        if constexpr (BLK != 0) asm_ok = asm_ok && ASM_BLK;
     }
-    if constexpr (ASM_B8N4 && SEM == 0) {
+    if constexpr (ASM_BLK && SEM == 0) {
+        if (asm_ok) { search_layer0_f32_blk_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status); return; }
+    }
+    if constexpr (BLK == 0 && ASM_B8N4 && SEM == 0) {
         if (asm_ok) { search_layer0_bytes4_asm<NSLOT, METRIC>(iv, w, cx, n_dist, n_hops, status); return; }
     }
-    if constexpr (ASM_B8 && !ASM_B8N4 && SEM == 0 && METRIC == 1) {
+    if constexpr (BLK == 0 && ASM_B8 && !ASM_B8N4 && SEM == 0 && METRIC == 1) {
         if (asm_ok) { search_layer0_bytes_ip_asm<NSLOT>(iv, w, cx, n_dist, n_hops, status); return; }
     }
-    if constexpr (ASM_B8 && !ASM_B8N4 && SEM == 0 && METRIC == 0) {
+    if constexpr (BLK == 0 && ASM_B8 && !ASM_B8N4 && SEM == 0 && METRIC == 0) {
         if (asm_ok) {
             if constexpr (NSLOT == 1) { search_layer0_bytes_l2_asm1(iv, w, cx, n_dist, n_hops, status); return; }
             if constexpr (NSLOT == 4) { search_layer0_bytes_l2_asm4(iv, w, cx, n_dist, n_hops, status); return; }
@@ -1102,7 +1202,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             }
         }
     }
-    if constexpr (ASM_F32 && SEM == 0) {
+    if constexpr (BLK == 0 && ASM_F32 && SEM == 0) {
         if (asm_ok) {
             if constexpr (ASM_F32N4) search_layer0_f32n4_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status);
             else search_layer0_f32_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status);
@@ -1111,6 +1211,8 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     }
 #endif
     int pref_id = -1, pref_nb = -1;
+    uint32_t pref_code = 0;
+    constexpr bool blocks = BLK != 0;                              // Visited as bitmap blocks over the neighbours' locality codes
     PhaseClock pc;
 #ifdef HNSW_PHASE_TIMING
     pc.mark = clock64();
@@ -1125,7 +1227,9 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
             if (asm_ok && w.ovf_cnt == 0) {
                 HopResume rs;
                 bool left;
-                if constexpr (ASM_B8N4) left = search_layer0_bytes4_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
+                if constexpr (ASM_BLK) left = search_layer0_f32_blk_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
+                else if constexpr (BLK != 0) left = false;       // (asm_ok is false for the block kernels of other shapes)
+                else if constexpr (ASM_B8N4) left = search_layer0_bytes4_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
                 else if constexpr (ASM_B8) left = search_layer0_bytes_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
                 else if constexpr (ASM_F32N4) left = search_layer0_f32n4_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
                 else left = search_layer0_f32_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
@@ -1187,10 +1291,16 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         }
         n_hops++;
         int nb;
-        if (c == pref_id) { nb = pref_nb; status += 256u; }              // Graph.adjacent, :570 (bits 8..: prefetch hits)
-        else nb = adj_entry(iv, layer, c, lane);
-        uint32_t vword;
-        const bool seen = visited_mem(cx, (uint32_t)nb, vword);          // Visited.mem, :571 (a hole reads some set: harmless)
+        uint32_t code = 0;
+        if (c == pref_id) { nb = pref_nb; code = pref_code; status += 256u; }   // Graph.adjacent, :570 (bits 8..: prefetch hits)
+        else {
+            nb = adj_entry(iv, layer, c, lane);
+            if (blocks) code = lane < iv.S0 ? (uint32_t)iv.lcode0[(int64_t)c * iv.S0 + lane] : 0u;
+        }
+        uint32_t vword = 0;
+        bool seen;
+        if constexpr (blocks) seen = visited_blocks_mem_add(cx, nb >= 0, code, visited_blocks_stamp(n_hops));   // Visited.mem and .add, :571-572
+        else seen = visited_mem(cx, (uint32_t)nb, vword);                // Visited.mem, :571 (a hole reads some set: harmless)
         const bool fresh = (nb >= 0) & !seen;
         const uint64_t m = ballot(fresh);
         const int cnt = popc(m);
@@ -1201,12 +1311,15 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
         // issued only now so that it shares its flight with this hop's rows (loads return in order)
         int pidx;
         pref_id = wlist_take_first(w, um, pidx);                         // the next nearest unexpanded
-        if (pref_id >= 0) pref_nb = adj_entry(iv, layer, pref_id, lane);
+        if (pref_id >= 0) {
+            pref_nb = adj_entry(iv, layer, pref_id, lane);
+            if (blocks) pref_code = lane < iv.S0 ? (uint32_t)iv.lcode0[(int64_t)pref_id * iv.S0 + lane] : 0u;
+        }
         if (cnt != 0) {
             const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
             __syncthreads();
             if (fresh) {                                                 // Visited.add, :572
-                cx.vt[(uint32_t)nb & cx.set_mask] = (vword << cx.tag_shift) | ((uint32_t)nb >> cx.set_bits);
+                if (!blocks) cx.vt[(uint32_t)nb & cx.set_mask] = (vword << cx.tag_shift) | ((uint32_t)nb >> cx.set_bits);
                 cx.cand_id[pos] = nb;
                 if (ROWS == 3) cx.cand_key[pos] = (uint32_t)lane;        // split rows: where in c's row (= in its tail row) the candidate sits
             }
@@ -1309,7 +1422,8 @@ __device__ __forceinline__ void load_row(float4 (&qv)[NCH], const IndexView &iv,
      (HNSW_ASM_LOOP && (NCH) == 2 && (NSLOT) <= 4 && (METRIC) == 0 && (ROWS) == 2 && ((SEMF) == 0 || HNSW_SEM1_8WAVES)) ? 8 : 1)
 #endif
 // SEMF: 0 = Ohnsw accept rule, 1 = the functor path's (a.sem 1 and 2); ROWS: 0 | 1 | 2 | 3, see hop_round
-template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, int ROWS>
+// BLK: 1 = Visited as bitmap blocks (a.blk_bits slots, iv.lcode / lcode0 present), see search_layer
+template <int NCH, int RB, int NSLOT, int METRIC, int SEMF, int ROWS, int BLK = 0>
 __global__ void __launch_bounds__(64, HNSW_SEARCH_MIN_WAVES(NCH, NSLOT, METRIC, ROWS, SEMF))
 hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     extern __shared__ uint32_t lds[];
@@ -1317,7 +1431,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     if ((int64_t)blockIdx.x >= a.nq) return;
     const int64_t q = a.qmap ? a.qmap[blockIdx.x] : (int64_t)blockIdx.x;
     if (a.q_limit && (q < 0 || q >= a.q_limit)) return;     // never follow a bad map entry into memory
-    WaveCtx cx = make_ctx(lds, a.vt_bits, lane);
+    WaveCtx cx = make_ctx(lds, a.vt_bits, lane, BLK ? a.blk_bits : 0);
     if (a.ovf_g) { cx.ovf.g = a.ovf_g + (int64_t)blockIdx.x * a.ovf_gcap; cx.ovf.gcap = a.ovf_gcap; }
 #if HNSW_VT_THREE_WAYS
     // ef > 128: the walk visits several times what the cache holds; float32 rows from ef 65 on (a re-evaluation costs four times a
@@ -1360,12 +1474,13 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
     WList<NSLOT> w;
     wlist_init(w, a.ef, lane);
     wlist_insert<NSLOT, SEMF>(w, cur_key, (uint32_t)cur, lane, cx.ovf, status);         // :871, seeds W :555-557
-    { uint32_t hw; (void)visited_mem(cx, (uint32_t)cur, hw); visited_add_masked(cx, (uint32_t)cur, hw, lane == 0); }
+    if constexpr (BLK != 0) (void)visited_blocks_mem_add(cx, lane == 0, (uint32_t)iv.lcode[cur], 0u);
+    else { uint32_t hw; (void)visited_mem(cx, (uint32_t)cur, hw); visited_add_masked(cx, (uint32_t)cur, hw, lane == 0); }
     __syncthreads();
 #ifdef HNSW_ASM_DEBUG
-    search_layer<NCH, RB, NSLOT, METRIC, SEMF, ROWS>(iv, qv, 0, w, a.ef | (a.lds_pad << 16), cx, n_dist, n_hops, status);
+    search_layer<NCH, RB, NSLOT, METRIC, SEMF, ROWS, BLK>(iv, qv, 0, w, a.ef | (a.lds_pad << 16), cx, n_dist, n_hops, status);
 #else
-    search_layer<NCH, RB, NSLOT, METRIC, SEMF, ROWS>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
+    search_layer<NCH, RB, NSLOT, METRIC, SEMF, ROWS, BLK>(iv, qv, 0, w, a.ef, cx, n_dist, n_hops, status); // :872-874
 #endif
 
     // results: W[0..k) ascending (lib/ohnsw.ml:886-893); sem 2: nearest_k's k farthest of W, lib/hnsw.ml:522-525

@@ -395,6 +395,129 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_lshl2_add_u32 %[lastad], %[cnt], %[candm4]\n\t"                             \
         "s_mov_b32 %[sx], %[cand]\n"                                                   
 
+// ---- Visited as bitmap blocks over the locality codes (visited_blocks_mem_add, hnsw_device.hip.h), for the loops with W in four
+// or eight registers instantiated with HNSW_LOOP_BLK 1.  The hop reads lcode0's row beside the adjacency row (nc / pnc beside nb /
+// pnb: same lane, same offset, base lcm), and the filter is the five steps of the C++ routine, same order, same arithmetic (a
+// build without the loops must count the same evaluations): the set's eight directory words (block << 8 | stamp), the way that
+// carries the lane's block or else the least recently touched one (largest (age << 3) | way, age = (now - stamp) mod 256), 1 the
+// bit of the lanes that hit, 2 every valid lane's (block << 8) | now into its way, 3 read back: the lane owns the slot iff the word
+// carries its block, 4 owners that missed clear the slot's bitmap, 5 owners whose bit was clear set it.  Scratch: the first
+// fifteen row registers (no rows are in flight between the rounds of two hops); um0..um3 are free between the peek and the
+// insertion.  vcc holds the valid lanes from label 6 on (every compare in between writes a scalar pair).
+#define HNSW_BLK_R(I) "v[" HNSW_STR(HNSW_F32_BASE) "+" #I "]"
+#define HNSW_BLK_R4(I) "v[" HNSW_STR(HNSW_F32_BASE) "+" #I ":" HNSW_STR(HNSW_F32_BASE) "+" #I "+3]"
+#define HNSW_HOP_ADJACENCY_BLK \
+        "4:\n\t"                            \
+        "s_add_u32 %[nh], %[nh], 1\n\t"     \
+        HNSW_SPLIT_HOP                      \
+        "s_cmp_lg_u32 %[kd], %[pref]\n\t"   \
+        "s_cbranch_scc1 44f\n\t"            \
+        HNSW_ASM_COUNT_HIT                  \
+        "s_waitcnt vmcnt(0)\n\t"            \
+        "v_mov_b32_e32 %[nb], %[pnb]\n\t"   \
+        "v_mov_b32_e32 %[nc], %[pnc]\n"
+#define HNSW_HOP_ADJACENCY_MISS_BLK \
+        "44:\n\t"                                                                                                             \
+        "s_mul_i32 %[tmp], %[kd], %[rowb]\n\t"                                                                                \
+        "v_lshl_add_u32 %[t0], %[lane], 2, %[tmp]\n\t"                                                                        \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                              \
+        "v_mov_b32_e32 %[nb], -1\n\t"                                                                                         \
+        "v_mov_b32_e32 %[nc], 0\n\t"                                                                                          \
+        "s_mov_b64 exec, %[rowm]\n\t"                                                                                         \
+        "global_load_dword %[nb], %[t0], %[nbrm]\n\t"                                                                          \
+        "global_load_dword %[nc], %[t0], %[lcm]\n\t"                                                                           \
+        "s_mov_b64 exec, -1\n\t"                                                                                              \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                              \
+        "s_branch 6b\n"
+#define HNSW_HOP_PREFETCH_LOAD_BLK \
+        "8:\n\t"                                                  \
+        "s_mul_i32 %[tmp], %[pref], %[rowb]\n\t"                  \
+        "v_lshl_add_u32 %[t1], %[lane], 2, %[tmp]\n\t"            \
+        "v_mov_b32_e32 %[pnb], -1\n\t"                            \
+        "v_mov_b32_e32 %[pnc], 0\n\t"                             \
+        "s_mov_b64 exec, %[rowm]\n\t"                             \
+        "global_load_dword %[pnb], %[t1], %[nbrm]\n\t"             \
+        "global_load_dword %[pnc], %[t1], %[lcm]\n\t"              \
+        "s_mov_b64 exec, -1\n"                                    \
+        "9:\n\t"
+// label 6: the lane's block, its set's directory words requested, the valid lanes
+#define HNSW_HOP_FILTER_ISSUE_BLK \
+        "6:\n\t"                                                               \
+        "v_lshrrev_b32_e32 %[tag], 8, %[nc]\n\t"          /* block number */   \
+        "v_and_b32_e32 %[va], %[bsm], %[tag]\n\t"         /* set */            \
+        "v_lshl_add_u32 %[va], %[va], 5, %[vtb]\n\t"      /* its eight words */ \
+        "ds_read_b128 " HNSW_BLK_R4(0) ", %[va]\n\t"                           \
+        "ds_read_b128 " HNSW_BLK_R4(4) ", %[va] offset:16\n\t"                 \
+        "v_cmp_lt_i32_e32 vcc, -1, %[nb]\n\t"
+// one way: hit -> t0 = way; (age << 3) | way -> running maximum t1   (the compare's mask is read three instructions later)
+#define HNSW_BLK_WAY(I) \
+        "v_lshrrev_b32_e32 " HNSW_BLK_R(8) ", 8, " HNSW_BLK_R(I) "\n\t"                        \
+        "v_cmp_eq_u32_e64 %[um0], " HNSW_BLK_R(8) ", %[tag]\n\t"                               \
+        "v_sub_u32_e32 " HNSW_BLK_R(8) ", %[tmp], " HNSW_BLK_R(I) "\n\t"                        \
+        "v_and_b32_e32 " HNSW_BLK_R(8) ", 0xff, " HNSW_BLK_R(8) "\n\t"                          \
+        "v_cndmask_b32_e64 %[t0], %[t0], " #I ", %[um0]\n\t"                                   \
+        "v_lshl_or_b32 " HNSW_BLK_R(8) ", " HNSW_BLK_R(8) ", 3, " #I "\n\t"                     \
+        "v_max_u32_e32 %[t1], %[t1], " HNSW_BLK_R(8) "\n\t"
+#define HNSW_HOP_FILTER_COMPACT_BLK \
+        "s_bfe_u32 %[tmp], %[nh], 0x80001\n\t"            /* now = (hops >> 1) & 255 */                         \
+        "v_mov_b32_e32 %[t0], -1\n\t"                                                                           \
+        "v_mov_b32_e32 %[t1], 0\n\t"                                                                            \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+        HNSW_BLK_WAY(0) HNSW_BLK_WAY(1) HNSW_BLK_WAY(2) HNSW_BLK_WAY(3)                                         \
+        HNSW_BLK_WAY(4) HNSW_BLK_WAY(5) HNSW_BLK_WAY(6) HNSW_BLK_WAY(7)                                         \
+        "v_cmp_lt_i32_e64 %[um1], -1, %[t0]\n\t"                                 /* the lanes that hit */       \
+        "v_and_b32_e32 %[t1], 7, %[t1]\n\t"                                      /* the victim's way */          \
+        "v_subrev_u32_e32 " HNSW_BLK_R(8) ", %[vtb], %[va]\n\t"                  /* set * 32 */                  \
+        "v_cndmask_b32_e64 %[t0], %[t1], %[t0], %[um1]\n\t"                      /* the lane's way */            \
+        "v_lshlrev_b32_e32 " HNSW_BLK_R(8) ", 3, " HNSW_BLK_R(8) "\n\t"          /* set * 8 slots * 32 bytes */  \
+        "v_lshl_add_u32 %[vw], %[t0], 2, %[va]\n\t"                              /* its directory word */        \
+        "v_lshl_add_u32 " HNSW_BLK_R(8) ", %[t0], 5, " HNSW_BLK_R(8) "\n\t"                                      \
+        "v_add_u32_e32 " HNSW_BLK_R(13) ", %[bmb], " HNSW_BLK_R(8) "\n\t"        /* the slot's bitmap */         \
+        "v_bfe_u32 " HNSW_BLK_R(8) ", %[nc], 5, 3\n\t"                                                          \
+        "v_lshl_add_u32 " HNSW_BLK_R(12) ", " HNSW_BLK_R(8) ", 2, " HNSW_BLK_R(13) "\n\t"   /* the code's word */ \
+        "v_and_b32_e32 " HNSW_BLK_R(8) ", 31, %[nc]\n\t"                                                        \
+        "v_lshlrev_b32_e64 " HNSW_BLK_R(11) ", " HNSW_BLK_R(8) ", 1\n\t"         /* ... and bit */               \
+        "v_lshl_or_b32 " HNSW_BLK_R(9) ", %[tag], 8, %[tmp]\n\t"                 /* (block << 8) | now */        \
+        "v_mov_b32_e32 " HNSW_BLK_R(10) ", 0\n\t"                                                               \
+        "s_mov_b64 exec, %[um1]\n\t"                                                                            \
+        "ds_read_b32 " HNSW_BLK_R(10) ", " HNSW_BLK_R(12) "\n\t"                 /* 1 */                         \
+        "s_mov_b64 exec, vcc\n\t"                                                                               \
+        "ds_write_b32 %[vw], " HNSW_BLK_R(9) "\n\t"                              /* 2 */                         \
+        "ds_read_b32 " HNSW_BLK_R(14) ", %[vw]\n\t"                              /* 3 */                         \
+        "s_mov_b64 exec, -1\n\t"                                                                                \
+        "v_mov_b32_e32 " HNSW_BLK_R(0) ", 0\n\t"                                                                \
+        "v_mov_b32_e32 " HNSW_BLK_R(1) ", 0\n\t"                                                                \
+        "v_mov_b32_e32 " HNSW_BLK_R(2) ", 0\n\t"                                                                \
+        "v_mov_b32_e32 " HNSW_BLK_R(3) ", 0\n\t"                                                                \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
+        "v_and_b32_e32 " HNSW_BLK_R(10) ", " HNSW_BLK_R(10) ", " HNSW_BLK_R(11) "\n\t"                          \
+        "v_lshrrev_b32_e32 " HNSW_BLK_R(14) ", 8, " HNSW_BLK_R(14) "\n\t"                                       \
+        "v_cmp_ne_u32_e64 %[um2], 0, " HNSW_BLK_R(10) "\n\t"                     /* Visited.mem */               \
+        "v_cmp_eq_u32_e64 %[um3], " HNSW_BLK_R(14) ", %[tag]\n\t"                /* the slot carries my block */ \
+        "s_and_b64 %[um3], %[um3], vcc\n\t"                                      /* ... and I hold a neighbour: owner */ \
+        "s_andn2_b64 %[um0], %[um3], %[um1]\n\t"                                 /* owners that missed */        \
+        "s_mov_b64 exec, %[um0]\n\t"                                                                            \
+        "ds_write_b128 " HNSW_BLK_R(13) ", " HNSW_BLK_R4(0) "\n\t"               /* 4 */                         \
+        "ds_write_b128 " HNSW_BLK_R(13) ", " HNSW_BLK_R4(0) " offset:16\n\t"                                    \
+        "s_andn2_b64 %[um0], %[um3], %[um2]\n\t"                                 /* owners whose bit was clear */ \
+        "s_mov_b64 exec, %[um0]\n\t"                                                                            \
+        "ds_or_b32 " HNSW_BLK_R(12) ", " HNSW_BLK_R(11) "\n\t"                   /* 5: Visited.add */            \
+        "s_mov_b64 exec, -1\n\t"                                                                                \
+        "s_andn2_b64 %[fresh], vcc, %[um2]\n\t"                                                                 \
+        "s_cbranch_scc0 1b\n\t"  /* nothing fresh: next hop */                                                  \
+  /* the list of fresh neighbours, in row order */                                                              \
+        "s_bcnt1_i32_b64 %[cnt], %[fresh]\n\t"                                                                  \
+        "s_mov_b64 exec, %[fresh]\n\t"                                                                          \
+        "v_mbcnt_lo_u32_b32 %[t0], exec_lo, 0\n\t"                                                              \
+        "v_mbcnt_hi_u32_b32 %[t0], exec_hi, %[t0]\n\t"                                                          \
+        "v_lshl_add_u32 %[t0], %[t0], 2, %[cand]\n\t"                                                           \
+        "ds_write_b32 %[t0], %[nb]\n\t"                                                                         \
+        HNSW_SPLIT_COMPACT                                                                                      \
+        "s_mov_b64 exec, -1\n\t"                                                                                \
+        "s_add_u32 %[nd], %[nd], %[cnt]\n\t"                                                                    \
+        "s_lshl2_add_u32 %[lastad], %[cnt], %[candm4]\n\t"                                                      \
+        "s_mov_b32 %[sx], %[cand]\n"
+
 // a list longer than one round (rare): the next candidate's address from what is left, then the next round
 #define HNSW_HOP_NEXT_ROUND \
         "s_lshl_b32 %[tmp], %[cnt], 2\n\t"         \
@@ -1727,6 +1850,163 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
+// ---- the same loops with Visited as bitmap blocks (HNSW_LOOP_BLK; hnsw_search_kernel<..., BLK = 1>): W in four / eight registers
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
 // float32 rows of 129..256 dimensions (NCH = 4), full and ragged
 #define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_asm1
 #define HNSW_LOOP_NSLOT 1
@@ -2138,6 +2418,34 @@ __device__ __forceinline__ bool search_layer0_f32_sem1_asm(const IndexView &iv, 
     HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_sem1_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_sem1_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_sem1_asm4) HNSW_F32_CALL(8, 1, 0, search_layer0_f32_ip_ragged_sem1_asm8)
     HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_sem1_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_sem1_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_sem1_asm4) HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_sem1_asm8)
     HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_sem1_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_sem1_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_sem1_asm4) HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_sem1_asm8)
+#undef HNSW_F32_CALL
+    return false;
+}
+
+
+// ... with Visited as bitmap blocks (search_layer<..., BLK = 1>)
+template <int NSLOT, int METRIC, int ROWS>
+__device__ __forceinline__ void search_layer0_f32_blk_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[2],
+                                                          uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
+    HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_blk_asm4)   HNSW_F32_CALL(8, 0, 1, search_layer0_f32_l2_full_blk_asm8)
+    HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_blk_asm4) HNSW_F32_CALL(8, 0, 0, search_layer0_f32_l2_ragged_blk_asm8)
+    HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_blk_asm4)  HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_blk_asm8)
+    HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_blk_asm4)   HNSW_F32_CALL(8, 1, 1, search_layer0_f32_ip_full_blk_asm8)
+    HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_blk_asm4) HNSW_F32_CALL(8, 1, 0, search_layer0_f32_ip_ragged_blk_asm8)
+    HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_blk_asm4)  HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_blk_asm8)
+#undef HNSW_F32_CALL
+}
+template <int NSLOT, int METRIC, int ROWS>
+__device__ __forceinline__ bool search_layer0_f32_blk_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
+                                                               const float4 (&qv)[2], uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
+    HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_sem1_blk_asm4)   HNSW_F32_CALL(8, 0, 1, search_layer0_f32_l2_full_sem1_blk_asm8)
+    HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_sem1_blk_asm4) HNSW_F32_CALL(8, 0, 0, search_layer0_f32_l2_ragged_sem1_blk_asm8)
+    HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_sem1_blk_asm4)  HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_sem1_blk_asm8)
+    HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_sem1_blk_asm4)   HNSW_F32_CALL(8, 1, 1, search_layer0_f32_ip_full_sem1_blk_asm8)
+    HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_sem1_blk_asm4) HNSW_F32_CALL(8, 1, 0, search_layer0_f32_ip_ragged_sem1_blk_asm8)
+    HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_sem1_blk_asm4)  HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_sem1_blk_asm8)
 #undef HNSW_F32_CALL
     return false;
 }

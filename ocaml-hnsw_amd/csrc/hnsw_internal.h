@@ -81,6 +81,12 @@ struct hnsw_index {
     hnsw_index_info info{};
     void *dX8 = nullptr;                 // byte rows (hnsw_rows8.hip), nullptr when the data does not qualify
     void *dXm = nullptr, *dTail0 = nullptr; // split rows (hnsw_rows_split.hip), nullptr when the row shape does not qualify
+    // locality codes (hnsw_locality.hip): per node and per layer-0 adjacency slot; built when the visited set first runs as
+    // bitmap blocks.  lcode_state: 0 not built yet, 1 built, -1 cannot be built (no upper layer to derive an order from)
+    void *dLcode = nullptr, *dLcode0 = nullptr;
+    int lcode_state = 0;
+    int blk_mode = -1;                   // option "visited_blocks": -1 automatic (measured per kernel shape on the index's own vectors), 0 never, 1 always
+    int blk_choice[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};   // [log2 NSLOT][accept rule]: -1 undecided, 0 tag cache, else log2 of the block slots
     void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr, *dRef = nullptr;
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt, sFlag; // scratch for the host-buffer entry points (sFlag: the launch's "any query flagged" word)
@@ -118,6 +124,17 @@ int make_byte_rows(::hnsw_index *idx);
 // hnsw_rows_split.hip: if a row ends 1..32 bytes past a 128-byte line (and there are no byte rows), build the split copy
 // (idx->dXm / dTail0, iv.Xm / tail0 / stride_m / main_chunks / tail_chunks); call after make_byte_rows, graph in place
 int make_split_rows(::hnsw_index *idx);
+
+// hnsw_order.hip: the descent alone for nq device-resident queries: d_entry[q] = the node the greedy descent reaches on layer
+// to_layer (lib/ohnsw.ml:865-867 stopped there); d_scratch: 4 * nq words
+int descent_entries(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, int32_t to_layer, int32_t *d_entry,
+                    uint32_t *d_scratch, hipStream_t st);
+// hnsw_layer_ops.hip: Ohnsw.search_k on one layer for device-resident targets (one start node each, W bounded by ef): the
+// nearest node found per target
+int layer_nearest_device(::hnsw_index *idx, int32_t layer, const float *d_targets, int64_t t_stride, int64_t nq, const int32_t *d_qmap,
+                         int64_t n_launch, const int32_t *d_starts, int32_t ef, int32_t *d_out_ids, float *d_out_dist);
+// hnsw_locality.hip: builds idx->dLcode / dLcode0 (and iv.lcode / lcode0) once; lcode_state says how it went
+int build_locality_codes(::hnsw_index *idx);
 
 // Longest-first ordering of a large batch (hnsw_order.hip): runs the descent kernel and a radix sort
 // on `st`; on success *block points to the handle's scratch for that stream (nothing to release)

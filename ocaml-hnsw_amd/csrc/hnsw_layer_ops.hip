@@ -198,6 +198,24 @@ int rebase_starts(const hnsw_index *idx, const int64_t *src, size_t count, bool 
 
 } // namespace
 
+namespace hnsw_host {
+// Ohnsw.search_k on `layer` for device-resident targets, one start node each, W bounded by ef, the NEAREST node found per target:
+// d_out_ids[q] (id_base-based) / d_out_dist[q].  With d_qmap: n_launch waves, wave b searches target d_qmap[b] (the others'
+// outputs are left alone).  Asynchronous on the null stream.  A target whose tie list overflows keeps its (still valid, possibly
+// not nearest) result: the callers want a good neighbour, not the reference's answer.
+int layer_nearest_device(::hnsw_index *idx, int32_t layer, const float *d_targets, int64_t t_stride, int64_t nq, const int32_t *d_qmap,
+                         int64_t n_launch, const int32_t *d_starts, int32_t ef, int32_t *d_out_ids, float *d_out_dist) {
+    if (n_launch <= 0) return HNSW_OK;
+    LayerSearchArgs a{};
+    a.Q = d_targets; a.q_stride = t_stride; a.nq = d_qmap ? n_launch : nq;
+    a.starts = d_starts; a.n_start = 1; a.layer = layer;
+    a.ef = ef; a.k = 1; a.fill = HNSW_FILL_OHNSW; a.sem = 0;
+    a.vt_bits = search_vt_bits(idx, ef);
+    a.out_ids = d_out_ids; a.out_dist = d_out_dist; a.qmap = d_qmap;
+    return launch_layer_args(idx, a);
+}
+} // namespace hnsw_host
+
 extern "C" {
 
 int32_t hnsw_search_layer_batch(hnsw_index *idx, int32_t layer, const float *targets, int64_t nq,

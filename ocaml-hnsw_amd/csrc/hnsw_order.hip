@@ -106,6 +106,19 @@ hipError_t launch_descent(int nch, const IndexView &iv, const float *Q, int64_t 
 
 namespace hnsw_host {
 
+int descent_entries(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, int32_t to_layer, int32_t *d_entry,
+                    uint32_t *d_scratch, hipStream_t st) {
+    if (nq <= 0) return HNSW_OK;
+    const int nch = pick_nch(idx->iv.nchunks);
+    uint32_t *key = d_scratch, *nd = d_scratch + nq, *sortkey = d_scratch + 2 * nq;
+    int32_t *index = (int32_t *)(d_scratch + 3 * nq);
+    const hipError_t e = idx->info.metric == HNSW_METRIC_L2
+        ? launch_descent<0>(nch, idx->iv, d_queries, q_stride, nq, to_layer, d_entry, key, nd, sortkey, index, nullptr, st)
+        : launch_descent<1>(nch, idx->iv, d_queries, q_stride, nq, to_layer, d_entry, key, nd, sortkey, index, nullptr, st);
+    if (e != hipSuccess) return fail(HNSW_ERR_HIP, "descent launch failed: %s", hipGetErrorString(e));
+    return HNSW_OK;
+}
+
 int order_longest_first(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, float *d_stage, hipStream_t st,
                         void **block, const int32_t **qmap, const int32_t **pre_entry, const uint32_t **pre_key,
                         const uint32_t **pre_nd, int32_t *pre_layer) {

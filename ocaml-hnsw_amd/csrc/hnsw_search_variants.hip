@@ -26,15 +26,32 @@ constexpr int RB1 = 8, RB2 = F_ == 2 ? HNSW_RB_BYTES_NCH2 : HNSW_RB_NCH2, RB4 = 
 
 template <int NCH, int RB, int NSLOT>
 hipError_t launch_one(const IndexView &iv, const SearchArgs &a, hipStream_t st) {
-    const size_t lds = hnsw_dev::wave_lds_words(a.vt_bits) * sizeof(uint32_t) + (size_t)a.lds_pad;
+    const size_t lds = hnsw_dev::search_lds_words(a.vt_bits, a.blk_bits) * sizeof(uint32_t) + (size_t)a.lds_pad;
+    // Visited as bitmap blocks (a.blk_bits > 0; W in four or more registers only) is a kernel of its own: the tag-cache kernels
+    // keep their registers
+    if constexpr (NSLOT >= 4) {
+        if (a.blk_bits > 0 && iv.lcode0 && iv.lcode) {
+            hipLaunchKernelGGL((hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_, 1>), dim3((unsigned)a.nq), dim3(64), lds, st, iv, a);
+            return hipGetLastError();
+        }
+    }
+    SearchArgs b = a;
+    b.blk_bits = 0;
     hipLaunchKernelGGL((hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_>), dim3((unsigned)a.nq),
-                       dim3(64), lds, st, iv, a);
+                       dim3(64), lds, st, iv, b);
     return hipGetLastError();
 }
 template <int NCH, int RB, int NSLOT>
-int occupancy_one(size_t lds) {
+int occupancy_one(size_t lds, int blk) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_>, 64, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    hipError_t e;
+    if constexpr (NSLOT >= 4) {
+        e = blk ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_, 1>, 64, lds)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_>, 64, lds);
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_>, 64, lds);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); nb = 0; }
     return nb;
 }
 
@@ -49,13 +66,13 @@ hipError_t launch_slot(int nslot, const IndexView &iv, const SearchArgs &a, hipS
     }
 }
 template <int NCH, int RB>
-int occupancy_slot(int nslot, size_t lds) {
+int occupancy_slot(int nslot, size_t lds, int blk) {
     switch (nslot) {
-    case 1: return occupancy_one<NCH, RB, 1>(lds);
-    case 2: return occupancy_one<NCH, RB, 2>(lds);
-    case 4: return occupancy_one<NCH, RB, 4>(lds);
-    case 8: return occupancy_one<NCH, RB, 8>(lds);
-    default: return occupancy_one<NCH, RB, 16>(lds);
+    case 1: return occupancy_one<NCH, RB, 1>(lds, blk);
+    case 2: return occupancy_one<NCH, RB, 2>(lds, blk);
+    case 4: return occupancy_one<NCH, RB, 4>(lds, blk);
+    case 8: return occupancy_one<NCH, RB, 8>(lds, blk);
+    default: return occupancy_one<NCH, RB, 16>(lds, blk);
     }
 }
 
@@ -75,13 +92,13 @@ hipError_t HNSW_V_CAT(search_launch_, HNSW_V_METRIC, HNSW_V_SEMF, HNSW_V_FULL)(i
     default: return launch_slot<16, RB16>(nslot, iv, a, st);
     }
 }
-int HNSW_V_CAT(search_occupancy_, HNSW_V_METRIC, HNSW_V_SEMF, HNSW_V_FULL)(int nch, int nslot, size_t lds) {
+int HNSW_V_CAT(search_occupancy_, HNSW_V_METRIC, HNSW_V_SEMF, HNSW_V_FULL)(int nch, int nslot, size_t lds, int blk) {
     switch (nch) {
-    case 1: return occupancy_slot<1, RB1>(nslot, lds);
-    case 2: return occupancy_slot<2, RB2>(nslot, lds);
-    case 4: return occupancy_slot<4, RB4>(nslot, lds);
-    case 8: return occupancy_slot<8, RB8>(nslot, lds);
-    default: return occupancy_slot<16, RB16>(nslot, lds);
+    case 1: return occupancy_slot<1, RB1>(nslot, lds, blk);
+    case 2: return occupancy_slot<2, RB2>(nslot, lds, blk);
+    case 4: return occupancy_slot<4, RB4>(nslot, lds, blk);
+    case 8: return occupancy_slot<8, RB8>(nslot, lds, blk);
+    default: return occupancy_slot<16, RB16>(nslot, lds, blk);
     }
 }
 

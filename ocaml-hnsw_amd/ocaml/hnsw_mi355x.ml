@@ -152,7 +152,17 @@ let hnsw_index_layer_stats =
 let hnsw_index_layer_isolated =
   foreign ~from:lib "hnsw_index_layer_isolated"
     (index @-> int32_t @-> ptr int64_t @-> int64_t @-> ptr int64_t @-> returning int32_t)
+let hnsw_index_locality_codes =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_index_locality_codes" (index @-> ptr int32_t @-> returning int32_t)
 let hnsw_abi_version = foreign ~from:lib "hnsw_abi_version" (void @-> returning int32_t)
+(* HNSW_ABI_VERSION of include/hnsw_mi355x.h this binding was written against: an older or newer library is refused at load
+   time (version 2: hnsw_search_batch_h2d, hnsw_host_alloc / hnsw_host_free, hnsw_index_layer_isolated, hnsw_multi_debug_counters,
+   hnsw_index_locality_codes; hnsw_index_info.row_format; the empty-layer values of hnsw_index_layer_stats) *)
+let expected_abi_version = 2l
+let () =
+  let v = hnsw_abi_version () in
+  if v <> expected_abi_version then
+    failwith (Printf.sprintf "libhnsw_mi355x.so speaks ABI version %ld, this binding %ld" v expected_abi_version)
 let hnsw_device_count = foreign ~from:lib "hnsw_device_count" (ptr int32_t @-> returning int32_t)
 type index_info
 let index_info : index_info structure typ = structure "hnsw_index_info"
@@ -394,7 +404,10 @@ let unflatten_ohnsw (distance : 'a Ohnsw.distance) (value : 'a Ohnsw.value) (f :
   h
 
 (* ---- device-resident index ------------------------------------------------------------------ *)
-type t = { handle : index; k_base : int; dim : int }
+(* [scratch]: page-locked result matrices per (k, nq) shape, see [scratch_for]: they belong to the HANDLE, so two threads that
+   search two different indices (one thread at a time per handle, INTEGRATION.md) never write into the same matrices *)
+type result_scratch = (int * int, (int32, Bigarray.int32_elt, Bigarray.fortran_layout) A2.t * Lacaml.S.mat) Hashtbl.t
+type t = { handle : index; k_base : int; dim : int; scratch : result_scratch }
 
 let create ?(device = 0) ?(metric = 0) ~id_base (vectors : Lacaml.S.mat) (f : flat) : t =
   (* a Lacaml.S.mat is a Fortran-layout dim x n Bigarray: in memory, n rows of dim floats *)
@@ -418,7 +431,7 @@ let create ?(device = 0) ?(metric = 0) ~id_base (vectors : Lacaml.S.mat) (f : fl
   setf d d_upper (CArray.start layers);
   let out = allocate index null in
   check (hnsw_index_create (addr d) (Int32.of_int device) out);
-  let t = { handle = !@out; k_base = id_base; dim } in
+  let t = { handle = !@out; k_base = id_base; dim; scratch = Hashtbl.create 4 } in
   Gc.finalise (fun t -> ignore (hnsw_index_destroy t.handle)) t;
   t
 
@@ -444,26 +457,27 @@ let alloc_ids ~k ~nq : (int32, Bigarray.int32_elt, Bigarray.fortran_layout) A2.t
   Gc.finalise (fun _ -> ignore (hnsw_host_free p)) m;
   m
 
-(* Page-locked result scratch, one pair per (k, nq) shape seen (a benchmark or serving loop repeats its shape): the search
-   kernel writes every query's results straight into it as the query finishes -- no download step -- and [search] hands
+(* Page-locked result scratch, one pair per handle and (k, nq) shape seen (a benchmark or serving loop repeats its shape): the
+   search kernel writes every query's results straight into it as the query finishes -- no download step -- and [search] hands
    fresh matrices to its caller, as the reference does (lib/ohnsw.ml:879-881), by two blits of 4 k nq bytes each.
-   (Allocating page-locked memory costs far more than a batch takes, so the scratch is kept, not the results.) *)
-let result_scratch : (int * int, (int32, Bigarray.int32_elt, Bigarray.fortran_layout) A2.t * Lacaml.S.mat) Hashtbl.t =
-  Hashtbl.create 4
-let scratch_for ~k ~nq =
-  match Hashtbl.find_opt result_scratch (k, nq) with
+   (Allocating page-locked memory costs far more than a batch takes, so the scratch is kept, not the results.)  The table is
+   a field of the handle (round 4 kept ONE table for the process: two threads searching two indices with the same batch shape
+   -- the call releases the runtime lock -- then had their kernels write into the same matrices); it dies with the handle,
+   its blocks through their own finalisers (hnsw_host_free). *)
+let scratch_for (t : t) ~k ~nq =
+  match Hashtbl.find_opt t.scratch (k, nq) with
   | Some s -> s
   | None ->
-    if Hashtbl.length result_scratch >= 8 then Hashtbl.reset result_scratch;   (* shapes keep changing: do not hoard *)
+    if Hashtbl.length t.scratch >= 8 then Hashtbl.reset t.scratch;   (* shapes keep changing: do not hoard *)
     let s = (alloc_ids ~k ~nq, alloc_mat ~dim:k ~n:nq) in
-    Hashtbl.replace result_scratch (k, nq) s;
+    Hashtbl.replace t.scratch (k, nq) s;
     s
 
 let search ?(semantics = 0) t (batch : Lacaml.S.mat) ~ef ~k ~fill =
   let nq = A2.dim2 batch in
   (* results as the reference lays them out: k x nq Fortran = [nq][k] in memory; written by the device into the
      page-locked scratch, then copied into fresh matrices for the caller *)
-  let ids_s, dist_s = scratch_for ~k ~nq in
+  let ids_s, dist_s = scratch_for t ~k ~nq in
   let p = make search_params in
   setf p p_ef (Int32.of_int ef); setf p p_k (Int32.of_int k); setf p p_fill (Int32.of_int fill);
   setf p p_semantics (Int32.of_int semantics);
@@ -718,7 +732,7 @@ let build ?(device = 0) ?(metric = 0) ?(seed = 0) ?(max_batch = 0) ?(batch_div =
   let out = allocate index null in
   check (hnsw_build (bigarray_start array2 vectors) (Int64.of_int n) (Int32.of_int dim) (Int64.of_int dim) (addr b)
            (Int32.of_int device) out);
-  let t = { handle = !@out; k_base = id_base; dim } in
+  let t = { handle = !@out; k_base = id_base; dim; scratch = Hashtbl.create 4 } in
   Gc.finalise (fun t -> ignore (hnsw_index_destroy t.handle)) t;
   t
 
@@ -727,7 +741,7 @@ let save (t : t) (path : string) = check (hnsw_index_save t.handle path)
 let load ?(device = 0) ~id_base ~dim (path : string) : t =
   let out = allocate index null in
   check (hnsw_index_load path (Int32.of_int device) out);
-  let t = { handle = !@out; k_base = id_base; dim } in
+  let t = { handle = !@out; k_base = id_base; dim; scratch = Hashtbl.create 4 } in
   Gc.finalise (fun t -> ignore (hnsw_index_destroy t.handle)) t;
   t
 
@@ -749,6 +763,12 @@ let isolated (t : t) ~layer : int list =
     check (hnsw_index_layer_isolated t.handle (Int32.of_int layer) (CArray.start ids) (Int64.of_int c) cnt);
     List.map Int64.to_int (CArray.to_list ids)
   end
+
+(* the permutation of 0 .. n-1 behind the option "visited_blocks" (hnsw_index_locality_codes): introspection only *)
+let locality_codes (t : t) ~n : (int32, Bigarray.int32_elt, Bigarray.c_layout) A1.t =
+  let out = A1.create Bigarray.int32 Bigarray.c_layout n in
+  check (hnsw_index_locality_codes t.handle (bigarray_start array1 out));
+  out
 
 (* Hgraph.Stats.compute (lib/hnsw.ml:370-375) as the reference's record: per layer (size, {min; max; mean; isolated}) *)
 let stats_compute (t : t) ~max_layer : (int * (int * int * float * int list)) list =

@@ -98,15 +98,19 @@ def test_built_code_objects_have_no_unpadded_hazard(objects):
 def _asm_kernels(objs):
     """the kernels that contain hand-scheduled code: the layer-0 loops (W in 1 / 2 / 4 key registers) over byte rows and over
     float32 rows (L2 and inner product, full and ragged rows), and the descent kernel with the hand-scheduled descent"""
-    want = [("hnsw_search_variants_0_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi0ELi2E" % s) for s in (1, 2, 4)]
+    want = [("hnsw_search_variants_0_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi0ELi2ELi0EE" % s) for s in (1, 2, 4)]
     for obj, metric, rows in (("hnsw_search_variants_0_0_1.o", 0, 1), ("hnsw_search_variants_0_0_0.o", 0, 0),
                               ("hnsw_search_variants_1_0_1.o", 1, 1), ("hnsw_search_variants_1_0_0.o", 1, 0)):
-        want += [(obj, "hnsw_search_kernelILi2ELi4ELi%dELi%dELi0ELi%dE" % (s, metric, rows)) for s in (1, 2, 4)]
-    want += [("hnsw_search_variants_0_1_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi1ELi2E" % s) for s in (1, 2, 4)]     # the functor rule's instantiations
-    want += [("hnsw_search_variants_1_1_0.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi1ELi0E" % s) for s in (2,)]
-    want += [("hnsw_search_variants_1_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi2E" % s) for s in (2, 4)]              # byte rows, inner product
-    want += [("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi3E" % s) for s in (4,)]               # split rows (C3's kernel)
-    want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi8ELi0ELi0ELi0E")]                                    # eight slots (C5's kernel)
+        want += [(obj, "hnsw_search_kernelILi2ELi4ELi%dELi%dELi0ELi%dELi0EE" % (s, metric, rows)) for s in (1, 2, 4)]
+    want += [("hnsw_search_variants_0_1_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi1ELi2ELi0EE" % s) for s in (1, 2, 4)]     # the functor rule's instantiations
+    want += [("hnsw_search_variants_1_1_0.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi1ELi0ELi0EE" % s) for s in (2,)]
+    want += [("hnsw_search_variants_1_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi2ELi0EE" % s) for s in (2, 4)]              # byte rows, inner product
+    want += [("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi3ELi0EE" % s) for s in (4,)]               # split rows (C3's kernel)
+    want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi8ELi0ELi0ELi0ELi0EE")]                                    # eight slots (C5's kernel)
+    # Visited as bitmap blocks (BLK = 1): the block filter inside the eight-slot ragged-row loop (C5's kernel when its data is
+    # clustered) and inside the four-slot split-row inner-product loop (C3's)
+    want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi8ELi0ELi0ELi0ELi1EE"),
+             ("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi4ELi1ELi0ELi3ELi1EE")]
     want += [("hnsw_order.hip.o", "hnsw_descent_kernelILi2ELi8ELi0ELi2E")]
     out = []
     for obj, frag in want:

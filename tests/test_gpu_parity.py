@@ -655,8 +655,11 @@ def test_registered_host_arrays_and_caller_owned_results(H, oracle):
                 for a in (Q, ids, dist):
                     H.unpin(a)
         if how == "registered":
-            with pytest.raises(H.Failure):
+            with pytest.raises(H.InvalidArgument, match="no range registered"):
                 H.unpin(ids)                         # not registered any more
+        else:
+            with pytest.raises(H.InvalidArgument, match="hnsw_host_alloc"):
+                H.unpin(ids)                         # the library's own block: freed with the array, never unregistered
     ids, dist = np.full((Q0.shape[0], k), -7, np.int32), np.zeros((Q0.shape[0], k), np.float32)
     with pytest.raises(H.InvalidArgument):
         H.Ohnsw.knn_batch_bigarray(hg, k, Q0, ef=ef, out=(ids[:, :5], dist))
@@ -681,3 +684,52 @@ def test_registered_host_arrays_and_caller_owned_results(H, oracle):
     small = np.arange(64, dtype=np.float32)
     H.pin(small)
     H.unpin(small)
+    # an array somebody else has page-locked (here: torch) is accepted, never unregistered by the library, and searched through copies
+    import torch
+    theirs = torch.from_numpy(Q0.copy()).pin_memory()
+    Qt = theirs.numpy()
+    H.pin(Qt)
+    ti, td = H.Ohnsw.knn_batch_bigarray(hg, k, Qt, ef=ef)
+    np.testing.assert_array_equal(ti, want_i)
+    H.unpin(Qt)
+    assert theirs.is_pinned()
+    ti, td = H.Ohnsw.knn_batch_bigarray(hg, k, Qt, ef=ef)           # still theirs, still valid
+    np.testing.assert_array_equal(ti, want_i)
+
+
+def test_unregistering_a_matrix_the_device_still_reads_waits(H, oracle):
+    """VERDICT r04 item 2.  hnsw_search_batch_h2d returns while the device still reads the caller's registered query matrix in
+    place (the ordering pre-pass of a large batch; the search kernel itself for a small one).  Round 4's second suite abort was a
+    test that unregistered at that moment: hipHostUnregister pulled the pages from under the kernel -- a GPU page fault, the
+    process gone.  The defined behaviour now: hnsw_host_unregister / hnsw_host_free WAIT for the readers the library knows of
+    (an event behind the launch, per range and stream); results are the plain call's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    X = _dataset("sift", 20000, 128, 3)
+    hg = H.Ohnsw.build_batch_bigarray(X, 16, 80, seed=2)
+    stream = torch.cuda.Stream()
+    for nq in (9000, 300):
+        Q0 = _dataset("sift", nq, 128, 40 + nq)
+        want_i, want_d = H.Ohnsw.knn_batch_bigarray(hg, 10, Q0, ef=128)
+        ids = torch.full((nq, 10), -9, dtype=torch.int32, device=dev)
+        dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        for how in ("registered", "allocated"):
+            if how == "registered":
+                Q = _mmap_array((nq, 128), np.float32, Q0)
+                H.pin(Q)
+            else:
+                Q = H.host_empty((nq, 128), np.float32)
+                Q[:] = Q0
+            ids.fill_(-9)
+            torch.cuda.synchronize()
+            keep = H.search_batch_h2d(hg, Q, 128, 10, ids.data_ptr(), dd.data_ptr(), stream=stream.cuda_stream)
+            # no synchronisation: the launch is in flight (or still queued) when the range is taken away
+            if how == "registered":
+                H.unpin(Q)
+            else:
+                del keep, Q                              # the last references: _HostBlock.__del__ -> hnsw_host_free
+            stream.synchronize()
+            np.testing.assert_array_equal(ids.cpu().numpy(), want_i)
+            np.testing.assert_array_equal(dd.cpu().numpy().view(np.uint32), want_d.view(np.uint32))
+    hg.release()
