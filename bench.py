@@ -97,10 +97,11 @@ def recall_ids(got, gt):
     return float(np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(got.tolist(), gt.tolist())]))
 
 
-def search_kernel_name(d, ef, metric, semf, rows=-1):
-    """The hnsw_search_kernel<NCH, RB, NSLOT, METRIC, SEMF, ROWS> instance the library launches for this shape
+def search_kernel_name(d, ef, metric, semf, rows=-1, blk=0):
+    """The hnsw_search_kernel<NCH, RB, NSLOT, METRIC, SEMF, ROWS, BLK> instance the library launches for this shape
     (csrc/hnsw_internal.h: pick_nch / pick_nslot; csrc/hnsw_search_variants.hip: RB per NCH).  rows: 2 = byte rows,
-    3 = split rows, -1 = plain float32 rows (1 when every chunk of the lane grid lies inside the row, else 0)."""
+    3 = split rows, -1 = plain float32 rows (1 when every chunk of the lane grid lies inside the row, else 0); blk: 1 = Visited as
+    bitmap blocks (Hgraph.visited_blocks(ef) != 0)."""
     nchunks = (d + 3) // 4
     per_lane = (nchunks + 15) // 16
     nch = next(c for c in (1, 2, 4, 8, 16) if per_lane <= c)
@@ -108,14 +109,30 @@ def search_kernel_name(d, ef, metric, semf, rows=-1):
     if rows < 0:
         rows = 1 if nchunks == 16 * nch else 0
     rb = {1: 8, 2: 4, 4: 4, 8: 2, 16: 1}[nch] if rows == 2 else {1: 8, 2: 4, 4: 2, 8: 1, 16: 1}[nch]
-    return "hnsw_search_kernel<%d,%d,%d,%d,%d,%d>" % (nch, rb, nslot, metric, semf, rows)
+    return "hnsw_search_kernel<%d,%d,%d,%d,%d,%d,%d>" % (nch, rb, nslot, metric, semf, rows, 1 if blk else 0)
+
+
+def search_nslot(ef):
+    """key registers per lane that hold W for this ef (pick_nslot of the library)"""
+    for s_ in (1, 2, 4, 8, 16):
+        if ef <= 64 * s_:
+            return s_
+    return 16
+
+
+def kernel_nslot_of(name):
+    """the NSLOT template argument (third) of a hnsw_search_kernel<...> name from a rocprofv3 trace, or -1"""
+    try:
+        return int(name.split("hnsw_search_kernel<", 1)[1].split(">", 1)[0].split(",")[2])
+    except Exception:
+        return -1
 
 
 def kernel_rows_of(name):
     """ROWS template argument of a (demangled) hnsw_search_kernel name, or None"""
     import re
     m = re.search(r"hnsw_search_kernel<([^>]*)>", name.replace(" ", ""))
-    return int(m.group(1).split(",")[-1]) if m else None
+    return int(m.group(1).split(",")[5]) if m else None
 
 
 def _stdout_to_stderr():
@@ -157,6 +174,8 @@ def main():
     ap.add_argument("--no-builder-check", action="store_true", help="skip the batched-vs-sequential builder comparison inside `secondary` (about 75 s)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic / roofline.issue are then null)")
     ap.add_argument("--pmc-child", default=None, help="(internal) load this index file and run a few steps: the process rocprofv3 wraps")
+    ap.add_argument("--pmc-hard", default=None, help="(internal) the harder set's index file for the same child")
+    ap.add_argument("--pmc-hard-ef", type=int, default=0, help="(internal) ... and the ef of its recall gate")
     ap.add_argument("--no-bench-dist", action="store_true", help="skip the bench_dist counterpart (object `bench_dist`; about 8 s)")
     ap.add_argument("--no-others", action="store_true", help="skip the C3 / C5 configurations (object `others`; about 100 s)")
     ap.add_argument("--no-clustered", action="store_true", help="skip the clustered variant of C3 inside `others` (its dispatches carry C3's kernel name)")
@@ -194,6 +213,15 @@ def main():
             for _ in range(5):
                 H.search_batch_device(hgc, Qc.data_ptr(), args.nq, args.d, args.ef, args.k, ic.data_ptr(), dc.data_ptr(), 0, 0, 0, stc.cuda_stream)
             torch.cuda.synchronize()
+        if args.pmc_hard:       # the harder set at the ef of its recall gate (another kernel: W in more registers)
+            hgc.release()
+            hgc = H.Hgraph.load(args.pmc_hard)
+            Qc = make_sift_like(args.nq, args.d, seed=2, device=dev_, n_centres=256, sigma=40.0)
+            for rows_ in (1, 0):
+                hgc.set_option("byte_rows", rows_)
+                for _ in range(5):
+                    H.search_batch_device(hgc, Qc.data_ptr(), args.nq, args.d, args.pmc_hard_ef, args.k, ic.data_ptr(), dc.data_ptr(), 0, 0, 0, stc.cuda_stream)
+                torch.cuda.synchronize()
         _restore_stdout(saved_stdout)
         return
     gpu = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
@@ -237,6 +265,11 @@ def main():
         # every rank searches its own shard of the global batch of world * nq queries
         Qall = make_sift_like(world * nq, d, seed=2, device=dev)
     Qd = Qall[rank * nq:(rank + 1) * nq].contiguous()
+    # The K timed steps (and the warm-up) ROTATE through NB distinct query batches (seeds 2 .. 9): the reference times one
+    # call on queries the caches have never seen (benchmark/benchmark.ml:86-98); K steps on ONE batch would find the rows of
+    # the walks in L2 / Infinity Cache from the second step on.  Batch 0 is the batch every check is made on.
+    NB = 1 if args.dataset else max(1, int(os.environ.get("BENCH_BATCHES", "8")))
+    Qd_b = [Qd] + [make_sift_like(world * nq, d, seed=2 + j, device=dev)[rank * nq:(rank + 1) * nq].contiguous() for j in range(1, NB)]
     if multi:   # every rank generated its own copy of the data: the copies must be identical
         import ocaml_hnsw_amd.sharding as sharding
         sharding.assert_same_on_all_ranks(dist, cdev, {"X": Xd, "Q": Qall})
@@ -279,8 +312,8 @@ def main():
     def kernel_name(bytes_):
         return search_kernel_name(d, ef, 0, 0, 2 if bytes_ else -1)
 
-    def search(ef_, counters=False, slot=0):
-        H.search_batch_device(hg, Qd.data_ptr(), nq, d, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(),
+    def search(ef_, counters=False, slot=0, j=0):
+        H.search_batch_device(hg, Qd_b[j % NB].data_ptr(), nq, d, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(),
                               nd_d.data_ptr() if counters else 0, nh_d.data_ptr() if counters else 0,
                               st_d.data_ptr(), stream.cuda_stream)
 
@@ -289,7 +322,7 @@ def main():
         src = res[slot] if args.backend == "nccl" else res[slot].cpu()
         return dist.all_gather_into_tensor(all_res[slot], src, async_op=True)
 
-    def run_steps(ef_, steps, ev=None):
+    def run_steps(ef_, steps, ev=None, j0=0):
         works = []
         for i in range(steps):
             slot = i & 1
@@ -297,7 +330,7 @@ def main():
                 works[i - 2].wait()          # the gather that read this slot two steps ago is done
             if ev:
                 ev[i][0].record(stream)
-            search(ef_, slot=slot)
+            search(ef_, slot=slot, j=j0 + i)
             if ev:
                 ev[i][1].record(stream)
             if multi:
@@ -321,7 +354,7 @@ def main():
         hg.set_option("time_kernels", 1 if instrument else 0)     # HIP events around the library's own launches, on the launch stream
         hg.kernel_times()
         t = time.perf_counter()
-        run_steps(ef_, steps, ev)
+        run_steps(ef_, steps, ev, j0=warmup)
         sync()
         wall = time.perf_counter() - t
         if instrument:
@@ -344,21 +377,26 @@ def main():
     #      up resident on every GPU), D2H of the rank's own shard, stream synchronisation. ----
     # the caller's matrices live in page-locked memory (hnsw_host_alloc; hnsw_host_register on an mmap-backed array is the
     # same to the library): the device reads the queries and writes the results directly, no copies
-    Qh = H.host_empty((nq, d), np.float32)
-    Qh[:] = Qd.cpu().numpy()
+    Qh_b = []
+    for j in range(NB):
+        q_ = H.host_empty((nq, d), np.float32)
+        q_[:] = Qd_b[j].cpu().numpy()
+        Qh_b.append(q_)
+    Qh = Qh_b[0]
     if not multi:
         host_i = H.host_empty((nq, k), np.int32)
         host_d = H.host_empty((nq, k), np.float32)
     else:
         host_res = torch.empty(2 * nres, dtype=torch.int32).pin_memory()
 
-    def host_step(ef_, slot=0):
+    def host_step(ef_, slot=0, j=0, q_=None):
+        q_ = Qh_b[j % NB] if q_ is None else q_
         if not multi:
-            H.Ohnsw.knn_batch_bigarray(hg, k, Qh, ef=ef_, out=(host_i, host_d))
+            H.Ohnsw.knn_batch_bigarray(hg, k, q_, ef=ef_, out=(host_i, host_d))
             return
         # hnsw_search_batch_h2d: the rank's registered query matrix is read by the device directly (as in hnsw_search_batch),
         # the shard's results stay in HBM for the exchange
-        H.search_batch_h2d(hg, Qh, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(), 0, 0, st_d.data_ptr(), stream.cuda_stream)
+        H.search_batch_h2d(hg, q_, ef_, k, ids_v[slot].data_ptr(), dist_v[slot].data_ptr(), 0, 0, st_d.data_ptr(), stream.cuda_stream)
         with torch.cuda.stream(stream):
             gather(slot).wait()                           # the current stream waits for the collective
             host_res.copy_(res[slot], non_blocking=True)
@@ -369,7 +407,7 @@ def main():
         launches with HIP events (option time_kernels: three event records per call, about 0.009 ms); the pass `value` is
         quoted on runs without them, an instrumented pass of the same steps gives the kernel durations of the roofline."""
         for i in range(warmup):
-            host_step(ef_, i & 1)
+            host_step(ef_, i & 1, i)
         sync()
         hg.set_option("time_kernels", 1 if instrument else 0)
         hg.kernel_times()
@@ -377,8 +415,9 @@ def main():
         t = time.perf_counter()
         for i in range(steps):
             t1 = time.perf_counter()
-            host_step(ef_, i & 1)
+            host_step(ef_, i & 1, warmup + i)
             ts.append(1e3 * (time.perf_counter() - t1))
+        last_host_batch[0] = (warmup + steps - 1) % NB
         sync()
         wall = time.perf_counter() - t
         lt = dict(zip(("search_ms", "prepass_ms", "calls"), hg.kernel_times()))
@@ -392,6 +431,38 @@ def main():
 
     lib_times = {}
     step_stats = {}
+    last_host_batch = [0]
+    # ---- the very first call after the index upload (nothing of this index in any cache -- and every one-time cost of a first
+    #      call in it: the handle's stream, its page-locked flag word, its scratch, the kernels' code objects), then calls with the
+    #      caches flushed in front (2 GiB written) on batches the device has never seen: what ONE call of the reference's benchmark
+    #      (benchmark/benchmark.ml:89-96) pays when it is not the twentieth of its kind ----
+    cold = None
+    if not args.dataset:
+        sync()
+        t1 = time.perf_counter()
+        host_step(ef, 0, 0)
+        sync()
+        first_ms = 1e3 * (time.perf_counter() - t1)
+        flush = torch.empty(1 << 31, dtype=torch.uint8, device=dev)
+        qc = H.host_empty((nq, d), np.float32)
+        cts = []
+        for j in range(3):
+            qc[:] = make_sift_like(world * nq, d, seed=40 + j, device=dev)[rank * nq:(rank + 1) * nq].cpu().numpy()
+            flush.fill_(j + 1)
+            sync()
+            t1 = time.perf_counter()
+            host_step(ef, 0, 0, q_=qc)
+            if multi:
+                sync()
+            cts.append(1e3 * (time.perf_counter() - t1))
+        del flush
+        cts.sort()
+        cold = {"first_call_ms": round(first_ms, 4), "cold_cache_call_ms": round(cts[1], 4), "cold_cache_call_ms_min": round(cts[0], 4),
+                "cold_cache_call_ms_max": round(cts[2], 4),
+                "what": "first_call_ms: the first search call after the index upload, one-time costs of the handle included (stream, scratch, "
+                        "code objects); cold_cache_call_ms: median of 3 later calls of the headline protocol, each on a batch never searched "
+                        "before and behind a 2 GiB write that empties L2 and the Infinity Cache"}
+        log("first call after the index upload %.3f ms; calls on unseen batches behind a cache flush %.3f ms (median of 3)" % (first_ms, cts[1]))
     # the K timed steps of `value`, with the library's kernel events in them (roofline.kernel_ms is measured over THIS region;
     # three event records per call cost 0.003-0.015 ms of a 0.44 ms step), and once more without, for the record
     wall, host_stats, host_lib = timed_host(ef, args.steps, args.warmup, instrument=True)
@@ -409,6 +480,39 @@ def main():
     qps_dev = world * nq * args.steps / wall_dev
     log("ef=%d, device-resident: %.0f q/s, %.3f ms/step; pre-pass %.3f ms + search kernel %.3f ms (device call %.3f ms)" %
         (ef, qps_dev, 1e3 * wall_dev / args.steps, dev_lib["prepass_ms"], dev_lib["search_ms"], kern_ms))
+    # ---- the bandwidth point: 100 000 queries per GPU per step, resident (SURVEY 8e "scaling caveat": 10 000 queries are
+    #      fewer than the 8192 wave slots plus their refill -- a launch that ends with its longest walk; ten times the batch
+    #      shows what the memory system sustains).  N > 1: with the all-gather of the per-shard results in the step. ----
+    big = None
+    if not args.dataset:
+        nqb = int(os.environ.get("BENCH_BIG_NQ", "100000"))
+        Qbig = make_sift_like(world * nqb, d, seed=30, device=dev)[rank * nqb:(rank + 1) * nqb].contiguous()
+        big_res = torch.empty(2 * nqb * k, dtype=torch.int32, device=dev)
+        big_all = torch.empty(world * 2 * nqb * k, dtype=torch.int32, device=cdev) if multi else None
+
+        def big_step():
+            H.search_batch_device(hg, Qbig.data_ptr(), nqb, d, ef, k, big_res[:nqb * k].data_ptr(), big_res[nqb * k:].data_ptr(), 0, 0, 0, stream.cuda_stream)
+            if multi:
+                dist.all_gather_into_tensor(big_all, big_res if args.backend == "nccl" else big_res.cpu())
+        big_step()
+        sync()
+        bsteps = max(3, args.steps // 4)
+        t = time.perf_counter()
+        for _ in range(bsteps):
+            big_step()
+        sync()
+        bw_ = time.perf_counter() - t
+        if multi:
+            w_ = torch.tensor([bw_], dtype=torch.float64, device=cdev)
+            dist.all_reduce(w_, op=dist.ReduceOp.MAX)
+            bw_ = float(w_[0])
+        big = {"value": round(world * nqb * bsteps / bw_, 1), "unit": "queries/s", "queries_per_gpu": nqb, "n_gpus": world, "steps": bsteps,
+               "ms_per_step": round(1e3 * bw_ / bsteps, 4), "scaling": "weak",
+               "what": "hnsw_search_batch_device on %d resident queries per GPU per step%s: the batch size at which a GPU is bound by its "
+                       "memory system, not by the length of one walk" % (nqb, ", all-gather of the per-shard results in the step" if multi else "")}
+        log("%d queries per GPU per step, resident: %.0f q/s, %.3f ms/step" % (nqb, big["value"], big["ms_per_step"]))
+        del Qbig, big_res, big_all
+
     # ---- the same steps through the float32 rows (never `value`): the general-format kernel, the one the HBM
     #      roofline bounds (a byte row is a quarter of the bytes and leaves that regime) ----
     fp32_leg = None
@@ -428,6 +532,7 @@ def main():
             (nq * args.steps / wall_fh, nq * args.steps / wall_f, 1e3 * wall_f / args.steps, fp32_leg["prepass_ms"], fp32_leg["search_ms"]))
     if not multi:
         host_last = (host_i.copy(), host_d.copy())
+        host_last_j = last_host_batch[0]
 
     # ---- extra (--pipelined, N = 1, not `value`): the same steps alternated over two HIP streams ----
     # A single 10 k-query launch ends with a drain phase (the last queries to start run on a nearly
@@ -536,8 +641,10 @@ def main():
         checks["device_call_equals_drop_in"] = bool(np.array_equal(hi_, got) and np.array_equal(hd_.view(np.uint32), got_dist.view(np.uint32)))
         # what the timed headline steps themselves left in the caller's matrices (float32-row leg last: same bits)
         if not multi:
-            checks["headline_steps_results_equal_device_call"] = bool(np.array_equal(host_last[0], got) and
-                                                                      np.array_equal(host_last[1].view(np.uint32), got_dist.view(np.uint32)))
+            search(ef, slot=1, j=host_last_j)     # the batch the last timed step searched
+            torch.cuda.synchronize()
+            checks["headline_steps_results_equal_device_call"] = bool(np.array_equal(host_last[0], ids_v[1].cpu().numpy()) and
+                                                                      np.array_equal(host_last[1].view(np.uint32), dist_v[1].cpu().numpy().view(np.uint32)))
 
         def timed_calls(fn):
             ts = []
@@ -625,6 +732,7 @@ def main():
     #      SURVEY 8d (4096 blobs, sigma 25) is benign: recall 1.0 at ef 128 with ~950 evaluations per query,
     #      where real SIFT1M needs 2500-3500.  Same n, d, M, efConstruction, batch; never `value`. ----
     secondary = None
+    hard_idx = None      # (index file, ef) of the harder set at its recall gate, for the live counter passes
     if world == 1 and rank == 0 and not args.dataset and not args.no_secondary:
         t0 = time.time()
         X2d = make_sift_like(n, d, seed=1, device=dev, n_centres=256, sigma=40.0)
@@ -727,12 +835,55 @@ def main():
                 r2 = recall_ids(ids_v[0].cpu().numpy()[:ns2], gt2)
                 if r2 >= 0.95:
                     w3h = timed2_host(ef2, steps2)
-                    w3, _, _ = timed2(ef2, steps2)
-                    secondary["at_recall_0.95"] = {"ef": ef2, "recall_at_10": round(r2, 4), "value": round(nq / w3h, 1),
-                                                   "unit": "queries/s", "ms_per_step": round(1e3 * w3h, 4),
-                                                   "device_resident_value": round(nq / w3, 1), "device_resident_ms_per_step": round(1e3 * w3, 4),
-                                                   "what": "`value`: the headline's protocol (host matrices in and out) at the smallest ef of the "
-                                                           "ladder that reaches recall@10 >= 0.95 on this set"}
+                    w3, sm3, pm3 = timed2(ef2, steps2)
+                    gate = {"ef": ef2, "recall_at_10": round(r2, 4), "value": round(nq / w3h, 1),
+                            "unit": "queries/s", "ms_per_step": round(1e3 * w3h, 4),
+                            "device_resident_value": round(nq / w3, 1), "device_resident_ms_per_step": round(1e3 * w3, 4),
+                            "what": "`value`: the headline's protocol (host matrices in and out) at the smallest ef of the "
+                                    "ladder that reaches recall@10 >= 0.95 on this set"}
+                    # the kernel that serves this point (W in four registers from ef 129 on) against the HBM line, as the headline's
+                    search2(ef2, counters=True)
+                    torch.cuda.synchronize()
+                    g_nd3 = nd_d.cpu().numpy().astype(np.int64)
+                    nd3, nh3, nu3 = float(g_nd3.mean()), float(nh_d.float().mean().item()), None
+                    src3 = "gpu counters (include re-evaluations)"
+                    if not args.no_cpu:
+                        sp3 = o.Space.l2(X2, arith=o.TREE16)
+                        g3 = o.Graph(hg2.n, hg2.entry_point, hg2.deg0, hg2.nbr0, hg2.upper)
+                        s3 = min(500, nq)
+                        oi3, od3, ond3, onh3, onu3 = o.Ohnsw.knn_batch_bigarray(g3, sp3, Q2d[:s3].cpu().numpy(), k=k, ef=ef2, ties=o.TIES_CANONICAL, split=True)
+                        gate["checks"] = {"parity_queries": s3, "parity_ids_equal": bool(np.array_equal(oi3, ids_v[0].cpu().numpy()[:s3])),
+                                          "parity_dist_bits_equal": bool(np.array_equal(od3.view(np.uint32), dist_v[0].cpu().numpy()[:s3].view(np.uint32))),
+                                          "gpu_reevaluation_overhead": round(float(g_nd3[:s3].mean() / max(ond3.mean(), 1) - 1), 4)}
+                        nd3, nh3, nu3 = float(ond3.mean()), float(onh3.mean()), float(onu3.mean())
+                        src3 = "oracle counters on %d queries" % s3
+                        del sp3, g3
+                    l03 = pm3 > 0 and nu3 is not None
+
+                    def bq3_of(rb_):
+                        return (nd3 - (nu3 if l03 else 0.0)) * (rb_ + 4) + nh3 * 4 * S2 + 4 * d + 8 * k + (16 if l03 else 0)
+                    kms3 = sm3 if (l03 or pm3 <= 0) else sm3 + pm3
+                    gate["roofline"] = {"bound": "hbm", "kernel": search_kernel_name(d, ef2, 0, 0, 2 if rb2 == d else -1), "kernel_ms": round(kms3, 4),
+                                        "prepass_ms": round(pm3, 4), "bytes_per_query": round(bq3_of(rb2), 1), "row_bytes": rb2,
+                                        "achieved": round(bq3_of(rb2) * nq / (kms3 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(bq3_of(rb2) * nq / (kms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                        "n_dist_per_query": round(nd3, 1), "n_hops_per_query": round(nh3, 1), "counters": src3}
+                    if rb2 == d:     # ... and through its float32 rows at this ef
+                        hg2.set_option("byte_rows", 0)
+                        w3fh = timed2_host(ef2, steps2)
+                        w3f, sm3f, pm3f = timed2(ef2, steps2)
+                        hg2.set_option("byte_rows", 1)
+                        kms3f = sm3f if (l03 or pm3f <= 0) else sm3f + pm3f
+                        gate["float32_rows"] = {"value": round(nq / w3fh, 1), "unit": "queries/s", "ms_per_step": round(1e3 * w3fh, 4),
+                                                "device_resident_value": round(nq / w3f, 1), "kernel": search_kernel_name(d, ef2, 0, 0, -1),
+                                                "kernel_ms": round(kms3f, 4), "bytes_per_query": round(bq3_of(4 * d), 1),
+                                                "frac": round(bq3_of(4 * d) * nq / (kms3f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}
+                    secondary["at_recall_0.95"] = gate
+                    if not args.no_pmc and ef2 != ef:
+                        import tempfile
+                        hard_dir = tempfile.mkdtemp(prefix="hnsw_pmc_hard_", dir="/tmp")
+                        hard_idx = (os.path.join(hard_dir, "hard.idx"), ef2)
+                        hg2.save(hard_idx[0])      # for the live counter passes further down
                     break
         log("secondary (256 blobs, sigma 40): %.0f q/s at ef=%d, recall@10 %.4f, %.0f evaluations/query, frac %.3f (%.1fs)" %
             (nq / w2, ef, rec2, nd2, ach2 / HBM_PEAK_GBS, time.time() - t0))
@@ -874,7 +1025,8 @@ def main():
             So = 2 * M_
             rbo = hgo.row_bytes()
             fmt_ = int(hgo.info().row_format)
-            kern = search_kernel_name(d_, ef_, metric_, 0, fmt_ if fmt_ else -1)
+            blk_ = hgo.visited_blocks(ef_)
+            kern = search_kernel_name(d_, ef_, metric_, 0, fmt_ if fmt_ else -1, blk_)
             ordered_ = pm_ > 0
             l0 = ordered_ and nu_ is not None
             bq_ = (nd_ - (nu_ if l0 else 0.0)) * (rbo + 4) + nh_ * 4 * So + 4 * d_ + 8 * k_ + (16 if l0 else 0)
@@ -894,6 +1046,8 @@ def main():
                                  "measured_gather_ceiling": dict(ceiling, frac_of_it=round(ach_ / (1e3 * ceiling["TBps"]), 4)),
                                  "prepass_ms": round(pm_, 4), "bytes_per_query": round(bq_, 1), "row_bytes": rbo,
                                  "n_dist_per_query": round(nd_, 1), "n_hops_per_query": round(nh_, 1), "counters": src_,
+                                 "visited": ("bitmap blocks over locality codes, 2^%d slots of 256 codes (the handle's own measurement: option visited_blocks -1)" % blk_) if blk_
+                                            else "tag cache (the handle's own measurement where the shape has a choice: option visited_blocks -1)",
                                  "index_bytes": int(hgo.info().device_bytes) if hasattr(hgo, "info") else None},
                     "checks": ck}
             log("%s: %.0f q/s, %.3f ms/step (kernel %.3f ms), %.0f evaluations/query, frac %.3f, parity %s (%.0fs)" %
@@ -1053,7 +1207,9 @@ def main():
                     outd = os.path.join(tmpd, gname)
                     cmd = [rp, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", outd, "--", sys.executable,
                            os.path.abspath(__file__), "--pmc-child", idx_file, "--nq", str(nq), "--d", str(d), "--ef", str(ef), "--k", str(k)]
-                    r_ = subprocess.run(cmd, cwd="/tmp", env=env_, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+                    if hard_idx:
+                        cmd += ["--pmc-hard", hard_idx[0], "--pmc-hard-ef", str(hard_idx[1])]
+                    r_ = subprocess.run(cmd, cwd="/tmp", env=env_, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
                     if r_.returncode != 0:
                         pmc.setdefault("failed", {})[gname] = r_.stderr.decode(errors="replace")[-300:]
                         continue
@@ -1063,15 +1219,19 @@ def main():
                             if "hnsw_search_kernel" not in kn:
                                 continue
                             key_ = "bytes" if kernel_rows_of(kn) == 2 else "float32"      # the ROWS template argument, whatever d and ef are
+                            if hard_idx and kernel_nslot_of(kn) == search_nslot(hard_idx[1]) != search_nslot(ef):
+                                key_ = "hard_" + key_                                       # the harder set's launches: W in more registers
                             a_ = pmc.setdefault(key_, {}).setdefault(row["Counter_Name"], [0.0, 0])
                             a_[0] += float(row["Counter_Value"]); a_[1] += 1
-                for key_ in ("bytes", "float32"):
+                for key_ in ("bytes", "float32", "hard_bytes", "hard_float32"):
                     if key_ in pmc:
                         pmc[key_] = {c_: v_[0] / v_[1] for c_, v_ in pmc[key_].items()}
             except Exception as e:
                 pmc = {"skipped": "live counter pass failed: %r" % (e,)}
             finally:
                 shutil.rmtree(tmpd, ignore_errors=True)
+                if hard_idx:
+                    shutil.rmtree(os.path.dirname(hard_idx[0]), ignore_errors=True)
         log("live rocprofv3 counter passes: %s (%.0fs)" % ({k_: (sorted(v_) if isinstance(v_, dict) else v_) for k_, v_ in pmc.items()}, time.time() - t0))
 
     def live_counters(rows_key, kernel_ms_):
@@ -1101,6 +1261,17 @@ def main():
                       "instructions_per_dispatch": tot,
                       "source": "rocprofv3 --pmc pass of this run (a child process on the same index and batch, 5 dispatches)"}
         return traffic_, issue_
+
+    if secondary and isinstance(secondary.get("at_recall_0.95"), dict) and "roofline" in secondary["at_recall_0.95"]:
+        g_ = secondary["at_recall_0.95"]
+        for key_, tgt in (("hard_bytes" if g_["roofline"]["row_bytes"] == d else "hard_float32", g_["roofline"]), ("hard_float32", g_.get("float32_rows"))):
+            if tgt is not None and tgt.get("traffic") is None:
+                tr_, is_ = live_counters(key_, tgt["kernel_ms"])
+                tgt["traffic"] = tr_
+                tgt["traffic_source"] = "live rocprofv3 FETCH_SIZE pass of this run x 2 (gfx950)" if tr_ is not None else None
+                if is_ is not None and tgt is g_["roofline"]:
+                    is_["instructions_per_hop"] = round(is_["instructions_per_dispatch"] / (nq * tgt["n_hops_per_query"]), 1)
+                    tgt["issue"] = is_
 
     # ---- algorithmic bytes from the CPU oracle's counters on the same graph/queries,
     #      parity spot-check, and the CPU baseline (rank 0) ----
@@ -1136,9 +1307,13 @@ def main():
                 # double: oracle SEQ_F32), not with the kernel's summation order used for the parity leg above
                 sp_ref = o.Space.l2(X, arith=o.SEQ_F32)
                 Qall_h = Qd.cpu().numpy()
-                t = time.perf_counter()
-                rids, rdist = o.Ohnsw.knn_batch_bigarray(g, sp_ref, Qall_h, k=k, ef=ef, ties=o.TIES_CANONICAL)
-                ref_s = time.perf_counter() - t
+                ref_ts = []
+                for _ in range(3):          # three passes, the median (one pass moved 3.7 -> 3.0 k q/s between two boxes in round 4)
+                    t = time.perf_counter()
+                    rids, rdist = o.Ohnsw.knn_batch_bigarray(g, sp_ref, Qall_h, k=k, ef=ef, ties=o.TIES_CANONICAL)
+                    ref_ts.append(time.perf_counter() - t)
+                ref_ts.sort()
+                ref_s = ref_ts[1]
                 # integer-valued data: every summation order is exact, so this leg must reproduce the GPU bit for bit too
                 checks["cpu_reference_arithmetic_ids_equal"] = bool(np.array_equal(rids, got))
                 ncores = host_cores()
@@ -1147,7 +1322,8 @@ def main():
                 mt_s = time.perf_counter() - t
                 checks["cpu_all_cores_ids_equal"] = bool(np.array_equal(mids, got))
                 cpu_baseline = {"value": round(nq / ref_s, 1), "unit": "queries/s", "cores": 1, "kind": "port",
-                                "sample": "all %d queries of one batch (%.1f s), same graph, ef=%d k=%d: single-thread C restatement of "
+                                "passes": 3, "statistic": "median", "value_min": round(nq / ref_ts[2], 1), "value_max": round(nq / ref_ts[0], 1),
+                                "sample": "all %d queries of one batch, three passes (median %.1f s), same graph, ef=%d k=%d: single-thread C restatement of "
                                           "Ohnsw.knn_batch_bigarray (not OCaml) with the reference's arithmetic (sequential fp32 "
                                           "sum, sqrt in double); the reference is single-threaded" % (nq, ref_s, ef, k),
                                 "all_cores": {"value": round(nq / mt_s, 1), "cores": ncores,
@@ -1255,14 +1431,17 @@ def main():
                                       ", RCCL all-gather of results" if world > 1 else "", nd_head, nd_hard),
                        "n": n, "d": d, "M": args.M, "ef_construction": args.efc, "ef": ef, "k": k,
                        "queries_per_gpu": nq, "global_batch": world * nq, "parallelism": "replica x%d" % world,
+                       "batches_rotated": NB,
                        "rows": "bytes (lossless copy of integer-valued float32 data)" if byte_rows else "float32",
                        "headline_set": {"n_dist_per_query": nd_head, "recall_at_10": checks.get("recall_at_10"), "ef": ef},
                        "harder_set": (None if not secondary else
                                       {"n_dist_per_query": nd_hard, "recall_at_10": secondary["checks"]["recall_at_10"], "ef": ef,
                                        "ef_at_recall_gate": (ef if secondary["checks"]["recall_at_10"] >= 0.95 else (secondary.get("at_recall_0.95") or {}).get("ef")),
                                        "closer_to_SIFT1M": True})},
+            "cold_first_call_ms": None if not cold else cold["first_call_ms"],
+            "cold": cold,
             "protocol": ("one synchronous call per %d-query batch with HOST matrices in and out, as benchmark/benchmark.ml:89-96 times knn_batch "
-                         "and SURVEY 8d prescribes: " % nq) +
+                         "and SURVEY 8d prescribes; the warm-up and the timed steps rotate through %d distinct batches (seeds 2..%d): " % (nq, NB, 1 + NB)) +
                         ("hnsw_search_batch (H2D of the queries, ordering pre-pass, search kernel, D2H of the results; the caller's matrices in "
                          "page-locked memory: hnsw_host_alloc / hnsw_host_register)" if world == 1 else
                          "per rank hnsw_search_batch_h2d (its registered query shard read by the device, ordering pre-pass, search kernel, results in "
@@ -1276,6 +1455,7 @@ def main():
                                         "results left in HBM%s; `value` from a pass without event records, the kernel durations from an instrumented "
                                         "pass of the same steps (five event records per step cost the stream about 0.02 ms)"
                                         % (args.steps, " (search of step i+1 overlapped with the all-gather of step i)" if world > 1 else "")},
+            "bandwidth_point": big,
             "float32_rows": (None if not fl else
                              {"value": round(nq * args.steps / fp32_leg["host_wall"], 1), "unit": "queries/s",
                               "ms_per_step": round(1e3 * fp32_leg["host_wall"] / args.steps, 4), "ms_per_step_stats": fp32_leg["host_stats"],

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_index_row_bytes", "hnsw_search_batch",
     "hnsw_search_batch_device", "hnsw_search_batch_h2d", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
-    "hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_locality_codes", "hnsw_index_save", "hnsw_index_load",
+    "hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_locality_codes", "hnsw_index_visited_blocks", "hnsw_index_save", "hnsw_index_load",
     "hnsw_search_layer_batch", "hnsw_search_one_batch",
     "hnsw_search_submit", "hnsw_search_wait", "hnsw_index_kernel_times",
     "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
@@ -124,6 +124,8 @@ def load():
     L.hnsw_index_layer_isolated.argtypes = [vp, i32, vp, i64, vp]
     L.hnsw_index_locality_codes.argtypes = [vp, vp]
     L.hnsw_index_locality_codes.restype = i32
+    L.hnsw_index_visited_blocks.argtypes = [vp, vp, vp]
+    L.hnsw_index_visited_blocks.restype = i32
     L.hnsw_index_save.argtypes = [vp, _C.c_char_p]
     L.hnsw_index_load.argtypes = [_C.c_char_p, i32, vp]
     for f in ("hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_save", "hnsw_index_load"):
@@ -272,6 +274,13 @@ class Hgraph:
         out = _np.empty(self.n, _np.int32)
         _check(load().hnsw_index_locality_codes(self.handle, _ptr(out)))
         return out
+
+    def visited_blocks(self, ef, sem=0):
+        """hnsw_index_visited_blocks: 0 = searches at this ef use the tag cache, else log2 of the bitmap-block slots"""
+        p = _SearchParams(ef, 1, FILL_OHNSW, sem)
+        out = _C.c_int32(0)
+        _check(load().hnsw_index_visited_blocks(self.handle, _C.byref(p), _C.byref(out)))
+        return out.value
 
     def stats(self):
         """Hgraph.Stats.compute (lib/hnsw.ml:353-375): {num_nodes, layer_sizes, layer_connectivity}; a layer's

@@ -503,6 +503,15 @@ int32_t hnsw_index_locality_codes(hnsw_index *idx, int32_t *out) {
     return HNSW_OK;
 }
 
+int32_t hnsw_index_visited_blocks(hnsw_index *idx, const hnsw_search_params *params, int32_t *log2_slots) {
+    if (!log2_slots) return fail(HNSW_ERR_BAD_ARG, "null argument");
+    int rc = check_params(idx, params);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(idx->device));
+    *log2_slots = knn_blk_bits(idx, params->ef, params->semantics ? 1 : 0);
+    return HNSW_OK;
+}
+
 int32_t hnsw_index_row_bytes(const hnsw_index *idx, int64_t *row_bytes) {
     if (!idx || !row_bytes) return fail(HNSW_ERR_BAD_ARG, "null argument");
     *row_bytes = idx->iv.X8 ? (int64_t)idx->iv.d : (int64_t)idx->iv.d * 4;
@@ -912,23 +921,26 @@ int32_t hnsw_host_register(void *p, int64_t bytes) {
                             "(unregister the shorter range first)", (long long)bytes);
         }
     }
-    hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
-    if (e == hipErrorHostMemoryAlreadyRegistered) {
-        // pinned by somebody else (the application, another library): theirs to unpin.  Copies out of it run at pinned speed
-        // anyway; the library neither maps it for direct access nor ever unregisters it.
-        (void)hipGetLastError();
-        remember_range(p, (size_t)bytes, nullptr, RANGE_FOREIGN);
-        return HNSW_OK;
-    }
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(HNSW_ERR_HIP, "hipHostRegister(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); }
-    // "success" is believed only if every page answers as page-locked host memory (at most 4096 probes: the step grows with
-    // the array) -- a foreign registration that covers only the array's beginning, or its two ends, leaves pageable pages
-    // that a kernel's loads would fault on
     auto locked = [](const void *q) {
         hipPointerAttribute_t a{};
         if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
         return a.type == hipMemoryTypeHost;
     };
+    hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        // Page-locked by somebody else -- registered (hipErrorHostMemoryAlreadyRegistered) or allocated page-locked (hipHostMalloc,
+        // a torch pin_memory tensor: the runtime then answers "invalid argument") --: theirs to unpin.  Copies out of it run at
+        // pinned speed anyway; the library neither maps it for direct access nor ever unregisters it.
+        if (e == hipErrorHostMemoryAlreadyRegistered || (locked(b) && locked(e_ - 1))) {
+            remember_range(p, (size_t)bytes, nullptr, RANGE_FOREIGN);
+            return HNSW_OK;
+        }
+        return fail(HNSW_ERR_HIP, "hipHostRegister(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e));
+    }
+    // "success" is believed only if every page answers as page-locked host memory (at most 4096 probes: the step grows with
+    // the array) -- a foreign registration that covers only the array's beginning, or its two ends, leaves pageable pages
+    // that a kernel's loads would fault on
     const size_t step = std::max<size_t>(4096, (((size_t)bytes / 4096) + 4095) / 4096 * 4096);
     bool whole = locked(e_ - 1);
     for (size_t o = 0; whole && o < (size_t)bytes; o += step) whole = locked(b + o);

@@ -154,6 +154,8 @@ let hnsw_index_layer_isolated =
     (index @-> int32_t @-> ptr int64_t @-> int64_t @-> ptr int64_t @-> returning int32_t)
 let hnsw_index_locality_codes =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_index_locality_codes" (index @-> ptr int32_t @-> returning int32_t)
+let hnsw_index_visited_blocks =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_index_visited_blocks" (index @-> ptr search_params @-> ptr int32_t @-> returning int32_t)
 let hnsw_abi_version = foreign ~from:lib "hnsw_abi_version" (void @-> returning int32_t)
 (* HNSW_ABI_VERSION of include/hnsw_mi355x.h this binding was written against: an older or newer library is refused at load
    time (version 2: hnsw_search_batch_h2d, hnsw_host_alloc / hnsw_host_free, hnsw_index_layer_isolated, hnsw_multi_debug_counters,
@@ -769,6 +771,14 @@ let locality_codes (t : t) ~n : (int32, Bigarray.int32_elt, Bigarray.c_layout) A
   let out = A1.create Bigarray.int32 Bigarray.c_layout n in
   check (hnsw_index_locality_codes t.handle (bigarray_start array1 out));
   out
+
+(* 0: searches at this ef use the tag cache; else log2 of the bitmap-block slots (hnsw_index_visited_blocks) *)
+let visited_blocks ?(semantics = 0) (t : t) ~ef : int =
+  let p = make search_params in
+  setf p p_ef (Int32.of_int ef); setf p p_k 1l; setf p p_fill 0l; setf p p_semantics (Int32.of_int semantics);
+  let out = allocate int32_t 0l in
+  check (hnsw_index_visited_blocks t.handle (addr p) out);
+  Int32.to_int !@out
 
 (* Hgraph.Stats.compute (lib/hnsw.ml:370-375) as the reference's record: per layer (size, {min; max; mean; isolated}) *)
 let stats_compute (t : t) ~max_layer : (int * (int * int * float * int list)) list =

@@ -8,8 +8,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # the default bench command minus the legs that would add dispatches of the same kernel on OTHER inputs (the
 # secondary data set), need the CPU oracle, or start rocprofv3 themselves: every hnsw_search_kernel dispatch below is the
-# headline workload (C2); BENCH_EXTRA=" " adds the C3 / C5 legs (`others`), whose kernels <2,4,4,1,0,0> / <2,4,8,0,0,0> then show too
-BENCH="python3 $PWD/bench.py --steps 20 --warmup 3 --no-cpu --no-secondary --no-bench-dist --no-pmc --no-clustered ${BENCH_EXTRA:---no-others}"
+# headline workload (C2); BENCH_EXTRA=" " adds the C3 / C5 legs (`others`), whose kernels then show too, the clustered twins under their own names (<...,1>: Visited as bitmap blocks)
+BENCH="python3 $PWD/bench.py --steps 20 --warmup 3 --no-cpu --no-secondary --no-bench-dist --no-pmc ${BENCH_EXTRA:---no-others}"
 cd /tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1 || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.json 2> $OUT/trace.log || exit 1
