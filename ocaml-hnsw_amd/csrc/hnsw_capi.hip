@@ -202,6 +202,10 @@ int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
         if (hnsw_dev::wave_lds_words_blocks(b) * sizeof(uint32_t) <= 65536 && occ0 > 0 &&
             occ(nch, nslot, hnsw_dev::search_lds_words(vt, b) * sizeof(uint32_t), 1) >= occ0) bits = b;
     if (bits == 0) return choice = 0;
+    {   // HNSW_BLK_BITS (tests): a smaller directory than fits, down to one set of eight slots -- evictions and contested slots on small graphs
+        const int forced = env_int("HNSW_BLK_BITS", 0);
+        if (forced >= 3) bits = std::min(bits, forced);
+    }
     if (build_locality_codes(idx) != HNSW_OK || idx->lcode_state != 1) return choice = 0;
     if (mode == 1) return choice = bits;
     // measure: every (n / 256)-th vector of the index as a query (a strided view of the vector table), k = 1

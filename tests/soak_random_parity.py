@@ -54,6 +54,8 @@ for trial in range(trials):
     hg.set_option("vt_bits", int(rng.choice([0, 4, 6, 9, 11, 13])))
     hg.set_option("byte_rows", int(rng.integers(0, 4) != 0))        # (no effect where the data has no byte copy)
     hg.set_option("split_rows", int(rng.integers(0, 4) != 0))       # (no effect where the row shape has no split copy)
+    os.environ["HNSW_BLK_BITS"] = str(int(rng.choice([0, 3, 4, 6])))  # Visited as bitmap blocks (ef > 128): the directory that fits, or a tiny one
+    hg.set_option("visited_blocks", int(rng.choice([0, 1, 1])))
     nq = int(rng.choice([1, 3, 17, 64, 200]))
     Q = (X[rng.integers(0, n, nq)] + (rng.integers(0, 2, size=(nq, d)) if metric == 0 else 0)).astype(np.float32)
     if rng.integers(0, 3) == 0:

@@ -120,6 +120,42 @@ def test_locality_codes_are_a_permutation_and_need_an_upper_layer(H, oracle):
     flat.release()
 
 
+@pytest.mark.parametrize("bits", [3, 4, 5])
+@pytest.mark.parametrize("shape", [("ragged_l2", 96, 0, 300), ("split_ip", 100, 1, 200), ("bytes_l2", 128, 0, 400)], ids=lambda s: s[0])
+def test_tiny_directories_evict_and_contest_without_inventing_visits(H, oracle, monkeypatch, shape, bits):
+    """HNSW_BLK_BITS forces a directory of 8 / 16 / 32 slots on a graph of 80 blocks: nearly every hop claims slots that other
+    lanes of the same hop claim too, and blocks are evicted while their nodes are still around -- the regime in which a wrong
+    ownership test would set a bit under another block's directory word.  Results must still be the oracle's, bit for bit
+    (only the evaluations may grow)."""
+    name, d, metric, ef = shape
+    monkeypatch.setenv("HNSW_BLK_BITS", str(bits))
+    if name == "bytes_l2":
+        rng = np.random.default_rng(5)
+        cen = rng.integers(20, 200, size=(16, d))
+        X = np.clip(np.rint(cen[rng.integers(0, 16, 20000)] + rng.normal(0, 25, size=(20000, d))), 0, 218).astype(np.float32)
+        Q = np.clip(np.rint(cen[rng.integers(0, 16, 60)] + rng.normal(0, 25, size=(60, d))), 0, 218).astype(np.float32)
+    else:
+        X = _clustered_np(20000, d, 21, 8)
+        Q = _clustered_np(60, d, 22, 8)
+    hg = H.Ohnsw.build_batch_bigarray(X, 16, 60, seed=3, metric=metric)
+    hg.export()
+    g = oracle.Graph(hg.n, hg.entry_point, hg.deg0, hg.nbr0, hg.upper)
+    sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
+    oi, od, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=10, ef=ef, ties=oracle.TIES_CANONICAL, counters=True)
+    fd, fi = oracle.Functor.knn_batch(g, sp, Q, ef, 10, ties=oracle.TIES_CANONICAL, with_ids=True)
+    hg.set_option("visited_blocks", 1)
+    assert hg.visited_blocks(ef) == bits
+    ids, dist, nd, nh = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=ef, counters=True)
+    np.testing.assert_array_equal(ids, oi)
+    np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+    np.testing.assert_array_equal(nh, onh)
+    assert (nd.astype(np.int64) + len(g.upper) >= ond).all()
+    gi, gd = H._search(hg, Q, ef, 10, H.FILL_BA, sem=H.SEM_FUNCTOR)
+    np.testing.assert_array_equal(gi, fi)
+    np.testing.assert_array_equal(gd.view(np.uint32), fd.view(np.uint32))
+    hg.release()
+
+
 def _sample_against_oracle(oracle, c, mode, n_sample, bound):
     H, hg = c["H"], c["hg"]
     hg.set_option("visited_blocks", mode)

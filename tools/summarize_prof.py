@@ -32,11 +32,18 @@ for f in find("trace/**/*kernel_trace.csv"):
                 if r0.get(nme) not in (None, ""):
                     return r0.get(nme)
             return "n/a"
+        # per kernel AND launch size: one bench run launches the same kernel on its 10 k batches, on the 100 k bandwidth point and
+        # (option visited_blocks -1) on the 256 sample queries of the handle's own measurement -- their durations are not one average
         by_name = defaultdict(list)
         for r, du in zip(rows, durs):
-            by_name[r["Kernel_Name"].split("(")[0]].append(du)
-        for nme, ds in sorted(by_name.items()):
-            out.append("== %s dispatches: n=%d avg=%.1f us min=%.1f us max=%.1f us" % (nme[-60:], len(ds), sum(ds) / len(ds) / 1e3, min(ds) / 1e3, max(ds) / 1e3))
+            grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
+            try:
+                grid = "%d queries" % (int(grid) // 64)
+            except ValueError:
+                pass
+            by_name[(r["Kernel_Name"].split("(")[0], grid)].append(du)
+        for (nme, grid), ds in sorted(by_name.items()):
+            out.append("== %s [%s per launch] dispatches: n=%d avg=%.1f us min=%.1f us max=%.1f us" % (nme[-60:], grid, len(ds), sum(ds) / len(ds) / 1e3, min(ds) / 1e3, max(ds) / 1e3))
         out.append("   (trace columns of the first dispatch: arch_vgpr=%s accum_vgpr=%s sgpr=%s lds=%s grid=%s wg=%s)" % (
             col("Arch_VGPR_Count", "VGPR_Count"), col("Accum_VGPR_Count"), col("SGPR_Count"), col("LDS_Block_Size", "LDS_Block_Size_v"),
             col("Grid_Size", "Grid_Size_X"), col("Workgroup_Size", "Workgroup_Size_X")))
@@ -53,7 +60,12 @@ for pdir in find("pmc_*/"):
         for r in csv.DictReader(open(f)):                            # byte-row and the float32-row kernel)
             if "hnsw_search_kernel" not in r.get("Kernel_Name", ""):
                 continue
-            a = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
+            grid = r.get("Grid_Size") or r.get("Grid_Size_X") or ""
+            try:
+                grid = " [%d queries per launch]" % (int(grid) // 64)
+            except ValueError:
+                grid = ""
+            a = acc[short(r["Kernel_Name"]) + grid][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
         for kn, cs in sorted(acc.items()):
             out.append("== PMC %s (per dispatch of %s, mean over %d dispatches)" % (

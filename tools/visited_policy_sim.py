@@ -52,8 +52,14 @@ def clustered(n, seed, centres=256, spread=1.5):
     return out
 
 
-X = clustered(N, 12)
-Q = clustered(NQ, 112)
+if os.environ.get("KIND", "clustered") == "sift":      # bench.py's harder SIFT-like set (256 blobs, sigma 40): byte-valued, M 16
+    import bench
+    X = bench.make_sift_like(N, D, 1, dev, 256, 40.0).cpu().numpy()
+    Q = bench.make_sift_like(NQ, D, 2, dev, 256, 40.0).cpu().numpy()
+    os.environ["BLOCKS_IDEAL"] = "0"
+else:
+    X = clustered(N, 12)
+    Q = clustered(NQ, 112)
 hg = H.Ohnsw.build_batch_bigarray(X, M, 200, seed=1, metric=METRIC)
 hg.export()
 deg0, nbr0 = hg.deg0, hg.nbr0
@@ -353,11 +359,13 @@ for sb in SB:
         names += [("thr%.2f" % a, sb, ways) for a in (0.0, 0.1, 0.2, 0.3, 0.5, 0.8, 1.2)]
 LCODES = {}
 if os.environ.get("BLOCKS", "1") != "0":
-    cl = np.concatenate(CLUSTER_OF[12])
-    order = np.lexsort((np.arange(N), cl))
-    Lc = np.empty(N, np.int64); Lc[order] = np.arange(N)
-    LCODES["ideal"] = Lc                                  # the generator's own cluster index: what a perfect order could do
-    LCODES["hubs"] = locality_codes()
+    if os.environ.get("BLOCKS_IDEAL", "1") != "0":
+        cl = np.concatenate(CLUSTER_OF[12])
+        order = np.lexsort((np.arange(N), cl))
+        Lc = np.empty(N, np.int64); Lc[order] = np.arange(N)
+        LCODES["ideal"] = Lc                              # the generator's own cluster index: what a perfect order could do
+    if os.environ.get("BLOCKS_HUBS", "1") != "0":
+        LCODES["hubs"] = locality_codes()
     LCODES["device"] = hg.locality_codes().astype(np.int64)        # what the library derives (greedy descents instead of exact nearest hubs)
     assert np.array_equal(np.sort(LCODES["device"]), np.arange(N)), "the device's codes are not a permutation"
     LCODES["ident"] = np.arange(N, dtype=np.int64)        # the ids as they are (insertion order: no locality)
@@ -368,7 +376,7 @@ if os.environ.get("BLOCKS", "1") != "0":
             for bs, nb in ((7, 409), (8, 227)):
                 for w in (8, 16):
                     names.append(("dl%d-" % w + lname, bs, nb))
-            for bs, sets, ways in ((8, 16, 16), (8, 32, 8), (7, 25, 16), (7, 32, 16), (8, 8, 16), (8, 8, 32), (7, 16, 16)):
+            for bs, sets, ways in ((8, 16, 16), (8, 32, 8), (7, 25, 16), (7, 32, 16), (8, 8, 16), (8, 8, 32), (7, 16, 16), (8, 8, 8), (8, 16, 8), (7, 16, 8), (6, 32, 8)):
                 names.append(("hw%d-" % sets + lname, bs, ways))
 tot = {nm: 0 for nm in names}
 exact = 0
