@@ -404,8 +404,43 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 // carries its block, 4 owners that missed clear the slot's bitmap, 5 owners whose bit was clear set it.  Scratch: the first
 // fifteen row registers (no rows are in flight between the rounds of two hops); um0..um3 are free between the peek and the
 // insertion.  vcc holds the valid lanes from label 6 on (every compare in between writes a scalar pair).
-#define HNSW_BLK_R(I) "v[" HNSW_STR(HNSW_F32_BASE) "+" #I "]"
-#define HNSW_BLK_R4(I) "v[" HNSW_STR(HNSW_F32_BASE) "+" #I ":" HNSW_STR(HNSW_F32_BASE) "+" #I "+3]"
+// The scratch registers by number: HNSW_BLK_R(I) = HNSW_BLK_REG_I, which hnsw_hop_loop.inc defines per row format -- the float32
+// loops' row registers are named (v40 ..: consecutive, so the directory is read and a bitmap cleared 128 bits at a time), the byte
+// loops' are operands (d0 .. d7, id0 .. id3, ta, tb, ckey: one dword per LDS instruction).
+#define HNSW_BLK_R(I) HNSW_BLK_REG_##I
+#define HNSW_BLK_F32_REG(I) "v[" HNSW_STR(HNSW_F32_BASE) "+" #I "]"
+#define HNSW_BLK_F32_REG4(I) "v[" HNSW_STR(HNSW_F32_BASE) "+" #I ":" HNSW_STR(HNSW_F32_BASE) "+" #I "+3]"
+#define HNSW_BLK_DIR_READ_F32                                                   \
+        "ds_read_b128 " HNSW_BLK_F32_REG4(0) ", %[va]\n\t"                      \
+        "ds_read_b128 " HNSW_BLK_F32_REG4(4) ", %[va] offset:16\n\t"
+#define HNSW_BLK_DIR_READ_B8                                                    \
+        "ds_read_b32 %[d0], %[va]\n\t"                                          \
+        "ds_read_b32 %[d1], %[va] offset:4\n\t"                                 \
+        "ds_read_b32 %[d2], %[va] offset:8\n\t"                                 \
+        "ds_read_b32 %[d3], %[va] offset:12\n\t"                                \
+        "ds_read_b32 %[d4], %[va] offset:16\n\t"                                \
+        "ds_read_b32 %[d5], %[va] offset:20\n\t"                                \
+        "ds_read_b32 %[d6], %[va] offset:24\n\t"                                \
+        "ds_read_b32 %[d7], %[va] offset:28\n\t"
+// (the zeros: register 0 .. 3 of the scratch set, resp. register 0 alone)
+#define HNSW_BLK_ZERO_F32                                                       \
+        "v_mov_b32_e32 " HNSW_BLK_F32_REG(0) ", 0\n\t"                          \
+        "v_mov_b32_e32 " HNSW_BLK_F32_REG(1) ", 0\n\t"                          \
+        "v_mov_b32_e32 " HNSW_BLK_F32_REG(2) ", 0\n\t"                          \
+        "v_mov_b32_e32 " HNSW_BLK_F32_REG(3) ", 0\n\t"
+#define HNSW_BLK_ZERO_B8 "v_mov_b32_e32 %[d0], 0\n\t"
+#define HNSW_BLK_CLEAR_F32(AD)                                                  \
+        "ds_write_b128 " AD ", " HNSW_BLK_F32_REG4(0) "\n\t"                    \
+        "ds_write_b128 " AD ", " HNSW_BLK_F32_REG4(0) " offset:16\n\t"
+#define HNSW_BLK_CLEAR_B8(AD)                                                   \
+        "ds_write_b32 " AD ", %[d0]\n\t"                                        \
+        "ds_write_b32 " AD ", %[d0] offset:4\n\t"                               \
+        "ds_write_b32 " AD ", %[d0] offset:8\n\t"                               \
+        "ds_write_b32 " AD ", %[d0] offset:12\n\t"                              \
+        "ds_write_b32 " AD ", %[d0] offset:16\n\t"                              \
+        "ds_write_b32 " AD ", %[d0] offset:20\n\t"                              \
+        "ds_write_b32 " AD ", %[d0] offset:24\n\t"                              \
+        "ds_write_b32 " AD ", %[d0] offset:28\n\t"
 #define HNSW_HOP_ADJACENCY_BLK \
         "4:\n\t"                            \
         "s_add_u32 %[nh], %[nh], 1\n\t"     \
@@ -446,8 +481,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_lshrrev_b32_e32 %[tag], 8, %[nc]\n\t"          /* block number */   \
         "v_and_b32_e32 %[va], %[bsm], %[tag]\n\t"         /* set */            \
         "v_lshl_add_u32 %[va], %[va], 5, %[vtb]\n\t"      /* its eight words */ \
-        "ds_read_b128 " HNSW_BLK_R4(0) ", %[va]\n\t"                           \
-        "ds_read_b128 " HNSW_BLK_R4(4) ", %[va] offset:16\n\t"                 \
+        HNSW_BLK_DIR_READ                                                      \
         "v_cmp_lt_i32_e32 vcc, -1, %[nb]\n\t"
 // one way: hit -> t0 = way; (age << 3) | way -> running maximum t1   (the compare's mask is read three instructions later)
 #define HNSW_BLK_WAY(I) \
@@ -485,10 +519,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "ds_write_b32 %[vw], " HNSW_BLK_R(9) "\n\t"                              /* 2 */                         \
         "ds_read_b32 " HNSW_BLK_R(14) ", %[vw]\n\t"                              /* 3 */                         \
         "s_mov_b64 exec, -1\n\t"                                                                                \
-        "v_mov_b32_e32 " HNSW_BLK_R(0) ", 0\n\t"                                                                \
-        "v_mov_b32_e32 " HNSW_BLK_R(1) ", 0\n\t"                                                                \
-        "v_mov_b32_e32 " HNSW_BLK_R(2) ", 0\n\t"                                                                \
-        "v_mov_b32_e32 " HNSW_BLK_R(3) ", 0\n\t"                                                                \
+        HNSW_BLK_ZERO                                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
         "v_and_b32_e32 " HNSW_BLK_R(10) ", " HNSW_BLK_R(10) ", " HNSW_BLK_R(11) "\n\t"                          \
         "v_lshrrev_b32_e32 " HNSW_BLK_R(14) ", 8, " HNSW_BLK_R(14) "\n\t"                                       \
@@ -497,8 +528,7 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_and_b64 %[um3], %[um3], vcc\n\t"                                      /* ... and I hold a neighbour: owner */ \
         "s_andn2_b64 %[um0], %[um3], %[um1]\n\t"                                 /* owners that missed */        \
         "s_mov_b64 exec, %[um0]\n\t"                                                                            \
-        "ds_write_b128 " HNSW_BLK_R(13) ", " HNSW_BLK_R4(0) "\n\t"               /* 4 */                         \
-        "ds_write_b128 " HNSW_BLK_R(13) ", " HNSW_BLK_R4(0) " offset:16\n\t"                                    \
+        HNSW_BLK_CLEAR(HNSW_BLK_R(13))                                           /* 4 */                         \
         "s_andn2_b64 %[um0], %[um3], %[um2]\n\t"                                 /* owners whose bit was clear */ \
         "s_mov_b64 exec, %[um0]\n\t"                                                                            \
         "ds_or_b32 " HNSW_BLK_R(12) ", " HNSW_BLK_R(11) "\n\t"                   /* 5: Visited.add */            \
@@ -1850,6 +1880,59 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_METRIC 1
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
+// ---- byte rows of 65..128 dimensions with Visited as bitmap blocks: W in four / eight registers
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_ROWS 2
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
 // ---- the same loops with Visited as bitmap blocks (HNSW_LOOP_BLK; hnsw_search_kernel<..., BLK = 1>): W in four / eight registers
 #define HNSW_LOOP_NAME search_layer0_f32_l2_full_blk_asm4
 #define HNSW_LOOP_NSLOT 4
@@ -2422,6 +2505,25 @@ __device__ __forceinline__ bool search_layer0_f32_sem1_asm(const IndexView &iv, 
     return false;
 }
 
+
+// byte rows of 65..128 dimensions with Visited as bitmap blocks
+template <int NSLOT, int METRIC>
+__device__ __forceinline__ void search_layer0_bytes_blk_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx,
+                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+    if constexpr (NSLOT == 4 && METRIC == 0) search_layer0_bytes_l2_blk_asm4(iv, w, cx, n_dist, n_hops, status);
+    if constexpr (NSLOT == 8 && METRIC == 0) search_layer0_bytes_l2_blk_asm8(iv, w, cx, n_dist, n_hops, status);
+    if constexpr (NSLOT == 4 && METRIC == 1) search_layer0_bytes_ip_blk_asm4(iv, w, cx, n_dist, n_hops, status);
+    if constexpr (NSLOT == 8 && METRIC == 1) search_layer0_bytes_ip_blk_asm8(iv, w, cx, n_dist, n_hops, status);
+}
+template <int NSLOT, int METRIC>
+__device__ __forceinline__ bool search_layer0_bytes_blk_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
+                                                                 uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+    if constexpr (NSLOT == 4 && METRIC == 0) return search_layer0_bytes_l2_sem1_blk_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+    if constexpr (NSLOT == 8 && METRIC == 0) return search_layer0_bytes_l2_sem1_blk_asm8(iv, w, cx, rs, n_dist, n_hops, status);
+    if constexpr (NSLOT == 4 && METRIC == 1) return search_layer0_bytes_ip_sem1_blk_asm4(iv, w, cx, rs, n_dist, n_hops, status);
+    if constexpr (NSLOT == 8 && METRIC == 1) return search_layer0_bytes_ip_sem1_blk_asm8(iv, w, cx, rs, n_dist, n_hops, status);
+    return false;
+}
 
 // ... with Visited as bitmap blocks (search_layer<..., BLK = 1>)
 template <int NSLOT, int METRIC, int ROWS>

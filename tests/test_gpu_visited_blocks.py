@@ -64,6 +64,10 @@ SMALL = [
     ("split_ip_4slots", 100, 1, 16, 60, 256, 50),
     ("full_l2_4slots", 128, 0, 12, 60, 200, 10),
     ("ragged_ip_8slots", 72, 1, 12, 60, 300, 10),
+    # byte-valued data of 65..128 dimensions (searched through the byte rows): the byte-row loops' block filter
+    ("bytes_l2_4slots", 128, 0, 16, 60, 200, 10),
+    ("bytes_l2_8slots", 100, 0, 12, 60, 400, 10),
+    ("bytes_ip_4slots", 96, 1, 12, 60, 256, 20),
     # other shapes: the C++ loop's block filter
     ("d32_4slots", 32, 0, 8, 40, 200, 10),
     ("d200_8slots", 200, 0, 8, 40, 400, 10),
@@ -74,12 +78,19 @@ SMALL = [
 @pytest.mark.parametrize("case", SMALL, ids=lambda c: c[0])
 def test_blocks_equal_the_exact_visited_set_on_small_graphs(H, oracle, case):
     name, d, metric, M, efc, ef, k = case
-    X = _clustered_np(5000, d, 11, 12)
-    Q = _clustered_np(120, d, 12, 12)
+    if name.startswith("bytes"):
+        rng = np.random.default_rng(11)
+        cen = rng.integers(20, 200, size=(12, d))
+        X = np.clip(np.rint(cen[rng.integers(0, 12, 5000)] + rng.normal(0, 25, size=(5000, d))), 0, 218).astype(np.float32)
+        Q = np.clip(np.rint(cen[rng.integers(0, 12, 120)] + rng.normal(0, 25, size=(120, d))), 0, 218).astype(np.float32)
+    else:
+        X = _clustered_np(5000, d, 11, 12)
+        Q = _clustered_np(120, d, 12, 12)
     sp = (oracle.Space.ip if metric else oracle.Space.l2)(X, arith=oracle.TREE16)
     g = oracle.build_ohnsw(sp, M, efc, seed=5)
     assert len(g.upper) >= 1, "the codes need an upper layer"
     hg = _hgraph(H, X, g, metric, M)
+    assert (hg.row_bytes() == d) == name.startswith("bytes")
     oi, od, ond, onh = oracle.Ohnsw.knn_batch_bigarray(g, sp, Q, k=k, ef=ef, ties=oracle.TIES_CANONICAL, counters=True)
     fd, fi = oracle.Functor.knn_batch(g, sp, Q, ef, k, ties=oracle.TIES_CANONICAL, with_ids=True)
     for mode in (1, 0):
