@@ -17,8 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _tool():
+    if "check_asm_hazards" in sys.modules:                   # (one module object per process: its classes travel between the worker
+        return sys.modules["check_asm_hazards"]              # processes of the `objects` fixture and the test process by name)
     spec = importlib.util.spec_from_file_location("check_asm_hazards", os.path.join(ROOT, "tools", "check_asm_hazards.py"))
     m = importlib.util.module_from_spec(spec)
+    sys.modules["check_asm_hazards"] = m
     spec.loader.exec_module(m)
     return m
 
@@ -75,29 +78,10 @@ def test_rules_on_hand_made_listings():
     assert not _violations(hz, loop)
 
 
-@pytest.fixture(scope="module")
-def objects():
-    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") and not shutil.which("llvm-objdump"):
-        pytest.skip("llvm-objdump not available")
-    hz = _tool()
-    paths = hz.default_objects()
-    if not all(os.path.exists(p) for p in paths):            # a tree that was never built here: build it (hipcc cross-compiles)
-        sys.path.insert(0, ROOT)
-        import __graft_entry__ as g
-        g._load_build_module().build(force=True)
-    return hz, {os.path.basename(p): hz.parse(hz.disassemble(p)) for p in paths}
-
-
-def test_built_code_objects_have_no_unpadded_hazard(objects):
-    hz, objs = objects
-    for name, funcs in objs.items():
-        bad = [(k, v) for k, body in funcs.items() for v in hz.check(body)]
-        assert not bad, "%s: %d hazards, first: %s\n%s" % (name, len(bad), bad[0][0], bad[0][1])
-
-
-def _asm_kernels(objs):
-    """the kernels that contain hand-scheduled code: the layer-0 loops (W in 1 / 2 / 4 key registers) over byte rows and over
-    float32 rows (L2 and inner product, full and ragged rows), and the descent kernel with the hand-scheduled descent"""
+def _wanted():
+    """(object, mangled-name fragment) of the kernels that contain hand-scheduled code: the layer-0 loops (W in 1 / 2 / 4 / 8 key
+    registers) over byte rows and over float32 rows (L2 and inner product; full, ragged and split rows), with the tag cache and
+    with the bitmap blocks, and the descent kernel with the hand-scheduled descent"""
     want = [("hnsw_search_variants_0_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi0ELi2ELi0EE" % s) for s in (1, 2, 4)]
     for obj, metric, rows in (("hnsw_search_variants_0_0_1.o", 0, 1), ("hnsw_search_variants_0_0_0.o", 0, 0),
                               ("hnsw_search_variants_1_0_1.o", 1, 1), ("hnsw_search_variants_1_0_0.o", 1, 0)):
@@ -108,13 +92,54 @@ def _asm_kernels(objs):
     want += [("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi3ELi0EE" % s) for s in (4,)]               # split rows (C3's kernel)
     want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi8ELi0ELi0ELi0ELi0EE")]                                    # eight slots (C5's kernel)
     # Visited as bitmap blocks (BLK = 1): the block filter inside the eight-slot ragged-row loop (C5's kernel when its data is
-    # clustered) and inside the four-slot split-row inner-product loop (C3's)
+    # clustered), inside the four-slot split-row inner-product loop (C3's) and inside the four-slot byte-row loop
     want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi8ELi0ELi0ELi0ELi1EE"),
-             ("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi4ELi1ELi0ELi3ELi1EE")]
+             ("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi4ELi1ELi0ELi3ELi1EE"),
+             ("hnsw_search_variants_0_0_2.o", "hnsw_search_kernelILi2ELi4ELi4ELi0ELi0ELi2ELi1EE")]
     want += [("hnsw_order.hip.o", "hnsw_descent_kernelILi2ELi8ELi0ELi2E")]
+    return want
+
+
+def _scan_object(path):
+    """(worker process) one code object: every kernel checked, the hand-scheduled ones handed back parsed"""
+    hz = _tool()
+    funcs = hz.parse(hz.disassemble(path))
+    name = os.path.basename(path)
+    bad = [(k, str(v)) for k, body in funcs.items() for v in hz.check(body)]
+    frags = [f for o, f in _wanted() if o == name]
+    keep = {k: b for k, b in funcs.items() if any(f in k for f in frags)}
+    return name, len(funcs), bad, keep
+
+
+@pytest.fixture(scope="module")
+def objects():
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") and not shutil.which("llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    hz = _tool()
+    paths = hz.default_objects()
+    if not all(os.path.exists(p) for p in paths):            # a tree that was never built here: build it (hipcc cross-compiles)
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g._load_build_module().build(force=True)
+    # seventeen objects of some 200 000 instructions each: disassembled, parsed and checked in worker processes; only the
+    # violations and the hand-scheduled kernels (the mutation test's material) come back
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
+        scanned = list(ex.map(_scan_object, paths))
+    return hz, {name: (nfuncs, bad, keep) for name, nfuncs, bad, keep in scanned}
+
+
+def test_built_code_objects_have_no_unpadded_hazard(objects):
+    hz, objs = objects
+    for name, (nfuncs, bad, _) in objs.items():
+        assert nfuncs >= 1, name
+        assert not bad, "%s: %d hazards, first: %s\n%s" % (name, len(bad), bad[0][0], bad[0][1])
+
+
+def _asm_kernels(objs):
     out = []
-    for obj, frag in want:
-        hits = [(k, b) for k, b in objs[obj].items() if frag in k]
+    for obj, frag in _wanted():
+        hits = [(k, b) for k, b in objs[obj][2].items() if frag in k]
         assert len(hits) == 1, (obj, frag, [k for k, _ in hits])
         out.append((obj, hits[0][0], hits[0][1]))
     return out
@@ -161,14 +186,16 @@ def test_labels_are_unique_within_every_block(tmp_path):
                     "-o", out], check=True, capture_output=True)
     text = open(out).read()
     blocks = []
+    lit = re.compile(r'\s*"((?:[^"\\]|\\.)*)"')
     for m in re.finditer(r"asm volatile\(", text):
-        j, body = m.end(), ""
+        j, parts = m.end(), []
         while True:
-            mm = re.match(r'\s*"((?:[^"\\]|\\.)*)"', text[j:])
+            mm = lit.match(text, j)                    # (no slicing: the preprocessed unit is tens of megabytes)
             if not mm:
                 break
-            body += bytes(mm.group(1), "utf-8").decode("unicode_escape")
-            j += mm.end()
+            parts.append(bytes(mm.group(1), "utf-8").decode("unicode_escape"))
+            j = mm.end()
+        body = "".join(parts)
         if re.search(r"^\s*\d+:", body, flags=re.M):
             blocks.append(body)
     assert len(blocks) >= 60, len(blocks)            # 3 x 2 byte-row + 3 x 2 x 2 x 3 float32-row loops per slot count ..., the descent, the island
@@ -232,3 +259,24 @@ def test_a_deleted_wait_state_is_noticed(objects):
         print("%s %s: %d instructions, %d of %d single s_nop deletions caught" % (obj, name[:60], len(body), caught, len(nops)))
         assert nops and caught >= 0.9 * len(nops), (name, caught, len(nops))
         assert not hz.check(body)                             # and the untouched listing is clean again
+
+
+def test_hand_scheduled_blocks_hand_m0_back():
+    """the blocks use m0 as the lane select of v_writelane.  m0 is a reserved register: naming it as a clobber
+    draws `inline asm clobber list contains reserved registers` (128 warnings in round 4) and promises nothing.  Every block now
+    saves m0 on entry and restores it at its single exit, and no clobber list names it -- checked on the source text (the build
+    prints no warning: ocaml-hnsw_amd/build.py)."""
+    import re
+    csrc = os.path.join(ROOT, "ocaml-hnsw_amd", "csrc")
+    inc = open(os.path.join(csrc, "hnsw_hop_loop.inc")).read()
+    blocks = inc.split("asm volatile(")[1:]
+    assert len(blocks) == 4                                   # W in 2 / 4 / 8 / 1 registers
+    for b in blocks:
+        body = b.split("    w.wmax = wmax;")[0]
+        assert body.count('"s_mov_b32 %[sm0], m0\\n\\t"') == 1 and body.count('s_mov_b32 m0, %[sm0]') == 1
+        assert body.index("s_mov_b32 %[sm0], m0") < body.index("v_alignbit_b32") < body.rindex("s_mov_b32 m0, %[sm0]")
+        assert '[sm0] "=&s"(sm0)' in body
+    for f in os.listdir(csrc):
+        txt = open(os.path.join(csrc, f)).read()
+        for clob in re.findall(r'\n\s*: ((?:"[a-z0-9]+",? ?)+)(?:HNSW_[A-Z0-9_]+ ?)*\);', txt):
+            assert '"m0"' not in clob, (f, clob)
