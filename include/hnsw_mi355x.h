@@ -418,7 +418,9 @@ int32_t hnsw_index_export_upper(const hnsw_index *idx, int32_t layer, int64_t *n
 int32_t hnsw_index_locality_codes(hnsw_index *idx, int32_t *out);
 /* Which visited structure the knn kernel of this handle uses for searches with this ef and accept rule (params->semantics):
  * *log2_slots = 0: the tag cache; else the bitmap-block directory has 2^*log2_slots slots (256 codes each).  With the option
- * "visited_blocks" at -1 the first call for a kernel shape makes the measurement described there (as the first search would). */
+ * "visited_blocks" at -1 the first call for a kernel shape makes the measurement described there (as the first search would):
+ * a program that must not meet a device synchronisation inside its first search (a latency-critical path, a stream capture)
+ * calls this once per ef at set-up. */
 int32_t hnsw_index_visited_blocks(hnsw_index *idx, const hnsw_search_params *params, int32_t *log2_slots);
 
 /* Per-layer degree statistics: Hgraph.Stats.compute (lib/hnsw.ml:353-375; printed by
