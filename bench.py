@@ -432,8 +432,8 @@ def main():
     lib_times = {}
     step_stats = {}
     last_host_batch = [0]
-    # ---- the very first call after the index upload (nothing of this index in any cache -- and every one-time cost of a first
-    #      call in it: the handle's stream, its page-locked flag word, its scratch, the kernels' code objects), then calls with the
+    # ---- the very first call after the index upload (nothing of this index in any cache; its scratch buffers allocated in it --
+    #      the kernels' code objects, the handle's stream and flag word are paid at index construction), then calls with the
     #      caches flushed in front (2 GiB written) on batches the device has never seen: what ONE call of the reference's benchmark
     #      (benchmark/benchmark.ml:89-96) pays when it is not the twentieth of its kind ----
     cold = None
@@ -459,8 +459,9 @@ def main():
         cts.sort()
         cold = {"first_call_ms": round(first_ms, 4), "cold_cache_call_ms": round(cts[1], 4), "cold_cache_call_ms_min": round(cts[0], 4),
                 "cold_cache_call_ms_max": round(cts[2], 4),
-                "what": "first_call_ms: the first search call after the index upload, one-time costs of the handle included (stream, scratch, "
-                        "code objects); cold_cache_call_ms: median of 3 later calls of the headline protocol, each on a batch never searched "
+                "what": "first_call_ms: the first search call after the index upload (its scratch buffers are allocated in it; the code objects of "
+                        "the kernels, the handle's stream and flag word are paid at index construction since round 5: warm_up in hnsw_capi.hip -- "
+                        "7 ms before); cold_cache_call_ms: median of 3 later calls of the headline protocol, each on a batch never searched "
                         "before and behind a 2 GiB write that empties L2 and the Infinity Cache"}
         log("first call after the index upload %.3f ms; calls on unseen batches behind a cache flush %.3f ms (median of 3)" % (first_ms, cts[1]))
     # the K timed steps of `value`, with the library's kernel events in them (roofline.kernel_ms is measured over THIS region;
@@ -561,7 +562,11 @@ def main():
     checks = {}
     strong = None
     if multi:   # the gathered table holds every rank's [ids | distances] block at its place
-        last = (args.steps - 1) & 1
+        # (one more step, untimed, on batch 0 -- the timed steps rotate their batches, and the checks below search batch 0)
+        last = 0
+        search(ef, slot=last, j=0)
+        gather(last).wait()
+        torch.cuda.synchronize()
         blocks = all_res[last].view(world, 2 * nres)
         checks["gathered_shard_matches"] = bool(torch.equal(blocks[rank].to(dev), res[last]))
         checks["gathered_all_shards_nonempty"] = bool((blocks[:, :nres] >= 0).any(dim=1).all())

@@ -305,6 +305,7 @@ done:
     if (st) (void)hipStreamDestroy(st);
     if (!rc) rc = make_byte_rows(idx);      // the finished index serves searches from the byte copy where the data allows
     if (!rc) rc = make_split_rows(idx);     // ... or from split rows where a row ends just past a 128-byte line
+    if (!rc) rc = warm_up(idx);             // ... and its first search call does not pay for the process's code loading
     if (rc) { hnsw_index_destroy(idx); return rc; }
     *out = idx;
     return HNSW_OK;

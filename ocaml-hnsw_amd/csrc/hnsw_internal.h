@@ -129,6 +129,9 @@ int make_split_rows(::hnsw_index *idx);
 // to_layer (lib/ohnsw.ml:865-867 stopped there); d_scratch: 4 * nq words
 int descent_entries(::hnsw_index *idx, const float *d_queries, int64_t nq, int64_t q_stride, int32_t to_layer, int32_t *d_entry,
                     uint32_t *d_scratch, hipStream_t st);
+// hnsw_capi.hip: the one-time costs of a process's first search (code objects, the handle's stream and flag word), paid at
+// index construction: one query through the plain and the ordered launch
+int warm_up(::hnsw_index *idx);
 // hnsw_layer_ops.hip: Ohnsw.search_k on one layer for device-resident targets (one start node each, W bounded by ef): the
 // nearest node found per target
 int layer_nearest_device(::hnsw_index *idx, int32_t layer, const float *d_targets, int64_t t_stride, int64_t nq, const int32_t *d_qmap,
