@@ -529,6 +529,7 @@ int32_t hnsw_index_destroy(hnsw_index *idx) {
     for (hipEvent_t e : idx->tev) (void)hipEventDestroy(e);
     for (auto &o : idx->order_scratch) if (o.p) (void)hipFree(o.p);
     if (idx->hFlag) (void)hipHostFree(idx->hFlag);
+    if (idx->hSmall) (void)hipHostFree(idx->hSmall);
     delete idx;
     return HNSW_OK;
 }
@@ -780,6 +781,29 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
     uint32_t *znd = out_ndist ? (uint32_t *)mapped(out_ndist, (size_t)nq * 4) : nullptr;
     uint32_t *znh = out_nhops ? (uint32_t *)mapped(out_nhops, (size_t)nq * 4) : nullptr;
     if (!zi || !zd) zi = nullptr, zd = nullptr;                      // results: both matrices or neither
+    // A SMALL batch from ordinary memory (a single query: Ohnsw.knn, test/test.ml:122) goes through a page-locked block of the
+    // handle's own instead of three staged copies: the queries are copied into it by the host, the device reads them and writes
+    // the results there, the host copies them out -- what is left of the call is one launch and one synchronisation.
+    constexpr size_t SMALL = 32768;
+    const size_t rbytes = (size_t)nq * k * 4;
+    const bool small = !zq && !zi && !znd && !znh && qbytes <= SMALL && rbytes <= SMALL && (size_t)nq * 4 <= SMALL && env_int("HNSW_SMALL_CALLS", 1);
+    if (small) {
+        if (!idx->hSmall) {
+            HIP_TRY(hipHostMalloc((void **)&idx->hSmall, 5 * SMALL, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void **)&idx->hSmallDev, idx->hSmall, 0));
+        }
+        memcpy(idx->hSmall, queries, qbytes);
+        zq = (const float *)idx->hSmallDev;
+        zi = (int32_t *)(idx->hSmallDev + SMALL); zd = (float *)(idx->hSmallDev + 2 * SMALL);
+        if (out_ndist) znd = (uint32_t *)(idx->hSmallDev + 3 * SMALL);
+        if (out_nhops) znh = (uint32_t *)(idx->hSmallDev + 4 * SMALL);
+    }
+    auto small_out = [&]() {
+        if (!small) return;
+        memcpy(out_ids, idx->hSmall + SMALL, rbytes); memcpy(out_dist, idx->hSmall + 2 * SMALL, rbytes);
+        if (out_ndist) memcpy(out_ndist, idx->hSmall + 3 * SMALL, (size_t)nq * 4);
+        if (out_nhops) memcpy(out_nhops, idx->hSmall + 4 * SMALL, (size_t)nq * 4);
+    };
     const float *dQ = zq ? zq : (const float *)idx->sQ.p;            // where the queries can be read from the device
     int32_t *dI = zi ? zi : (int32_t *)idx->sIds.p;
     float *dD = zi ? zd : (float *)idx->sDist.p;
@@ -804,7 +828,7 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
         if (rc) return rc;
         if (es != hipSuccess) return fail(HNSW_ERR_HIP, "search failed: %s", hipGetErrorString(es));
     }
-    if (!(*(volatile uint32_t *)idx->hFlag & 1u)) return HNSW_OK;      // written by the kernel (pinned host memory)
+    if (!(*(volatile uint32_t *)idx->hFlag & 1u)) { small_out(); return HNSW_OK; }      // (the flag: written by the kernel, pinned host memory)
     // Exactness fallback for queries whose tie-overflow stack outgrew its LDS slots (rare: the rows
     // of the whole batch are then copied out again)
     int64_t n_rerun = 0;
@@ -820,6 +844,7 @@ int32_t hnsw_search_batch(hnsw_index *idx, const float *queries, int64_t nq, int
         if (rc) return rc;
         if (es != hipSuccess) return fail(HNSW_ERR_HIP, "result download failed: %s", hipGetErrorString(es));
     }
+    small_out();
     return HNSW_OK;
 }
 

@@ -91,6 +91,7 @@ struct hnsw_index {
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt, sFlag; // scratch for the host-buffer entry points (sFlag: the launch's "any query flagged" word)
     uint32_t *hFlag = nullptr, *hFlagDev = nullptr;          // the same word in pinned host memory (zero-copy calls) and its device address
+    char *hSmall = nullptr, *hSmallDev = nullptr;            // page-locked block for small host-buffer calls (hnsw_search_batch: queries, ids, distances, counters)
     // option "device_fallback_slab_bytes": a slab of the caller's chosen size for the exactness fallback of
     // hnsw_search_batch_device, run on the caller's stream without a host round trip (dFbMap: the flagged queries' list)
     hnsw_host::DevBuf dFbSlab, dFbMap;
