@@ -877,10 +877,16 @@ def main():
                         hg2.set_option("byte_rows", 0)
                         w3fh = timed2_host(ef2, steps2)
                         w3f, sm3f, pm3f = timed2(ef2, steps2)
+                        blk3f = hg2.visited_blocks(ef2)      # float32 rows, W in four registers: the handle may take the bitmap blocks here
+                        search2(ef2, counters=True)
+                        torch.cuda.synchronize()
+                        nd3f = float(nd_d.float().mean().item())
                         hg2.set_option("byte_rows", 1)
                         kms3f = sm3f if (l03 or pm3f <= 0) else sm3f + pm3f
                         gate["float32_rows"] = {"value": round(nq / w3fh, 1), "unit": "queries/s", "ms_per_step": round(1e3 * w3fh, 4),
-                                                "device_resident_value": round(nq / w3f, 1), "kernel": search_kernel_name(d, ef2, 0, 0, -1),
+                                                "device_resident_value": round(nq / w3f, 1), "kernel": search_kernel_name(d, ef2, 0, 0, -1, blk3f),
+                                                "visited": ("bitmap blocks, 2^%d slots" % blk3f) if blk3f else "tag cache",
+                                                "gpu_evaluations_per_query": round(nd3f, 1),
                                                 "kernel_ms": round(kms3f, 4), "bytes_per_query": round(bq3_of(4 * d), 1),
                                                 "frac": round(bq3_of(4 * d) * nq / (kms3f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}
                     secondary["at_recall_0.95"] = gate
