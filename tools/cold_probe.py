@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Where does a process's FIRST search go?  (GPU box)  Times, after an index build, the first 1-query device call (the search
+kernels' code object), the first ordered call (the ordering pre-pass's), the first 10 k device call (its scratch) and the first
+host-buffer call (the handle's stream, flag word, scratch).  With HNSW_WARM_UP=0 (round 4's behaviour): 1.4 + 5.2 + 0.4 + 0.9 ms;
+by default index construction has paid the first two and the handle's state already (warm_up, hnsw_capi.hip).
+    python tools/cold_probe.py [steps|host]"""
 import sys, time, os
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
