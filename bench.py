@@ -1014,6 +1014,26 @@ def main():
             hgo.set_option("time_kernels", 0)
             ts_.sort()
             med_ = ts_[len(ts_) // 2]
+            # where the handle chose the bitmap blocks: the same index, batch and steps with the tag cache (round 4's structure), for the record
+            tags_ = None
+            if hgo.visited_blocks(ef_):
+                hgo.set_option("visited_blocks", 0)
+                go(True)
+                torch.cuda.synchronize()
+                same_ = bool(np.array_equal(io.cpu().numpy(), gi) and np.array_equal(do.cpu().numpy().view(np.uint32), gd.view(np.uint32)))
+                ndt_ = float(ndo.float().mean().item())
+                tt_ = []
+                for _ in range(3):
+                    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a_.record(stream); go(); b_.record(stream); torch.cuda.synchronize()
+                    tt_.append(a_.elapsed_time(b_))
+                tt_.sort()
+                tags_ = {"ms_per_step": round(tt_[1], 4), "value": round(nq / (tt_[1] * 1e-3), 1), "gpu_evaluations_per_query": round(ndt_, 1),
+                         "gpu_evaluations_per_query_with_blocks": round(nd_, 1), "same_ids_and_distance_bits": same_,
+                         "what": "option visited_blocks = 0 on the same index: the tag cache of rounds 1-4"}
+                hgo.set_option("visited_blocks", -1)
+                go(True)                                   # (the counters below are the default structure's)
+                torch.cuda.synchronize()
             ck = {"tie_overflow_flagged": int((sto & 1).sum().item())}
             nrec_ = min(300, nq)
             ck["recall_at_k"] = round(recall_ids(gi[:nrec_], exact_topk(Xo, Qod[:nrec_], k_, metric_)), 4)      # id-set recall@k, exact ground truth
@@ -1061,6 +1081,8 @@ def main():
                                             else "tag cache (the handle's own measurement where the shape has a choice: option visited_blocks -1)",
                                  "index_bytes": int(hgo.info().device_bytes) if hasattr(hgo, "info") else None},
                     "checks": ck}
+            if tags_:
+                res_["with_the_tag_cache"] = tags_
             log("%s: %.0f q/s, %.3f ms/step (kernel %.3f ms), %.0f evaluations/query, frac %.3f, parity %s (%.0fs)" %
                 (tag, nq / (med_ * 1e-3), med_, kms_, nd_, ach_ / HBM_PEAK_GBS, ck.get("parity_ids_equal"), time.time() - t0_))
             hgo.release()
