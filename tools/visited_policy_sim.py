@@ -163,8 +163,8 @@ class HW:
     """what the kernel would do: `sets` sets x `ways` ways of (block tag, 8-bit stamp) + one bitmap of 2^bs codes per way; the 64 lanes
     of a hop look up the state the hop started with, a lane that misses claims the set's least recently touched way
     (stamp = hop >> 1, ages modulo 256), the last writer of a way owns it, owners clear the bitmap, then bits are set"""
-    def __init__(self, L, bs, sets, ways, shift=1):
-        self.L, self.bs, self.ns, self.ways, self.shift = L, bs, sets, ways, shift
+    def __init__(self, L, bs, sets, ways, shift=1, alt=False):
+        self.L, self.bs, self.ns, self.ways, self.shift, self.alt = L, bs, sets, ways, shift, alt
         self.tag = [[-1] * ways for _ in range(sets)]
         self.stamp = [[0] * ways for _ in range(sets)]
         self.bits = [[set() for _ in range(ways)] for _ in range(sets)]
@@ -185,6 +185,9 @@ class HW:
             if w < 0:
                 ages = [((now - st) & 255) if t >= 0 else 1000 for t, st in zip(self.tag[s_], self.stamp[s_])]
                 w2 = ages.index(max(ages))
+                if self.alt and (b >> 5) & 1:            # every other block claims the SECOND oldest way: two new blocks of one set in one hop both get a slot
+                    a2 = list(ages); a2[w2] = -1
+                    w2 = a2.index(max(a2))
             else:
                 w2 = w
             lanes.append((b, bit, s_, w, w2, vis))
@@ -379,6 +382,7 @@ if os.environ.get("BLOCKS", "1") != "0":
             for bs, sets, ways in ((8, 16, 16), (8, 32, 8), (7, 25, 16), (7, 32, 16), (8, 8, 16), (8, 8, 32), (7, 16, 16), (8, 8, 8), (8, 16, 8), (7, 16, 8), (6, 32, 8)):
                 names.append(("hw%d-" % sets + lname, bs, ways))
             names.append(("hx32-" + lname, 8, 8))        # 32 sets x 8 ways with a stamp per FOUR hops (1024 hops before it wraps)
+            names.append(("hy32-" + lname, 8, 8))        # 32 sets x 8 ways, every other block claims the second oldest way
 tot = {nm: 0 for nm in names}
 exact = 0
 enc = 0
@@ -404,12 +408,13 @@ for qi in range(NQ):
                    Blocks(LCODES[kind[4:]], sb, ways) if kind.startswith("blk-") else
                    BlocksDM(LCODES[kind.split("-")[1]], sb, ways, int(kind.split("-")[0][2:]), kind[1] == "l") if kind[0] == "d" else
                    HW(LCODES[kind.split("-")[1]], sb, int(kind.split("-")[0][2:]), ways) if kind.startswith("hw") else
-                   HW(LCODES[kind.split("-")[1]], sb, 32, ways, shift=2) if kind.startswith("hx") else Opt(ways << sb, nxt))
+                   HW(LCODES[kind.split("-")[1]], sb, 32, ways, shift=2) if kind.startswith("hx") else
+                   HW(LCODES[kind.split("-")[1]], sb, 32, ways, alt=True) if kind.startswith("hy") else Opt(ways << sb, nxt))
     for e in tr:
         for p in pol.values():
             p.see(*e)
     for nm in names:
-        if nm[0].startswith("hw") or nm[0].startswith("hx"):
+        if nm[0][:2] in ("hw", "hx", "hy"):
             pol[nm].flush()
         tot[nm] += pol[nm].evals
     exact += sum(1 for e in tr if e[1])
@@ -434,7 +439,7 @@ for i in range(40):
     if all_hist[i]:
         print("  rank %2dk: %7.0f %7.0f %7.0f" % (i, rank_hist[i] / NQ, again_hist[i] / NQ, all_hist[i] / NQ))
 for nm in names:
-    if nm[0].startswith("hw") or nm[0].startswith("hx"):
+    if nm[0][:2] in ("hw", "hx", "hy"):
         sets = int(nm[0].split("-")[0][2:])
         print("%-10s %d sets x %d ways, blocks of 2^%d codes (%d B): %.0f evaluations per query (+%.1f %%)" % (nm[0], sets, nm[2], nm[1], sets * nm[2] * ((1 << nm[1]) // 8 + 4), tot[nm] / NQ, 100.0 * (tot[nm] / max(exact, 1) - 1)))
         continue
