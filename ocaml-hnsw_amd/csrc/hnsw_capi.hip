@@ -185,13 +185,13 @@ int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
     const int mode = idx->blk_mode >= 0 ? idx->blk_mode : env_int("HNSW_VISITED_BLOCKS", -1);
     if (mode == 0 || nslot < 4 || idx->lcode_state < 0) return 0;
     if (mode < 0 && idx->iv.n < env_int("HNSW_VISITED_BLOCKS_MIN_N", 200000)) return 0;
-    // Left to itself the handle only considers the FLOAT32 shapes whose hand-scheduled loop has the block filter (rows of 65..128
+    // Left to itself the handle only considers the FLOAT32 shapes whose hand-scheduled loop has the block filter (rows of 65..256
     // dimensions -- full, ragged or split --, W in four or eight registers: C3's and C5's kernels): those kernels are bound by
     // row requests, so fewer evaluations are less time.  The byte-row loops have the filter too (an explicit "visited_blocks" 1
     // runs it, and the C++ loop of every other shape), but a byte-row kernel is bound by the LATENCY of a hop, and the filter's
     // four dependent LDS round trips and ~90 vector instructions cost a hop more than the evaluations it saves: the harder
     // SIFT-like set at ef 192, 8 % fewer evaluations, 0.98 -> 1.10 ms per 10 k batch (profiles/r05_ab_bytes_blocks.txt).
-    if (mode < 0 && !(variant_full(idx) != 2 && pick_nch(idx->iv.nchunks) == 2 && idx->iv.nchunks > 16 && nslot <= 8)) return 0;
+    if (mode < 0 && !(variant_full(idx) != 2 && idx->iv.nchunks > 16 && idx->iv.nchunks <= 64 && nslot <= 8)) return 0;
     int &choice = idx->blk_choice[ls][semf];
     if (choice >= 0) return choice;
     // the largest directory that keeps the variant's waves per CU

@@ -1167,17 +1167,21 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
                                (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT));                            // float32 rows of 129..256 dimensions
     constexpr bool ASM_F32 = (HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT))) || ASM_F32N4;
     constexpr bool ASM_BLKF = BLK != 0 && ASM_F32 && !ASM_F32N4 && NSLOT >= 4 && NSLOT <= 8;        // float32 rows of 65..128 dimensions
+    constexpr bool ASM_BLKF4 = BLK != 0 && ASM_F32N4 && NSLOT >= 4 && NSLOT <= 8;                   // ... of 129..256 dimensions
     constexpr bool ASM_BLKB = BLK != 0 && ASM_B8 && !ASM_B8N4 && NSLOT >= 4 && NSLOT <= 8;          // byte rows of 65..128 dimensions
-    constexpr bool ASM_BLK = ASM_BLKF || ASM_BLKB;
+    constexpr bool ASM_BLK = ASM_BLKF || ASM_BLKF4 || ASM_BLKB;
     bool asm_ok = false;
     if constexpr (ASM_B8 || ASM_F32) {
         asm_ok = layer == 0 && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30) &&
                  (ASM_B8 ? cx.qint != 0 : iv.nchunks > (ASM_F32N4 ? 32 : 16));
-        // Visited as bitmap blocks: the loops over rows of 65..128 dimensions (float32 or bytes) with W in four / eight registers have it
+        // Visited as bitmap blocks: the loops over float32 rows of 65..256 dimensions and byte rows of 65..128 with W in four / eight registers have it
         if constexpr (BLK != 0) asm_ok = asm_ok && ASM_BLK;
     }
     if constexpr (ASM_BLKF && SEM == 0) {
         if (asm_ok) { search_layer0_f32_blk_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status); return; }
+    }
+    if constexpr (ASM_BLKF4 && SEM == 0) {
+        if (asm_ok) { search_layer0_f32n4_blk_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status); return; }
     }
     if constexpr (ASM_BLKB && SEM == 0) {
         if (asm_ok) { search_layer0_bytes_blk_asm<NSLOT, METRIC>(iv, w, cx, n_dist, n_hops, status); return; }
@@ -1233,6 +1237,7 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
                 HopResume rs;
                 bool left;
                 if constexpr (ASM_BLKF) left = search_layer0_f32_blk_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
+                else if constexpr (ASM_BLKF4) left = search_layer0_f32n4_blk_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
                 else if constexpr (ASM_BLKB) left = search_layer0_bytes_blk_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
                 else if constexpr (BLK != 0) left = false;       // (asm_ok is false for the block kernels of other shapes)
                 else if constexpr (ASM_B8N4) left = search_layer0_bytes4_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);

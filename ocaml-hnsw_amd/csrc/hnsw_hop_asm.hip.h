@@ -2405,6 +2405,188 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_LOOP_SEM 1
 #include "hnsw_hop_loop.inc"
 
+// ---- float32 rows of 129..256 dimensions with Visited as bitmap blocks: W in four / eight registers
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_blk_asm4
+#define HNSW_LOOP_NSLOT 4
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 0
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 1
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 0
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_blk_asm8
+#define HNSW_LOOP_NSLOT 8
+#define HNSW_LOOP_NCH 4
+#define HNSW_LOOP_ROWS 3
+#define HNSW_LOOP_METRIC 1
+#define HNSW_LOOP_SEM 1
+#define HNSW_LOOP_BLK 1
+#include "hnsw_hop_loop.inc"
+
 // the instantiation for a kernel variant's (slots, metric, row shape)
 template <int NSLOT, int METRIC, int ROWS>
 __device__ __forceinline__ void search_layer0_f32_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[2],
@@ -2505,6 +2687,33 @@ __device__ __forceinline__ bool search_layer0_f32_sem1_asm(const IndexView &iv, 
     return false;
 }
 
+
+// ... of 129..256 dimensions
+template <int NSLOT, int METRIC, int ROWS>
+__device__ __forceinline__ void search_layer0_f32n4_blk_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[4],
+                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
+    HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_blk_asm4)   HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_blk_asm8)
+    HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_blk_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_blk_asm8)
+    HNSW_F4_CALL(4, 0, 3, search_layer0_f32n4_l2_split_blk_asm4)  HNSW_F4_CALL(8, 0, 3, search_layer0_f32n4_l2_split_blk_asm8)
+    HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_blk_asm4)   HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_blk_asm8)
+    HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_blk_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_blk_asm8)
+    HNSW_F4_CALL(4, 1, 3, search_layer0_f32n4_ip_split_blk_asm4)  HNSW_F4_CALL(8, 1, 3, search_layer0_f32n4_ip_split_blk_asm8)
+#undef HNSW_F4_CALL
+}
+template <int NSLOT, int METRIC, int ROWS>
+__device__ __forceinline__ bool search_layer0_f32n4_blk_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
+                                                                 const float4 (&qv)[4], uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
+#define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
+    HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_sem1_blk_asm4)   HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_sem1_blk_asm8)
+    HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_sem1_blk_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_sem1_blk_asm8)
+    HNSW_F4_CALL(4, 0, 3, search_layer0_f32n4_l2_split_sem1_blk_asm4)  HNSW_F4_CALL(8, 0, 3, search_layer0_f32n4_l2_split_sem1_blk_asm8)
+    HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_sem1_blk_asm4)   HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_sem1_blk_asm8)
+    HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_sem1_blk_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_sem1_blk_asm8)
+    HNSW_F4_CALL(4, 1, 3, search_layer0_f32n4_ip_split_sem1_blk_asm4)  HNSW_F4_CALL(8, 1, 3, search_layer0_f32n4_ip_split_sem1_blk_asm8)
+#undef HNSW_F4_CALL
+    return false;
+}
 
 // byte rows of 65..128 dimensions with Visited as bitmap blocks
 template <int NSLOT, int METRIC>

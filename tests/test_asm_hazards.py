@@ -96,6 +96,7 @@ def _wanted():
     want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi8ELi0ELi0ELi0ELi1EE"),
              ("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi4ELi1ELi0ELi3ELi1EE"),
              ("hnsw_search_variants_0_0_2.o", "hnsw_search_kernelILi2ELi4ELi4ELi0ELi0ELi2ELi1EE")]
+    want += [("hnsw_search_variants_0_0_1.o", "hnsw_search_kernelILi4ELi2ELi4ELi0ELi0ELi1ELi1EE")]      # ... and in a loop over rows of 129..256 dimensions
     want += [("hnsw_order.hip.o", "hnsw_descent_kernelILi2ELi8ELi0ELi2E")]
     return want
 

@@ -68,9 +68,13 @@ SMALL = [
     ("bytes_l2_4slots", 128, 0, 16, 60, 200, 10),
     ("bytes_l2_8slots", 100, 0, 12, 60, 400, 10),
     ("bytes_ip_4slots", 96, 1, 12, 60, 256, 20),
+    # float32 rows of 129..256 dimensions: the four-chunk loops' block filter
+    ("d200_ragged_8slots", 200, 0, 8, 40, 400, 10),
+    ("d256_full_ip_4slots", 256, 1, 8, 40, 200, 10),
+    ("d132_split_4slots", 132, 0, 8, 40, 160, 10),
     # other shapes: the C++ loop's block filter
     ("d32_4slots", 32, 0, 8, 40, 200, 10),
-    ("d200_8slots", 200, 0, 8, 40, 400, 10),
+    ("d300_8slots", 300, 0, 8, 40, 400, 10),
     ("ef1000_16slots", 96, 0, 8, 40, 1000, 20),
 ]
 
