@@ -32,6 +32,15 @@ __global__ void __launch_bounds__(64) row_read(const float2 *src, size_t rows, f
     dst[q * 64 + threadIdx.x] = src[q * 64 + threadIdx.x];
 }
 
+// when does each row arrive?  (the wave's clock when its 512 bytes are in registers, by block index)
+__global__ void __launch_bounds__(64) row_read_timed(const float2 *src, size_t rows, float2 *dst, long long *when) {
+    const size_t q = blockIdx.x;
+    if (q >= rows) return;
+    const float2 v = src[q * 64 + threadIdx.x];
+    dst[q * 64 + threadIdx.x] = v;
+    if (threadIdx.x == 0) when[q] = wall_clock64() + (v.x == 12345.678f ? 1 : 0);
+}
+
 template <typename F>
 static float median_ms(F &&launch, hipStream_t st, int reps = 15) {
     hipEvent_t a, b;
@@ -75,6 +84,27 @@ int main() {
         const size_t rows = bytes / 512;
         const float tr = median_ms([&] { row_read<<<(unsigned)rows, 64, 0, st>>>((const float2 *)hd, rows, (float2 *)d); }, st);
         printf("one wave per 512-byte row, copied to device memory  %8.4f ms  %6.1f GB/s\n", tr, bytes / tr * 1e-6);
+        {   // arrival order: quartiles of the block index against the time of arrival
+            long long *d_when;
+            CHECK(hipMalloc(&d_when, rows * 8));
+            int khz = 0;
+            CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0));
+            for (int rep = 0; rep < 3; ++rep) {
+                row_read_timed<<<(unsigned)rows, 64, 0, st>>>((const float2 *)hd, rows, (float2 *)d, d_when);
+                CHECK(hipStreamSynchronize(st));
+            }
+            std::vector<long long> when(rows);
+            CHECK(hipMemcpy(when.data(), d_when, rows * 8, hipMemcpyDeviceToHost));
+            const long long t0 = *std::min_element(when.begin(), when.end());
+            printf("arrival of the rows by block index (us after the first; last row of each eighth of the grid, and the latest row in it):");
+            for (int e = 0; e < 8; ++e) {
+                const size_t a = rows * e / 8, b = rows * (e + 1) / 8;
+                const long long mx = *std::max_element(when.begin() + a, when.begin() + b);
+                printf("  [%d] %.1f / %.1f", e, (when[b - 1] - t0) * 1e3 / khz, (mx - t0) * 1e3 / khz);
+            }
+            printf("\n");
+            CHECK(hipFree(d_when));
+        }
         CHECK(hipFree(d));
         CHECK(hipHostFree(h));
     }
