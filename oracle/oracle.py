@@ -14,7 +14,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# ORACLE_SANITIZE=1 (tests/test_oracle_sanitizers.py, in a child process with libasan preloaded): an AddressSanitizer +
+# UndefinedBehaviorSanitizer build of the same restatement under another name
+_SANITIZE = bool(os.environ.get("ORACLE_SANITIZE"))
+_LIB_PATH = os.path.join(_HERE, "liboracle_san.so" if _SANITIZE else "liboracle.so")
 
 SCALAR_ABS, L2, IP = 0, 1, 2
 SEQ_F32, F64, TREE16 = 0, 1, 2
@@ -30,6 +33,8 @@ def build(force=False):
         return _LIB_PATH
     cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-fPIC", "-shared", "-mavx2", "-mfma",
            "-ffp-contract=off", src, "-o", _LIB_PATH, "-lm", "-lpthread"]
+    if _SANITIZE:
+        cmd[1:2] = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
     subprocess.check_call(cmd)
     return _LIB_PATH
 
