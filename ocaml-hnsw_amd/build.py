@@ -43,6 +43,7 @@ def build(force=False, verbose=False, resource_log=None):
     # -fno-slp-vectorize: the SLP vectorizer pairs the fp32 chains of two row batches into v_pk_fma_f32,
     # which costs extra register moves and is no faster than two v_fma_f32 on this SIMD
     base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
+            "-Wall", "-Wextra", "-Wno-unused-parameter",        # the sources are clean under these: keep them so
             "-I", os.path.join(ROOT, "include")]
     if os.environ.get("HNSW_RB_NCH2"):
         base += ["-DHNSW_RB_NCH2=" + os.environ["HNSW_RB_NCH2"]]
