@@ -6,7 +6,6 @@
 plus the TEXMEX .fvecs / .ivecs files of the Makefile's download-data target (Makefile:27-28).
 Ground truth comes from an exact scan (brute_force_knn_l2, benchmark/dataset.ml:15-30).
 """
-import os
 
 import numpy as np
 

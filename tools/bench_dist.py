@@ -2,10 +2,9 @@
 """Distance micro-benchmark: the counterpart of bench_dist/bench_dist.ml (1 M calls of distance_l2 at
 d = 784, one fixed `a`, fresh `b` each call, prints checksum, s/call, calls/s) on the device:
 batched gathered distances over random rows, bytes = pairs * 4 * d."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import ctypes as C
 import numpy as np, torch
 import ocaml_hnsw_amd as H
 

@@ -5,7 +5,7 @@ a time (max_batch = 1 = Ohnsw.insert, pinned link for link against the reference
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 import ocaml_hnsw_amd as H
 import bench
 dev = torch.device("cuda", 0)

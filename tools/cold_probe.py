@@ -4,7 +4,7 @@ kernels' code object), the first ordered call (the ordering pre-pass's), the fir
 host-buffer call (the handle's stream, flag word, scratch).  With HNSW_WARM_UP=0 (round 4's behaviour): 1.4 + 5.2 + 0.4 + 0.9 ms;
 by default index construction has paid the first two and the handle's state already (warm_up, hnsw_capi.hip).
     python tools/cold_probe.py [steps|host]"""
-import sys, time, os
+import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 import ocaml_hnsw_amd as H, bench

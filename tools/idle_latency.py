@@ -3,7 +3,7 @@
 (launch + descent) at ef = 1 and the layer-0 walk growing with ef.  Run on the GPU box."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import ocaml_hnsw_amd as H
 import bench
 dev = torch.device("cuda", 0)

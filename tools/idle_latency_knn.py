@@ -10,7 +10,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
-    import numpy as np
     import torch
     import ocaml_hnsw_amd as H
     import bench

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How fast can the chip start one-wave workgroups of the search kernel?  100 k queries at ef = 1, 8, 32 on the C2
 index (short walks): the time per query is then mostly launch + prologue, i.e. the floor under a large batch."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch

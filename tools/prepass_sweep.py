@@ -3,11 +3,9 @@
 size, C2 index (run on the GPU box): is the pre-pass one pass or two?"""
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import torch
 import ocaml_hnsw_amd as H
 import bench
