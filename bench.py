@@ -137,6 +137,166 @@ def kernel_rows_of(name):
     return int(m.group(1).split(",")[5]) if m else None
 
 
+LINE_LIMIT = 4096          # bytes of the ONE stdout line (round 5's 25 KB line fell off the driver's record)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _finite(o):
+    """the same structure with every non-finite float replaced by None (strict JSON has no NaN / Infinity)"""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {str(k_): _finite(v_) for k_, v_ in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v_) for v_ in o]
+    if isinstance(o, (np.floating, np.integer, np.bool_)):
+        return _finite(o.item())
+    return o
+
+
+def _pick(src, *keys, **renamed):
+    """{key: src[key]} for the keys src has (None when src is no dict); renamed: out_key = 'src_key'"""
+    if not isinstance(src, dict):
+        return None
+    out = {k_: src[k_] for k_ in keys if k_ in src}
+    out.update({k_: src[v_] for k_, v_ in renamed.items() if v_ in src})
+    return out
+
+
+def driver_line(detail):
+    """The ONE stdout line: what the driver parses and a judge checks, numbers only, at most LINE_LIMIT bytes of strict JSON.
+    `detail` is the full result dictionary (written to DETAIL_FILE and stderr by the caller); every prose field stays there.
+    Shape follows the reference's own report -- a rate, a time per call, a recall (benchmark/benchmark.ml:95-98)."""
+    d_ = _finite(detail)
+    cfg = d_.get("config") or {}
+    roof = d_.get("roofline") or {}
+    out = {k_: d_.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                      "scaling", "vs_baseline", "dtype", "data")}
+    c_ = _pick(cfg, "workload", "n", "d", "M", "ef_construction", "ef", "k", "queries_per_gpu", "global_batch", "parallelism", "rows",
+               "batches_rotated") or {}
+    c_["workload"] = str(c_.get("workload", ""))[:300]
+    out["config"] = c_
+    r_ = _pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_query", "row_bytes",
+               "n_dist_per_query", "n_hops_per_query", "latency_floor")
+    if r_ is not None:
+        alg = (roof.get("bytes_per_query") or 0) * (cfg.get("queries_per_gpu") or 0)
+        r_["traffic_over_algorithmic"] = round(roof["traffic"] / alg, 3) if roof.get("traffic") and alg else None
+        iss = roof.get("issue") or {}
+        r_["issue"] = _pick(iss, "valu", "salu", "clock_GHz", "instructions_per_hop", "wave_occupancy")
+    out["roofline"] = r_
+    cb = d_.get("cpu_baseline")
+    if isinstance(cb, dict):
+        ac = cb.get("all_cores") or {}
+        out["cpu_baseline"] = dict(_pick(cb, "value", "unit", "cores", "kind", "value_min", "value_max"),
+                                   sample=str(cb.get("sample", ""))[:160], all_cores_value=ac.get("value"), all_cores=ac.get("cores"))
+    else:
+        out["cpu_baseline"] = None
+    out["checks"] = d_.get("checks")
+    out["recall_at_10"] = (d_.get("checks") or {}).get("recall_at_10")
+    fl, rfl = d_.get("float32_rows"), roof.get("float32_rows") or {}
+    out["float32_rows"] = None if not isinstance(fl, dict) else dict(
+        _pick(fl, "value", "ms_per_step", "device_resident_value", "frac", "kernel", "kernel_ms"), traffic=rfl.get("traffic"))
+    out["device_resident"] = _pick(d_.get("device_resident"), "value", "ms_per_step", "kernel_ms", "prepass_ms")
+    out["bandwidth_point"] = _pick(d_.get("bandwidth_point"), "value", "queries_per_gpu", "ms_per_step", "frac")
+    hg_ = d_.get("harder_set_at_recall_gate")
+    if isinstance(hg_, dict):
+        hr, hf, hc = hg_.get("roofline") or {}, hg_.get("float32_rows") or {}, hg_.get("checks") or {}
+        out["harder_set_at_recall_gate"] = dict(
+            _pick(hg_, "ef", "recall_at_10", "value", "ms_per_step", "device_resident_value"),
+            frac=hr.get("frac"), kernel=hr.get("kernel"), kernel_ms=hr.get("kernel_ms"), bytes_per_query=hr.get("bytes_per_query"),
+            n_dist_per_query=hr.get("n_dist_per_query"), traffic=hr.get("traffic"),
+            instructions_per_hop=(hr.get("issue") or {}).get("instructions_per_hop"),
+            parity=(hc.get("parity_ids_equal") and hc.get("parity_dist_bits_equal")) if hc else None,
+            float32_rows=_pick(hf, "value", "device_resident_value", "frac", "kernel_ms", "traffic"))
+    else:
+        out["harder_set_at_recall_gate"] = None
+    oth = d_.get("others")
+    if isinstance(oth, dict):
+        o2 = {}
+        for tag, v_ in oth.items():
+            if not isinstance(v_, dict):
+                continue
+            if "skipped" in v_:
+                o2[tag] = {"skipped": str(v_["skipped"])[:80]}
+                continue
+            if tag == "C1":
+                ck = v_.get("checks") or {}
+                o2[tag] = {"cpu_value": (v_.get("cpu_restatement") or {}).get("value"), "gpu_value": (v_.get("gpu_same_graph") or {}).get("value"),
+                           "recall_at_10": v_.get("recall_at_10"), "parity": ck.get("gpu_bits_equal_oracle_kernel_order")}
+                continue
+            ro, ck = v_.get("roofline") or {}, v_.get("checks") or {}
+            o2[tag] = {"value": v_.get("value"), "frac": ro.get("frac"), "kernel_ms": ro.get("kernel_ms"),
+                       "recall_at_k": ck.get("recall_at_k"),
+                       "parity": (ck.get("parity_ids_equal") and ck.get("parity_dist_bits_equal")) if "parity_ids_equal" in ck else None}
+        out["others"] = o2
+    else:
+        out["others"] = None
+    out["bench_dist"] = _pick(d_.get("bench_dist"), "d", "pairs", "ms", "calls_per_s", "gathered_TBps", "frac_of_hbm_peak")
+    out["functor_api"] = _pick(d_.get("functor_api"), "value", "ms_per_step")
+    out["cold"] = _pick(d_.get("cold"), "first_call_ms", "cold_cache_call_ms")
+    for k_ in ("one_process", "strong"):
+        out[k_] = _pick(d_.get(k_), "value", "ms_per_step", "n_gpus", "global_batch", "equals_single_device", "exchange", "scaling")
+    out["detail"] = DETAIL_FILE
+    # never above the limit: whatever a future leg adds, the optional objects go first, the contract's keys never
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    for k_ in ("cold", "functor_api", "bench_dist", "bandwidth_point", "others", "device_resident", "strong", "one_process",
+               "float32_rows", "harder_set_at_recall_gate", "checks"):
+        if len(line) < LINE_LIMIT:
+            break
+        out[k_] = None
+        out["truncated"] = True
+        line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:
+        raise ValueError("driver line is %d bytes with every optional object dropped" % len(line))
+    return line
+
+
+def counter_means(rows, want_queries, wave=64):
+    """Means of rocprofv3 --pmc rows (dicts of a *counter_collection.csv) per search-kernel INSTANCE and LAUNCH SIZE:
+    {(kernel instance, e.g. 'hnsw_search_kernel<2,4,2,0,0,2,0>', queries per launch): {counter: mean over the dispatches}}
+    for the launches of `want_queries` queries (an int or a collection of ints) only -- an index construction's warm_up
+    dispatches one query through the same instance and the handle's visited-structure measurement 256, and neither belongs
+    in the mean of the 10 000-query launches (round 5's roofline.traffic was 0.54x for exactly that).  Grid_Size = 64 x queries."""
+    import re
+    want = {int(want_queries)} if isinstance(want_queries, (int, np.integer)) else {int(w_) for w_ in want_queries}
+    acc = {}
+    for row in rows:
+        m = re.search(r"hnsw_search_kernel<([^>]*)>", (row.get("Kernel_Name") or "").replace(" ", ""))
+        if not m:
+            continue
+        try:
+            nq_ = int(row.get("Grid_Size") or row.get("Grid_Size_X") or -1) // wave
+        except ValueError:
+            continue
+        if nq_ not in want:
+            continue
+        a_ = acc.setdefault(("hnsw_search_kernel<%s>" % m.group(1), nq_), {}).setdefault(row["Counter_Name"], [0.0, 0])
+        a_[0] += float(row["Counter_Value"])
+        a_[1] += 1
+    return {key_: {c_: v_[0] / v_[1] for c_, v_ in cs.items()} for key_, cs in acc.items()}
+
+
+def self_launch(argv, gpus, extra_env=None, script=None):
+    """`python3 bench.py --gpus N` typed without a launcher: start the N ranks as FRESH child processes (this process has
+    made no GPU call yet), one per GPU, through torch.distributed.run on 127.0.0.1; relay rank 0's single stdout line and
+    return the children's exit status.  Never an exec of a process that has touched the GPU."""
+    import socket
+    import subprocess
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ, **(extra_env or {}))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    log("starting %d ranks: %s" % (gpus, " ".join(cmd)))
+    pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    out, _ = pr.communicate()
+    lines = [l_ for l_ in out.decode(errors="replace").splitlines() if l_.startswith("{")]
+    return pr.returncode, (lines[-1] if lines else None)
+
+
 def _stdout_to_stderr():
     """Everything libraries write to fd 1 while the bench runs (RCCL prints a version banner there at
     communicator creation) goes to stderr: stdout carries the ONE JSON line only."""
@@ -176,8 +336,7 @@ def main():
     ap.add_argument("--no-builder-check", action="store_true", help="skip the batched-vs-sequential builder comparison inside `secondary` (about 75 s)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic / roofline.issue are then null)")
     ap.add_argument("--pmc-child", default=None, help="(internal) load this index file and run a few steps: the process rocprofv3 wraps")
-    ap.add_argument("--pmc-hard", default=None, help="(internal) the harder set's index file for the same child")
-    ap.add_argument("--pmc-hard-ef", type=int, default=0, help="(internal) ... and the ef of its recall gate")
+    ap.add_argument("--pmc-phase", default="head", choices=("head", "hard"), help="(internal) which set's query batch the child generates")
     ap.add_argument("--no-bench-dist", action="store_true", help="skip the bench_dist counterpart (object `bench_dist`; about 8 s)")
     ap.add_argument("--no-others", action="store_true", help="skip the C3 / C5 configurations (object `others`; about 100 s)")
     ap.add_argument("--no-clustered", action="store_true", help="skip the clustered variant of C3 inside `others` (its dispatches carry C3's kernel name)")
@@ -193,20 +352,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "LOCAL_RANK" not in os.environ:
+        # typed as the driver types the N = 1 form: start the ranks ourselves, as fresh children, before any GPU call here
+        rc_, line_ = self_launch(sys.argv[1:], args.gpus)
+        _restore_stdout(saved_stdout)
+        if line_:
+            print(line_, flush=True)
+        raise SystemExit(rc_ if rc_ else (0 if line_ else 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+        raise SystemExit("bench.py --gpus %d inside a torch.distributed.run of %d ranks" % (args.gpus, world))
     import ocaml_hnsw_amd as H
     H.load()
     if H.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the search path has no CPU fallback")
     if args.pmc_child:
-        # the process a rocprofv3 --pmc pass wraps: the index file the parent saved, the parent's query batch (same
-        # seed), a few steps of the headline call and (byte_rows = 0) of the float32-row call
+        # the process a rocprofv3 --pmc pass wraps: ONE index file the parent saved (--pmc-phase head: the headline's, the
+        # parent's query batch by its seed; hard: the harder set's at the ef of its recall gate), five launches through the
+        # byte rows and five through the float32 rows.  One phase per process: the rows of a pass then belong to one index.
         torch.cuda.set_device(0)
         dev_ = torch.device("cuda", 0)
         hgc = H.Hgraph.load(args.pmc_child)
-        Qc = make_sift_like(args.nq, args.d, seed=2, device=dev_)
+        hard_ = args.pmc_phase == "hard"
+        Qc = make_sift_like(args.nq, args.d, seed=2, device=dev_, **({"n_centres": 256, "sigma": 40.0} if hard_ else {}))
         ic = torch.empty((args.nq, args.k), dtype=torch.int32, device=dev_)
         dc = torch.empty((args.nq, args.k), dtype=torch.float32, device=dev_)
         stc = torch.cuda.current_stream()
@@ -215,15 +382,6 @@ def main():
             for _ in range(5):
                 H.search_batch_device(hgc, Qc.data_ptr(), args.nq, args.d, args.ef, args.k, ic.data_ptr(), dc.data_ptr(), 0, 0, 0, stc.cuda_stream)
             torch.cuda.synchronize()
-        if args.pmc_hard:       # the harder set at the ef of its recall gate (another kernel: W in more registers)
-            hgc.release()
-            hgc = H.Hgraph.load(args.pmc_hard)
-            Qc = make_sift_like(args.nq, args.d, seed=2, device=dev_, n_centres=256, sigma=40.0)
-            for rows_ in (1, 0):
-                hgc.set_option("byte_rows", rows_)
-                for _ in range(5):
-                    H.search_batch_device(hgc, Qc.data_ptr(), args.nq, args.d, args.pmc_hard_ef, args.k, ic.data_ptr(), dc.data_ptr(), 0, 0, 0, stc.cuda_stream)
-                torch.cuda.synchronize()
         _restore_stdout(saved_stdout)
         return
     gpu = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
@@ -242,6 +400,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        # a host-side group: ranks that wait while rank 0 runs a one-process leg must not spin a kernel on their GPU
+        host_pg = dist.new_group(backend="gloo") if args.backend == "nccl" else None
 
     n, d, nq, k, ef = args.n, args.d, args.nq, args.k, args.ef
     t0 = time.time()
@@ -632,6 +792,83 @@ def main():
     # host-buffer entry point searches such queries again with a global slab.  Count them.
     flagged = int((st_d & 1).sum().item())
     checks["tie_overflow_flagged"] = flagged
+
+    # ---- what bounds a 10 k launch of the byte-row kernel: it lasts as long as its longest walk.  The hops of the longest walk
+    #      of every rotated batch (the kernel counts hops), and a launch that holds ONLY batch 0's 64 longest walks -- each wave
+    #      with a CU to itself, the descent in the pre-pass as in the timed launches: its search-kernel duration is the floor no
+    #      10 k launch containing those walks can go below, whatever the memory system sustains. ----
+    latency_floor = None
+    if world == 1 and rank == 0 and nq >= 64:
+        longest = []
+        for j in range(NB):
+            search(ef, counters=True, slot=1, j=j)
+            torch.cuda.synchronize()
+            longest.append(int(nh_d.max().item()))
+        top = torch.argsort(torch.from_numpy(gpu_nh).to(dev), descending=True)[:64]
+        Q64 = Qd[top].contiguous()
+        i64 = torch.empty((64, k), dtype=torch.int32, device=dev)
+        d64 = torch.empty((64, k), dtype=torch.float32, device=dev)
+        hg.set_option("order_queries", 1)
+        hg.set_option("time_kernels", 1)
+        for phase_ in range(2):
+            for _ in range(3 if phase_ == 0 else 20):
+                H.search_batch_device(hg, Q64.data_ptr(), 64, d, ef, k, i64.data_ptr(), d64.data_ptr(), 0, 0, 0, stream.cuda_stream)
+            torch.cuda.synchronize()
+            lone_ms, lone_pre, _ = hg.kernel_times()
+        hg.set_option("time_kernels", 0)
+        hg.set_option("order_queries", -1)
+        same64 = bool(torch.equal(i64, ids_d[top]))
+        hops64 = int(gpu_nh[top[0].item()])
+        latency_floor = {"longest_walk_hops": longest[0], "longest_walk_hops_mean_over_batches": round(float(np.mean(longest)), 1),
+                         "longest_walk_hops_max_over_batches": max(longest), "mean_hops": round(float(gpu_nh.mean()), 1),
+                         "lone_launch_ms": round(lone_ms, 4), "lone_hop_us": round(1e3 * lone_ms / max(hops64, 1), 4),
+                         "floor_ms": round(lone_ms * float(np.mean(longest)) / max(hops64, 1), 4),
+                         "lone_launch_results_equal": same64}
+        log("latency floor: longest walk %d hops (mean over batches %.1f); 64 longest walks alone %.4f ms = %.3f us per hop" %
+            (longest[0], float(np.mean(longest)), lone_ms, 1e3 * lone_ms / max(hops64, 1)))
+        del Q64, i64, d64
+
+    # ---- N > 1: the ONE-PROCESS form of C4, the one an OCaml program (a single process) can reach:
+    #      hnsw_multi_create on devices 0 .. N-1 + hnsw_multi_search_batch -- host matrices in and out, the batch split into N
+    #      contiguous shards, one RCCL all-gather inside the library (lib/ohnsw.ml:883-895 is the map being sharded).  Rank 0
+    #      runs it while the other ranks wait on the host; same global batch of N x nq queries as the weak line.  Never `value`. ----
+    one_process = None
+    if multi:
+        sync()
+        if rank == 0:
+            try:
+                ndev = torch.cuda.device_count()
+                devs = list(range(world)) if ndev >= world else [g_ % ndev for g_ in range(world)]
+                mh = H.MultiHgraph(hg, devs)
+                gq = world * nq
+                Qm = H.host_empty((gq, d), np.float32)
+                Qm[:] = Qall.cpu().numpy()
+                for _ in range(max(1, args.warmup)):
+                    mi_, md_ = mh.knn_batch_bigarray(k, Qm, ef=ef)
+                t = time.perf_counter()
+                for _ in range(args.steps):
+                    mi_, md_ = mh.knn_batch_bigarray(k, Qm, ef=ef)
+                mw = time.perf_counter() - t
+                s_i = torch.empty((gq, k), dtype=torch.int32, device=dev)
+                s_d = torch.empty((gq, k), dtype=torch.float32, device=dev)
+                H.search_batch_device(hg, Qall.data_ptr(), gq, d, ef, k, s_i.data_ptr(), s_d.data_ptr(), 0, 0, 0, stream.cuda_stream)
+                torch.cuda.synchronize()
+                cnt_ = mh.debug_counters()
+                one_process = {"value": round(gq * args.steps / mw, 1), "unit": "queries/s", "n_gpus": world, "global_batch": gq,
+                               "ms_per_step": round(1e3 * mw / args.steps, 4), "scaling": "weak", "devices": devs,
+                               "exchange": "rccl" if cnt_["peer_copies"] == 0 else "device-to-device copies (replicas share a device)",
+                               "equals_single_device": bool(np.array_equal(mi_, s_i.cpu().numpy()) and
+                                                            np.array_equal(md_.view(np.uint32), s_d.cpu().numpy().view(np.uint32))),
+                               "what": "hnsw_multi_search_batch from ONE process (rank 0; the other ranks wait on the host): host matrices in "
+                                       "and out, %d contiguous shards, per-shard search, one exchange, D2H from one device" % world}
+                log("one process, %d devices %s: %.0f q/s, %.3f ms/step, equals one device: %s" %
+                    (world, devs, one_process["value"], one_process["ms_per_step"], one_process["equals_single_device"]))
+                mh.release()
+                del s_i, s_d, Qm
+            except Exception as e:     # never lose the line to a secondary leg
+                one_process = {"skipped": "failed: %r" % (e,)}
+                log("one-process leg failed: %r" % (e,))
+        dist.barrier(group=host_pg) if host_pg is not None else dist.barrier()
     if fp32_leg is not None:
         checks["byte_rows_equal_float32_rows"] = bool(np.array_equal(fp32_leg["ids"], got) and
                                                       np.array_equal(fp32_leg["dist"].view(np.uint32), got_dist.view(np.uint32)))
@@ -1238,29 +1475,24 @@ def main():
                 groups = {"inst": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"],
                           "fetch": ["FETCH_SIZE"]}
                 env_ = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
-                for gname, counters in groups.items():
-                    outd = os.path.join(tmpd, gname)
-                    cmd = [rp, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", outd, "--", sys.executable,
-                           os.path.abspath(__file__), "--pmc-child", idx_file, "--nq", str(nq), "--d", str(d), "--ef", str(ef), "--k", str(k)]
-                    if hard_idx:
-                        cmd += ["--pmc-hard", hard_idx[0], "--pmc-hard-ef", str(hard_idx[1])]
-                    r_ = subprocess.run(cmd, cwd="/tmp", env=env_, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
-                    if r_.returncode != 0:
-                        pmc.setdefault("failed", {})[gname] = r_.stderr.decode(errors="replace")[-300:]
-                        continue
-                    for f_ in glob.glob(os.path.join(outd, "**", "*counter_collection.csv"), recursive=True):
-                        for row in csv.DictReader(open(f_)):
-                            kn = row.get("Kernel_Name", "")
-                            if "hnsw_search_kernel" not in kn:
-                                continue
-                            key_ = "bytes" if kernel_rows_of(kn) == 2 else "float32"      # the ROWS template argument, whatever d and ef are
-                            if hard_idx and kernel_nslot_of(kn) == search_nslot(hard_idx[1]) != search_nslot(ef):
-                                key_ = "hard_" + key_                                       # the harder set's launches: W in more registers
-                            a_ = pmc.setdefault(key_, {}).setdefault(row["Counter_Name"], [0.0, 0])
-                            a_[0] += float(row["Counter_Value"]); a_[1] += 1
-                for key_ in ("bytes", "float32", "hard_bytes", "hard_float32"):
-                    if key_ in pmc:
-                        pmc[key_] = {c_: v_[0] / v_[1] for c_, v_ in pmc[key_].items()}
+                phases = [("head", idx_file, ef)] + ([("hard", hard_idx[0], hard_idx[1])] if hard_idx else [])
+                for phase, file_, ef_p in phases:
+                    for gname, counters in groups.items():
+                        outd = os.path.join(tmpd, phase + "_" + gname)
+                        cmd = [rp, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", outd, "--", sys.executable,
+                               os.path.abspath(__file__), "--pmc-child", file_, "--pmc-phase", phase, "--nq", str(nq), "--d", str(d),
+                               "--ef", str(ef_p), "--k", str(k)]
+                        r_ = subprocess.run(cmd, cwd="/tmp", env=env_, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+                        if r_.returncode != 0:
+                            pmc.setdefault("failed", {})[phase + "_" + gname] = r_.stderr.decode(errors="replace")[-300:]
+                            continue
+                        rows_ = []
+                        for f_ in glob.glob(os.path.join(outd, "**", "*counter_collection.csv"), recursive=True):
+                            rows_ += list(csv.DictReader(open(f_)))
+                        # per kernel instance AND launch size: only the nq-query launches (warm_up's one-query dispatches and the
+                        # handle's 256-query visited-structure measurement run the same instances)
+                        for (kn, _nq), cs in counter_means(rows_, nq).items():
+                            pmc.setdefault(phase, {}).setdefault(kn, {}).update(cs)
             except Exception as e:
                 pmc = {"skipped": "live counter pass failed: %r" % (e,)}
             finally:
@@ -1269,9 +1501,9 @@ def main():
                     shutil.rmtree(os.path.dirname(hard_idx[0]), ignore_errors=True)
         log("live rocprofv3 counter passes: %s (%.0fs)" % ({k_: (sorted(v_) if isinstance(v_, dict) else v_) for k_, v_ in pmc.items()}, time.time() - t0))
 
-    def live_counters(rows_key, kernel_ms_):
-        """(traffic bytes per launch, issue dict) of one search-kernel variant from this run's counter passes"""
-        c_ = pmc.get(rows_key) if isinstance(pmc.get(rows_key), dict) else None
+    def live_counters(phase, kernel, kernel_ms_):
+        """(traffic bytes per launch, issue dict) of one search-kernel instance from this run's counter passes"""
+        c_ = (pmc.get(phase) or {}).get((kernel or "").replace(" ", "")) if isinstance(pmc.get(phase), dict) else None
         if not c_:
             return None, None
         traffic_ = int(2 * c_["FETCH_SIZE"] * 1024) if "FETCH_SIZE" in c_ else None     # gfx950: FETCH_SIZE (KB) counts 128-B requests at 64 B
@@ -1299,9 +1531,9 @@ def main():
 
     if secondary and isinstance(secondary.get("at_recall_0.95"), dict) and "roofline" in secondary["at_recall_0.95"]:
         g_ = secondary["at_recall_0.95"]
-        for key_, tgt in (("hard_bytes" if g_["roofline"]["row_bytes"] == d else "hard_float32", g_["roofline"]), ("hard_float32", g_.get("float32_rows"))):
+        for tgt in (g_["roofline"], g_.get("float32_rows")):
             if tgt is not None and tgt.get("traffic") is None:
-                tr_, is_ = live_counters(key_, tgt["kernel_ms"])
+                tr_, is_ = live_counters("hard", tgt.get("kernel"), tgt["kernel_ms"])
                 tgt["traffic"] = tr_
                 tgt["traffic_source"] = "live rocprofv3 FETCH_SIZE pass of this run x 2 (gfx950)" if tr_ is not None else None
                 if is_ is not None and tgt is g_["roofline"]:
@@ -1358,9 +1590,9 @@ def main():
                 checks["cpu_all_cores_ids_equal"] = bool(np.array_equal(mids, got))
                 cpu_baseline = {"value": round(nq / ref_s, 1), "unit": "queries/s", "cores": 1, "kind": "port",
                                 "passes": 3, "statistic": "median", "value_min": round(nq / ref_ts[2], 1), "value_max": round(nq / ref_ts[0], 1),
-                                "sample": "all %d queries of one batch, three passes (median %.1f s), same graph, ef=%d k=%d: single-thread C restatement of "
-                                          "Ohnsw.knn_batch_bigarray (not OCaml) with the reference's arithmetic (sequential fp32 "
-                                          "sum, sqrt in double); the reference is single-threaded" % (nq, ref_s, ef, k),
+                                "sample": "all %d queries of one batch x 3 passes (median %.1f s), 1 thread: C restatement of Ohnsw.knn_batch_bigarray, "
+                                          "reference arithmetic (not OCaml)" % (nq, ref_s),
+                                "sample_note": "same graph, ef=%d k=%d; sequential fp32 sum, sqrt in double; the reference is single-threaded" % (ef, k),
                                 "all_cores": {"value": round(nq / mt_s, 1), "cores": ncores,
                                               "sample": "all %d queries split over %d host threads" % (nq, ncores)}}
                 log("cpu restatement (reference arithmetic): %.1f q/s single-thread, %.1f q/s on %d threads" % (nq / ref_s, nq / mt_s, ncores))
@@ -1395,7 +1627,7 @@ def main():
         else:
             bq, kernel_ms, kname = bq_total, search_ms, kernel_name(byte_rows)
         achieved = bq * nq / (kernel_ms * 1e-3) / 1e9
-        traffic, issue = live_counters("bytes" if byte_rows else "float32", kernel_ms)
+        traffic, issue = live_counters("head", kernel_name(byte_rows), kernel_ms)
         traffic_src = "live rocprofv3 FETCH_SIZE pass of this run x 2 (gfx950)" if traffic is not None else None
         if traffic is None:
             traffic = traffic_of(kname, ordered)
@@ -1418,6 +1650,12 @@ def main():
                              "bytes_per_query_whole_path": round(bq_total, 1),
                              "n_dist_before_layer0_per_query": None if n_upper_mean is None else round(n_upper_mean, 1),
                              "achieved_whole_path": round(bq_total * nq / (kern_ms * 1e-3) / 1e9, 1)}}
+        if latency_floor is not None:
+            # what a reader needs beside `frac` when the launch is bound by its longest walk, not by HBM
+            latency_floor["kernel_ms"] = round(kernel_ms, 4)
+            latency_floor["kernel_over_floor"] = round(kernel_ms / latency_floor["floor_ms"], 3) if latency_floor["floor_ms"] else None
+            latency_floor["wave_occupancy"] = (issue or {}).get("wave_occupancy")
+            roofline["latency_floor"] = latency_floor
         if byte_rows:
             roofline["note"] = ("byte rows: every value of this data set is an integer in 0..255, so the knn kernel gathers d-byte rows "
                                 "(a quarter of the float32 bytes, same arithmetic, bit-identical results); the launch is then bound by "
@@ -1433,8 +1671,8 @@ def main():
                                         "kernel": kernel_name(False), "kernel_ms": round(f_ms, 4), "prepass_ms": round(fp32_leg["prepass_ms"], 4),
                                         "bytes_per_query": round(f_bq, 1), "achieved": round(f_ach, 1), "peak": HBM_PEAK_GBS, "unit_bw": "GB/s",
                                         "frac": round(f_ach / HBM_PEAK_GBS, 4),
-                                        "traffic": live_counters("float32", f_ms)[0] if live_counters("float32", f_ms)[0] is not None else traffic_of(kernel_name(False), f_ord),
-                                        "issue": live_counters("float32", f_ms)[1],
+                                        "traffic": live_counters("head", kernel_name(False), f_ms)[0] if live_counters("head", kernel_name(False), f_ms)[0] is not None else traffic_of(kernel_name(False), f_ord),
+                                        "issue": live_counters("head", kernel_name(False), f_ms)[1],
                                         "what": "option byte_rows = 0: the same index, batch and steps through the float32 rows"}
 
     if rank == 0:
@@ -1444,6 +1682,8 @@ def main():
             harder_gate = ({"ef": ef, "recall_at_10": secondary["checks"]["recall_at_10"], "value": secondary.get("value_host_protocol"),
                             "device_resident_value": secondary["value"], "unit": "queries/s"}
                            if secondary["checks"]["recall_at_10"] >= 0.95 else secondary.get("at_recall_0.95"))
+            if harder_gate is secondary.get("at_recall_0.95"):
+                secondary["at_recall_0.95"] = "see harder_set_at_recall_gate"      # embedded once
         fl = roofline.get("float32_rows") if roofline else None
         # which synthetic set is the closer stand-in for SIFT1M (about 2.5-3 k evaluations per query at ef 128)
         nd_head = roofline["n_dist_per_query"] if roofline else None
@@ -1455,13 +1695,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # the arithmetic of the timed kernel, not a precision claim: byte rows are gathered as uint8 and summed with
             # v_dot4_u32_u8 (exact: every partial sum < 2^24, the float32 result bit for bit); float data computes in f32
-            "dtype": "u8 rows, u32 dot products (exact) -> f32 distances" if byte_rows else "f32",
+            "dtype": "u8" if byte_rows else "f32",
+            "dtype_note": "u8 rows, u32 dot products (exact) -> f32 distances" if byte_rows else "f32",
             "data": ("file:" + os.path.basename(os.path.normpath(args.dataset))) if args.dataset else "synthetic",
-            "config": {"workload": "C2: %s (n=%d d=%d), M=%d efConstruction=%d "
-                                   "(graph built on the GPU), ef=%d k=%d, %d queries per GPU per step, replicated index%s; this set is the one SURVEY 8d "
-                                   "prescribes and is EASIER than SIFT1M (%s evaluations per query where SIFT1M needs about 2.5-3 k at ef 128): "
-                                   "the harder set of `secondary` (%s evaluations per query) is the closer stand-in, see `harder_set_at_recall_gate`"
-                                   % ("vectors from " + args.dataset if args.dataset else "SIFT1M-shaped synthetic, clustered ints 0..218 stored as float32",
+            "config": {"workload": "C2: %s (n=%d d=%d), M=%d efConstruction=%d (graph built on the GPU), ef=%d k=%d, %d queries per GPU per step, "
+                                   "replicated index%s; easier than SIFT1M (%s evaluations/query vs ~2.5-3k): see harder_set_at_recall_gate (%s)"
+                                   % ("vectors from " + args.dataset if args.dataset else "SIFT1M-shaped synthetic, clustered ints 0..218 as fp32",
                                       n, d, args.M, args.efc, ef, k, nq,
                                       ", RCCL all-gather of results" if world > 1 else "", nd_head, nd_hard),
                        "n": n, "d": d, "M": args.M, "ef_construction": args.efc, "ef": ef, "k": k,
@@ -1507,12 +1746,30 @@ def main():
                             "headline_set": {"ef": ef if gate_ok else checks.get("ef_for_recall_0.95"),
                                              "recall_at_10": checks.get("recall_at_10") if gate_ok else checks.get("recall_at_that_ef"),
                                              "value": round(qps, 1) if gate_ok else checks.get("qps_at_that_ef")},
-                            "harder_set": harder_gate} if rank == 0 and world == 1 else None,
-            "others": others, "bench_dist": bench_dist, "strong": strong, "pipelined": pipelined, "checks": checks,
+                            "harder_set": _pick(harder_gate, "ef", "recall_at_10", "value")} if rank == 0 and world == 1 else None,
+            "others": others, "bench_dist": bench_dist, "strong": strong, "one_process": one_process, "pipelined": pipelined, "checks": checks,
         }
+        if big and roofline:
+            # the 100 k launch against the same line: whole-path bytes per query x its rate (no kernel-only duration is taken there)
+            big["frac"] = round(roofline["step"]["bytes_per_query_whole_path"] * big["value"] / world / 1e9 / HBM_PEAK_GBS, 4)
+        # Everything measured goes to DETAIL_FILE beside this script (and to stderr); stdout carries the short driver line only
+        detail_txt = json.dumps(_finite(out), allow_nan=False)
+        for path_ in (os.path.join(ROOT, DETAIL_FILE), os.path.join(ROOT, "gpurun_out", DETAIL_FILE)):
+            try:
+                if os.path.isdir(os.path.dirname(path_)):
+                    with open(path_, "w") as f_:
+                        f_.write(detail_txt + "\n")
+            except OSError as e:
+                log("could not write %s: %r" % (path_, e))
+        print("[bench-detail] " + detail_txt, file=sys.stderr, flush=True)
+        line = driver_line(out)
+        r_ = roofline or {}
+        log("SUMMARY value %.0f q/s (%.4f ms/step, n_gpus %d); roofline frac %s (kernel %s ms, traffic %s B); cpu_baseline %s q/s; recall@10 %s; line %d bytes" %
+            (out["value"], out["ms_per_step"], world, r_.get("frac"), r_.get("kernel_ms"), r_.get("traffic"),
+             (cpu_baseline or {}).get("value"), checks.get("recall_at_10"), len(line)))
         _restore_stdout(saved_stdout)
         saved_stdout = None
-        print(json.dumps(out), flush=True)
+        print(line, flush=True)
         os.dup2(2, 1)                      # whatever teardown prints does not follow the JSON line
     if multi:
         dist.barrier()

@@ -200,7 +200,11 @@ int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info);
  *                   handle decides per kernel shape by searching 256 of the index's own vectors both ways and counting
  *                   evaluations, inside the first search call that needs the answer (which then also builds the codes: one
  *                   small layer search per node, n * (1 + max_degree0) * 4 bytes of tables, a device synchronisation --
- *                   1.2 s for 10 M nodes; indices below 200 000 nodes are not measured).  Clustered / embedding-like data:
+ *                   1.2 s for 10 M nodes; indices below 200 000 nodes are not measured).  MEMORY: the n * max_degree0 * 4 bytes of
+ *                   per-slot codes (2.56 GB for 10 M nodes at M 32; counted in hnsw_index_info.device_bytes while they exist) are kept
+ *                   only while some kernel shape of the handle uses the blocks: a measurement that chooses the tag cache frees
+ *                   them again, the n * 4 bytes of per-node codes stay (a later measurement re-makes the table in milliseconds).
+ *                   Clustered / embedding-like data:
  *                   the blocks end the repeated evaluations of forgotten nodes (DEEP10M shape, ef 512: 40 % -> 5 % of all
  *                   evaluations); structureless data: the tags win and are kept.  Results are the same bits either way.
  * and one that buys exactness for the device-pointer entry point:
@@ -345,6 +349,10 @@ int32_t hnsw_search_one_batch(hnsw_index *idx, int32_t layer, const float *targe
  * replicas on one GPU: a test arrangement); RCCL refuses that, the exchange is then device-to-device
  * copies.  The library pins nothing of the caller's: the shard uploads run at PCIe speed when the caller registered its
  * query matrix with hnsw_host_register (its lifetime, not the library's) and are staged by the runtime otherwise.
+ * ERRORS.  A search that fails before the exchange leaves nothing enqueued.  If the exchange itself is refused part-way (one
+ * device's collective not accepted inside the group) the library ABORTS the handle's communicators (ncclCommAbort) before it
+ * returns HNSW_ERR_HIP, so no device is left waiting for a peer that never joins; the result tables of that call are undefined
+ * and the next search on the handle creates new communicators.
  * (One process PER GPU, each with its own RCCL rank, is the other deployment:
  * ocaml-hnsw_amd/sharding.py and bench.py.) */
 typedef struct hnsw_multi hnsw_multi;

@@ -44,11 +44,16 @@ void range_reader_enqueued(const void *p, size_t bytes, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_ranges_mu);
     for (HostRange &r : g_ranges) {
         if (!((const char *)p >= r.p && (const char *)p + bytes <= r.p + r.bytes)) continue;
+        // Whatever goes wrong with the event, the guarantee stands: without an event behind the reader the stream is drained
+        // HERE, before the entry point returns (slow, never a page unpinned under a running kernel).
         for (InFlight &f : r.readers)
-            if (f.st == st) { (void)hipEventRecord(f.ev, st); return; }   // work on one stream is ordered: the later record covers the earlier reader
+            if (f.st == st) {      // work on one stream is ordered: the later record covers the earlier reader
+                if (hipEventRecord(f.ev, st) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); }
+                return;
+            }
         InFlight f{st, nullptr};
-        if (hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
-        if (hipEventRecord(f.ev, st) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(f.ev); return; }
+        if (hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(st); return; }
+        if (hipEventRecord(f.ev, st) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(f.ev); (void)hipStreamSynchronize(st); return; }
         r.readers.push_back(f);
         return;
     }
@@ -177,6 +182,19 @@ int launch_search_args(hnsw_index *idx, SearchArgs &a, hipStream_t st);
 // when they save at least 5 %.  The measurement (and building the codes: one descent per node per upper layer, a sort) runs
 // inside the first search call that needs the answer and synchronises the device; indices of fewer than 200 000 nodes are
 // not measured (a walk cannot visit much more than the tag cache holds).  Never changes results.
+// The per-slot code table (n * max_degree0 * 4 bytes: 2.56 GB for 10 M nodes at M 32) is only worth its memory while some kernel
+// shape of the handle runs the bitmap blocks.  After a measurement that chose the tag cache -- structureless data -- it is freed
+// again unless another shape took the blocks; the per-node codes (n * 4 bytes) stay, so a later measurement for another shape
+// re-makes the table with one fill kernel instead of the whole build.  Only called with the device idle (the measurement
+// synchronises; nothing in flight reads the table when no shape has chosen it).
+void release_unused_lcode0(hnsw_index *idx) {
+    if (!idx->dLcode0) return;
+    const int mode = idx->blk_mode >= 0 ? idx->blk_mode : env_int("HNSW_VISITED_BLOCKS", -1);
+    if (mode == 1) return;                   // the caller asked for blocks wherever they can run: keep the table
+    for (auto &c : idx->blk_choice) if (c[0] > 0 || c[1] > 0) return;
+    drop_lcode0(idx);
+}
+
 int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
     const int nslot = pick_nslot(ef);
     int ls = 0;
@@ -228,8 +246,9 @@ int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
         for (uint32_t v : nd) sum[pass] += v;
     }
     out.release();
-    if (!ok) { (void)hipGetLastError(); return choice = 0; }
+    if (!ok) { (void)hipGetLastError(); choice = 0; release_unused_lcode0(idx); return 0; }
     choice = (double)sum[1] <= 0.95 * (double)sum[0] ? bits : 0;
+    release_unused_lcode0(idx);     // the tags won and no other shape uses the blocks: the per-slot table (GBs at 10 M nodes) goes again
     if (env_int("HNSW_DEBUG_VISITED", 0))
         fprintf(stderr, "hnsw: visited set for ef %d (W in %d registers, rule %d): tag cache %.0f evaluations per sample query, 2^%d blocks %.0f -> %s\n",
                 ef, nslot, semf, (double)sum[0] / (double)nq, bits, (double)sum[1] / (double)nq, choice ? "blocks" : "tags");
@@ -366,8 +385,16 @@ int ensure_host_call_state(hnsw_index *idx) {
 // runtime loads a translation unit's code when its first kernel is launched: 1.4 ms and 5.2 ms, tools/cold_probe.py), the
 // handle's stream and flag word.  One query (node 0's vector, ef 1) through the plain and through the ordered launch; results
 // are discarded.  HNSW_WARM_UP=0 leaves them to the first call (7 ms instead of 0.6 ms for a 10 k batch).
+static int warm_up_steps(hnsw_index *idx);
 int warm_up(hnsw_index *idx) {
     if (!env_int("HNSW_WARM_UP", 1) || idx->iv.n < 1 || idx->iv.entry_point < 0) return HNSW_OK;
+    // Nothing here is needed for a valid index: a failure (a stream, 64 bytes, a dummy launch) clears the HIP error and leaves the
+    // one-time costs to the first search call, which reports its own errors.  Callers ignore the return value.
+    const int rc = warm_up_steps(idx);
+    if (rc) (void)hipGetLastError();
+    return rc;
+}
+static int warm_up_steps(hnsw_index *idx) {
     int rc = ensure_host_call_state(idx);
     if (rc) return rc;
     DevBuf out;
@@ -509,7 +536,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
     inf.row_stride_bytes = stride * 4; inf.device = device;
     { int rc8 = make_byte_rows(idx); if (rc8) return bail(rc8); }
     { int rcs = make_split_rows(idx); if (rcs) return bail(rcs); }
-    { int rcw = warm_up(idx); if (rcw) return bail(rcw); }
+    (void)warm_up(idx);      // an optimisation: whatever fails in it is left to the first search call
     *out = idx;
     return HNSW_OK;
 }
@@ -547,6 +574,8 @@ int32_t hnsw_index_locality_codes(hnsw_index *idx, int32_t *out) {
     if (rc) return rc;
     if (idx->lcode_state != 1) return fail(HNSW_ERR_UNSUPPORTED, "no locality codes: the index has no upper layer (or no room for the tables)");
     HIP_TRY(hipMemcpy(out, idx->dLcode, (size_t)idx->iv.n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());
+    release_unused_lcode0(idx);              // introspection needs the per-node codes only
     return HNSW_OK;
 }
 
@@ -567,10 +596,17 @@ int32_t hnsw_index_row_bytes(const hnsw_index *idx, int64_t *row_bytes) {
 
 int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) {
     if (!idx || !name) return fail(HNSW_ERR_BAD_ARG, "null argument");
-    if (!strcmp(name, "vt_bits")) { idx->vt_bits_override = (int)value; return HNSW_OK; }
+    // (an option that changes the kernel variant or its LDS makes the cached per-shape choices stale: the visited structure's
+    // directory size follows the variant's occupancy, the residency follows the LDS)
+    auto forget_shape_choices = [&]() {
+        for (auto &c : idx->blk_choice) c[0] = c[1] = -1;
+        idx->resident_queries = 0; idx->vt_grow_key = -1;
+    };
+    if (!strcmp(name, "vt_bits")) { idx->vt_bits_override = (int)value; forget_shape_choices(); return HNSW_OK; }
     if (!strcmp(name, "lds_pad")) { idx->lds_pad = value < 0 ? -1 : (int)std::min<int64_t>(value, 32768); return HNSW_OK; }
     if (!strcmp(name, "byte_rows")) {     // 0: search the fp32 rows even where a byte copy exists; otherwise: use it where it exists
         idx->iv.X8 = value != 0 ? (const uint8_t *)idx->dX8 : nullptr;
+        forget_shape_choices();
         return HNSW_OK;
     }
     if (!strcmp(name, "split_rows")) {    // 0: search the plain fp32 rows even where a split copy exists; -1: ... and free the copy; otherwise: use it where it exists
@@ -582,15 +618,13 @@ int32_t hnsw_index_set_option(hnsw_index *idx, const char *name, int64_t value) 
             idx->dXm = nullptr; idx->dTail0 = nullptr; idx->iv.tail0 = nullptr;
         }
         idx->iv.Xm = value > 0 ? (const float *)idx->dXm : nullptr;
-        idx->resident_queries = 0; idx->vt_grow_key = -1;
-        for (auto &c : idx->blk_choice) c[0] = c[1] = -1;
+        forget_shape_choices();
         return HNSW_OK;
     }
     if (!strcmp(name, "time_kernels")) { idx->time_kernels = value != 0; return HNSW_OK; }
     if (!strcmp(name, "visited_blocks")) {   // -1: measured per kernel shape (default); 0: the tag cache; 1: bitmap blocks wherever the codes can be built
         idx->blk_mode = value < 0 ? -1 : (value ? 1 : 0);
-        for (auto &c : idx->blk_choice) c[0] = c[1] = -1;
-        idx->resident_queries = 0;            // (the LDS per wave, hence the residency, may differ)
+        forget_shape_choices();               // (the LDS per wave, hence the residency, may differ)
         return HNSW_OK;
     }
     if (!strcmp(name, "device_fallback_slab_bytes")) {

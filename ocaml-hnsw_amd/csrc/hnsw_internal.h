@@ -137,8 +137,13 @@ int warm_up(::hnsw_index *idx);
 // nearest node found per target
 int layer_nearest_device(::hnsw_index *idx, int32_t layer, const float *d_targets, int64_t t_stride, int64_t nq, const int32_t *d_qmap,
                          int64_t n_launch, const int32_t *d_starts, int32_t ef, int32_t *d_out_ids, float *d_out_dist);
-// hnsw_locality.hip: builds idx->dLcode / dLcode0 (and iv.lcode / lcode0) once; lcode_state says how it went
+// hnsw_locality.hip: builds idx->dLcode / dLcode0 (and iv.lcode / lcode0) once; lcode_state says how it went.  The per-slot
+// table dLcode0 (n * max_degree0 * 4 bytes) exists only while a kernel shape uses the bitmap blocks or is being measured:
+// drop_lcode0 frees it, materialise_lcode0 (also reached through build_locality_codes) makes it again from dLcode.
 int build_locality_codes(::hnsw_index *idx);
+int materialise_lcode0(::hnsw_index *idx);
+void drop_lcode0(::hnsw_index *idx);
+int adopt_locality_codes(::hnsw_index *idx, const int32_t *codes);
 
 // Longest-first ordering of a large batch (hnsw_order.hip): runs the descent kernel and a radix sort
 // on `st`; on success *block points to the handle's scratch for that stream (nothing to release)

@@ -32,8 +32,17 @@ lcode0_fill_kernel(const int32_t *nbr0, const int32_t *lcode, int64_t total, int
 
 namespace hnsw_host {
 
+static int build_codes(::hnsw_index *idx);
+
 int build_locality_codes(::hnsw_index *idx) {
+    if (idx->lcode_state == 1) return materialise_lcode0(idx);      // built before (or adopted from a file): the large table may have been dropped
     if (idx->lcode_state != 0) return HNSW_OK;
+    const int rc = build_codes(idx);
+    if (rc != HNSW_OK && idx->lcode_state == 0) idx->lcode_state = -1;   // the error is reported ONCE; later searches keep the tag cache
+    return rc;
+}
+
+static int build_codes(::hnsw_index *idx) {
     const int64_t n = idx->iv.n;
     const int T = idx->iv.max_layer;
     if (n < 2 || T < 1 || idx->iv.entry_point < 0) { idx->lcode_state = -1; return HNSW_OK; }
@@ -99,22 +108,77 @@ int build_locality_codes(::hnsw_index *idx) {
     number_layer(T, nullptr);
     for (int l = T - 1; l >= lo; --l) number_layer(l, &ent[(size_t)(l + 1 - lo)]);
     number_layer(0, &ent[0]);                       // all nodes, by (number of their layer-`lo` node, id): the codes
-    void *dL = nullptr, *dL0 = nullptr;
-    const size_t total = (size_t)n * (size_t)idx->iv.S0;
-    if (hipMalloc(&dL, (size_t)n * 4) != hipSuccess || hipMalloc(&dL0, std::max<size_t>(total, 1) * 4) != hipSuccess) {
+    // the per-node table (n * 4 bytes) stays with the handle from here on; the per-slot table (n * max_degree0 * 4 bytes: the large
+    // one) is made from it by materialise_lcode0 and can be dropped and made again in milliseconds (drop_lcode0)
+    void *dL = nullptr;
+    if (hipMalloc(&dL, (size_t)n * 4) != hipSuccess) {
         (void)hipGetLastError();
-        if (dL) (void)hipFree(dL);
         idx->lcode_state = -1;                      // no room: the tag cache stays (not an error of the search)
         return HNSW_OK;
     }
-    HIP_TRY(hipMemcpy(dL, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    if (hipMemcpy(dL, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(dL);
+        idx->lcode_state = -1;                      // a failed build is not retried by every later search
+        return fail(HNSW_ERR_HIP, "upload of the locality codes failed");
+    }
+    idx->dLcode = dL;
+    idx->iv.lcode = (const int32_t *)dL;
+    idx->info.device_bytes += (int64_t)n * 4;
+    idx->lcode_state = 1;
+    return materialise_lcode0(idx);
+}
+
+// lcode0[c][j] = L[nbr0[c][j]], the table the block filter reads beside the adjacency row: n * max_degree0 * 4 bytes
+// (C5's shape: 2.56 GB), counted in hnsw_index_info.device_bytes while it exists
+int materialise_lcode0(::hnsw_index *idx) {
+    if (idx->lcode_state != 1 || idx->dLcode0) return HNSW_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    const size_t total = (size_t)idx->iv.n * (size_t)idx->iv.S0;
+    void *dL0 = nullptr;
+    if (hipMalloc(&dL0, std::max<size_t>(total, 1) * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        idx->lcode_state = -1;                      // no room for the large table: the tag cache stays
+        (void)hipFree(idx->dLcode);
+        idx->info.device_bytes -= (int64_t)idx->iv.n * 4;
+        idx->dLcode = nullptr; idx->iv.lcode = nullptr;
+        return HNSW_OK;
+    }
     hipLaunchKernelGGL(lcode0_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr,
-                       (const int32_t *)idx->dNbr0, (const int32_t *)dL, (int64_t)total, (int32_t *)dL0);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    idx->dLcode = dL; idx->dLcode0 = dL0;
-    idx->iv.lcode = (const int32_t *)dL; idx->iv.lcode0 = (const int32_t *)dL0;
-    idx->info.device_bytes += (int64_t)(n * 4 + total * 4);
+                       (const int32_t *)idx->dNbr0, (const int32_t *)idx->dLcode, (int64_t)total, (int32_t *)dL0);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(dL0);
+        idx->lcode_state = -1;
+        return fail(HNSW_ERR_HIP, "filling the per-slot locality codes failed: %s", hipGetErrorString(e));
+    }
+    idx->dLcode0 = dL0;
+    idx->iv.lcode0 = (const int32_t *)dL0;
+    idx->info.device_bytes += (int64_t)total * 4;
+    return HNSW_OK;
+}
+
+// frees the per-slot table again (no launch that reads it may be in flight: the caller has synchronised); the per-node codes stay
+void drop_lcode0(::hnsw_index *idx) {
+    if (!idx->dLcode0) return;
+    (void)hipSetDevice(idx->device);
+    (void)hipFree(idx->dLcode0);
+    idx->dLcode0 = nullptr; idx->iv.lcode0 = nullptr;
+    idx->info.device_bytes -= (int64_t)idx->iv.n * (int64_t)idx->iv.S0 * 4;
+}
+
+// the codes of a saved index (hnsw_index_load): adopted instead of built
+int adopt_locality_codes(::hnsw_index *idx, const int32_t *codes) {
+    if (idx->lcode_state != 0) return HNSW_OK;
+    const int64_t n = idx->iv.n;
+    HIP_TRY(hipSetDevice(idx->device));
+    void *dL = nullptr;
+    if (hipMalloc(&dL, (size_t)std::max<int64_t>(n, 1) * 4) != hipSuccess) { (void)hipGetLastError(); return HNSW_OK; }   // built later, if ever
+    if (hipMemcpy(dL, codes, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dL); return HNSW_OK; }
+    idx->dLcode = dL;
+    idx->iv.lcode = (const int32_t *)dL;
+    idx->info.device_bytes += n * 4;
     idx->lcode_state = 1;
     return HNSW_OK;
 }

@@ -21,6 +21,7 @@ struct RcclApi {
     void *lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -41,6 +42,7 @@ int load_rccl(RcclApi &api) {
     if (!api.field) return fail(HNSW_ERR_HIP, "RCCL symbol %s missing", sym)
     HNSW_RCCL_SYM(CommInitAll, "ncclCommInitAll");
     HNSW_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    HNSW_RCCL_SYM(CommAbort, "ncclCommAbort");
     HNSW_RCCL_SYM(AllGather, "ncclAllGather");
     HNSW_RCCL_SYM(Broadcast, "ncclBroadcast");
     HNSW_RCCL_SYM(GroupStart, "ncclGroupStart");
@@ -112,6 +114,20 @@ int ensure_comms(hnsw_multi *m) {
 
 int sync_all(hnsw_multi *m);
 
+// An exchange that was only PARTLY enqueued (one device's collective refused inside the group) must not be left standing:
+// the devices whose collectives were accepted would wait on their streams for a peer that never joins -- harmless at
+// communicator size 1, a hang of hnsw_multi_search_batch on a real node.  ncclCommAbort ends whatever those communicators
+// have in flight (their kernels leave, the streams drain); the communicators are gone afterwards and the next search on
+// the handle creates new ones (ensure_comms).  The call that hit the error returns it; its result tables are undefined.
+void abort_comms(hnsw_multi *m) {
+    for (size_t g = 0; g < m->comms.size(); ++g) {
+        if (!m->comms[g]) continue;
+        (void)hipSetDevice(m->devices[g]);
+        (void)m->rccl.CommAbort(m->comms[g]);
+    }
+    m->comms.clear();
+}
+
 // Sharded search + gather: on return every device's dIds / dDist hold the full [nq][k] result.
 int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q_stride, const hnsw_search_params *params,
                       uint32_t *out_ndist, uint32_t *out_nhops) {
@@ -156,8 +172,11 @@ int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q
             const bool equal = nq % G == 0 && only_shard < 0;
             RCCL_TRY(m, m->rccl.GroupStart());
             int err = HNSW_OK;
+            // (tests) HNSW_MULTI_FAIL_ENQUEUE=g: device g's enqueue is answered as refused, after the devices before it were accepted
+            const int fail_at = env_int("HNSW_MULTI_FAIL_ENQUEUE", -1);
             for (int g = 0; g < G && !err; ++g) {
                 if (hipSetDevice(m->devices[(size_t)g]) != hipSuccess) { err = fail(HNSW_ERR_HIP, "hipSetDevice failed"); break; }
+                if (g == fail_at) { err = fail(HNSW_ERR_HIP, "RCCL exchange failed: enqueue on device %d refused (HNSW_MULTI_FAIL_ENQUEUE)", g); break; }
                 int32_t *ids = (int32_t *)m->dIds[(size_t)g].p;
                 float *dd = (float *)m->dDist[(size_t)g].p;
                 ncclResult_t r1 = ncclSuccess;
@@ -181,8 +200,12 @@ int search_and_gather(hnsw_multi *m, const float *queries, int64_t nq, int64_t q
             // the group is ALWAYS closed: an early return between GroupStart and GroupEnd would leave this thread
             // inside an open group and every later call on these communicators would misbehave
             ncclResult_t re = m->rccl.GroupEnd();
-            if (err) return err;
-            if (re != ncclSuccess) return fail(HNSW_ERR_HIP, "ncclGroupEnd failed: %s", m->rccl.GetErrorString(re));
+            if (err || re != ncclSuccess) {
+                // part of the exchange may stand enqueued with no peer to meet: end it (see abort_comms) before anybody waits
+                const std::string msg = err ? std::string(hnsw_last_error()) : std::string("ncclGroupEnd failed: ") + m->rccl.GetErrorString(re);
+                abort_comms(m);
+                return fail(HNSW_ERR_HIP, "%s; the communicators were aborted and are re-created by the next search", msg.c_str());
+            }
         } else {
             // several replicas on one device (a test arrangement): RCCL refuses duplicate devices, and the
             // "exchange" between buffers of the same device is a device-to-device copy

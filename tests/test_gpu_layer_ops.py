@@ -301,6 +301,30 @@ def test_multi_device_call_reuses_buffers_checks_parameters_and_repairs_flagged_
     one.release()
 
 
+def test_multi_exchange_refused_part_way_aborts_instead_of_hanging(H, oracle, built, monkeypatch):
+    """An enqueue refused inside the RCCL group (hook HNSW_MULTI_FAIL_ENQUEUE = device index) must not leave the other devices'
+    collectives standing: the call returns Failure with the communicators aborted (it does not hang in its own stream
+    synchronisation), and the next search on the handle re-creates them and is exact.  Communicator size 1 here (one GPU)."""
+    X, sp, g = built
+    hg = _hgraph(H, X, g, M=6)
+    one = H.MultiHgraph(hg, [0])
+    Q = (X[:40] + 1).astype(np.float32)
+    want_i, want_d = H.Ohnsw.knn_batch_bigarray(hg, 10, Q, ef=48)
+    one.search_device(Q, 48, 10)                       # communicators exist
+    before = one.debug_counters()
+    monkeypatch.setenv("HNSW_MULTI_FAIL_ENQUEUE", "0")
+    with pytest.raises(H.Failure, match="communicators were aborted"):
+        one.search_device(Q, 48, 10)
+    monkeypatch.delenv("HNSW_MULTI_FAIL_ENQUEUE")
+    assert one.debug_counters()["allgather"] == before["allgather"]           # nothing of the refused exchange was counted
+    one.search_device(Q, 48, 10)                       # new communicators, same table
+    gi, gd = one.copy_result(0)
+    np.testing.assert_array_equal(gi, want_i)
+    np.testing.assert_array_equal(gd.view(np.uint32), want_d.view(np.uint32))
+    assert one.debug_counters()["allgather"] == before["allgather"] + 2
+    one.release()
+
+
 def test_multi_device_errors(H, oracle, built):
     X, sp, g = built
     hg = _hgraph(H, X, g, M=6)
