@@ -107,16 +107,17 @@ def search_kernel_name(d, ef, metric, semf, rows=-1, blk=0):
     nchunks = (d + 3) // 4
     per_lane = (nchunks + 15) // 16
     nch = next(c for c in (1, 2, 4, 8, 16) if per_lane <= c)
-    nslot = next(s_ for s_ in (1, 2, 4, 8, 16) if ef <= 64 * s_)
+    nslot = search_nslot(ef, nch)
     if rows < 0:
         rows = 1 if nchunks == 16 * nch else 0
     rb = {1: 8, 2: 4, 4: 4, 8: 2, 16: 1}[nch] if rows == 2 else {1: 8, 2: 4, 4: 2, 8: 1, 16: 1}[nch]
     return "hnsw_search_kernel<%d,%d,%d,%d,%d,%d,%d>" % (nch, rb, nslot, metric, semf, rows, 1 if blk else 0)
 
 
-def search_nslot(ef):
-    """key registers per lane that hold W for this ef (pick_nslot of the library)"""
-    for s_ in (1, 2, 4, 8, 16):
+def search_nslot(ef, nch=2):
+    """key registers per lane that hold W for this ef (pick_nslot_knn of the library: rows of 65..256 dimensions -- NCH 2 and 4 --
+    also have three and six)"""
+    for s_ in ((1, 2, 3, 4, 6, 8, 16) if nch in (2, 4) else (1, 2, 4, 8, 16)):
         if ef <= 64 * s_:
             return s_
     return 16
@@ -1085,7 +1086,7 @@ def main():
                             "device_resident_value": round(nq / w3, 1), "device_resident_ms_per_step": round(1e3 * w3, 4),
                             "what": "`value`: the headline's protocol (host matrices in and out) at the smallest ef of the "
                                     "ladder that reaches recall@10 >= 0.95 on this set"}
-                    # the kernel that serves this point (W in four registers from ef 129 on) against the HBM line, as the headline's
+                    # the kernel that serves this point (W in three registers for ef 129..192, four up to 256) against the HBM line, as the headline's
                     search2(ef2, counters=True)
                     torch.cuda.synchronize()
                     g_nd3 = nd_d.cpu().numpy().astype(np.int64)
@@ -1655,6 +1656,8 @@ def main():
             latency_floor["kernel_ms"] = round(kernel_ms, 4)
             latency_floor["kernel_over_floor"] = round(kernel_ms / latency_floor["floor_ms"], 3) if latency_floor["floor_ms"] else None
             latency_floor["wave_occupancy"] = (issue or {}).get("wave_occupancy")
+            if big:      # what the chip sustains per 10000 queries when every wave slot stays busy (the 100 k launch, whole step)
+                latency_floor["full_load_ms_per_batch"] = round(big["ms_per_step"] * nq / big["queries_per_gpu"], 4)
             roofline["latency_floor"] = latency_floor
         if byte_rows:
             roofline["note"] = ("byte rows: every value of this data set is an integer in 0..255, so the knn kernel gathers d-byte rows "
@@ -1710,7 +1713,7 @@ def main():
                        "headline_set": {"n_dist_per_query": nd_head, "recall_at_10": checks.get("recall_at_10"), "ef": ef},
                        "harder_set": (None if not secondary else
                                       {"n_dist_per_query": nd_hard, "recall_at_10": secondary["checks"]["recall_at_10"], "ef": ef,
-                                       "ef_at_recall_gate": (ef if secondary["checks"]["recall_at_10"] >= 0.95 else (secondary.get("at_recall_0.95") or {}).get("ef")),
+                                       "ef_at_recall_gate": (harder_gate or {}).get("ef"),
                                        "closer_to_SIFT1M": True})},
             "cold_first_call_ms": None if not cold else cold["first_call_ms"],
             "cold": cold,

@@ -13,7 +13,7 @@ SOURCES = ["hnsw_capi.hip", "hnsw_build.hip", "hnsw_layer_ops.hip", "hnsw_multi.
 # the knn kernel's variants: one object per (metric, accept rule, row shape), see hnsw_search_variants.hip
 VARIANT_SOURCE = "hnsw_search_variants.hip"
 VARIANTS = [(m, s, f) for m in (0, 1) for s in (0, 1) for f in (0, 1, 2, 3)]   # f: rows ragged fp32 / full fp32 / bytes / split fp32
-DEPS = SOURCES + [VARIANT_SOURCE, "hnsw_device.hip.h", "hnsw_hop_asm.hip.h", "hnsw_hop_loop.inc", "hnsw_hop_slots8.inc", "hnsw_build_device.hip.h", "hnsw_internal.h",
+DEPS = SOURCES + [VARIANT_SOURCE, "hnsw_device.hip.h", "hnsw_hop_asm.hip.h", "hnsw_hop_loop.inc", "hnsw_hop_slots.inc", "hnsw_hop_instances.inc", "hnsw_build_device.hip.h", "hnsw_internal.h",
         os.path.join(ROOT, "include", "hnsw_mi355x.h")]
 
 

@@ -158,7 +158,7 @@ hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t q
 int knn_vt_bits(hnsw_index *idx, int ef, int semf) {
     const int base = search_vt_bits(idx, ef);
     if (idx->vt_bits_override || env_int("HNSW_VT_BITS", 0) > 0 || !env_int("HNSW_VT_GROW", 1)) return base;
-    const int nslot = pick_nslot(ef), nch = pick_nch(idx->iv.nchunks);
+    const int nch = pick_nch(idx->iv.nchunks), nslot = pick_nslot_knn(ef, nch);
     const int vkey = ((nslot * 2 + semf) * 4 + variant_full(idx)) * 32 + base;
     if (idx->vt_grow_key == vkey) return idx->vt_grow_bits;
     const search_occupancy_fn occ = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)];
@@ -196,12 +196,10 @@ void release_unused_lcode0(hnsw_index *idx) {
 }
 
 int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
-    const int nslot = pick_nslot(ef);
-    int ls = 0;
-    while ((1 << ls) < nslot) ++ls;
-    if (ls > 4) return 0;
+    const int nslot = pick_nslot_knn(ef, pick_nch(idx->iv.nchunks));
+    const int ls = slot_class(nslot);
     const int mode = idx->blk_mode >= 0 ? idx->blk_mode : env_int("HNSW_VISITED_BLOCKS", -1);
-    if (mode == 0 || nslot < 4 || idx->lcode_state < 0) return 0;
+    if (mode == 0 || nslot < 3 || idx->lcode_state < 0) return 0;
     if (mode < 0 && idx->iv.n < env_int("HNSW_VISITED_BLOCKS_MIN_N", 200000)) return 0;
     // Left to itself the handle only considers the FLOAT32 shapes whose hand-scheduled loop has the block filter (rows of 65..256
     // dimensions -- full, ragged or split --, W in four or eight registers: C3's and C5's kernels): those kernels are bound by
@@ -262,7 +260,7 @@ size_t knn_lds_bytes(hnsw_index *idx, int ef, int semf) {
 // how many one-wave workgroups of the search kernel for this ef are resident on the device at once (no LDS padding)
 int64_t resident_queries(hnsw_index *idx, int ef, int semf) {
     // cached in the handle; the answer depends on the kernel variant's registers and LDS
-    const int nslot = pick_nslot(ef), nch = pick_nch(idx->iv.nchunks);
+    const int nch = pick_nch(idx->iv.nchunks), nslot = pick_nslot_knn(ef, nch);
     const size_t lds = knn_lds_bytes(idx, ef, semf);
     const int vkey = (nslot * 2 + semf) * 4 + variant_full(idx);
     if (idx->resident_queries && idx->resident_nslot == vkey && idx->resident_lds == lds) return idx->resident_queries;
@@ -312,7 +310,7 @@ int balanced_lds_pad(hnsw_index *idx, int64_t nq, int ef, int semf) {
     if (pad > 0) {
         int max_lds = 0;
         if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, idx->device) != hipSuccess) { (void)hipGetLastError(); max_lds = 65536; }
-        const int nslot_ = pick_nslot(ef), nch_ = pick_nch(idx->iv.nchunks);
+        const int nch_ = pick_nch(idx->iv.nchunks), nslot_ = pick_nslot_knn(ef, nch_);
         const search_occupancy_fn occ = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)];
         while (pad > 0 && (base + pad > max_lds || occ(nch_, nslot_, (size_t)(base + pad), knn_blk_bits(idx, ef, semf) > 0) < want_per_cu)) pad = pad > GRANULE ? pad - GRANULE : 0;
     }
@@ -669,7 +667,7 @@ int search_rerun_device(hnsw_index *idx, const float *d_queries, int64_t nq, int
 } // extern "C++"
 namespace {
 int launch_search_args(hnsw_index *idx, SearchArgs &a, hipStream_t st) {
-    const int nch = pick_nch(idx->iv.nchunks), nslot = pick_nslot(a.ef);
+    const int nch = pick_nch(idx->iv.nchunks), nslot = pick_nslot_knn(a.ef, nch);
     hipError_t e = k_launch[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][a.sem ? 1 : 0][variant_full(idx)](nch, nslot, idx->iv, a, st);
     if (e != hipSuccess) return fail(HNSW_ERR_HIP, "search kernel launch failed: %s", hipGetErrorString(e));
     return HNSW_OK;

@@ -1153,69 +1153,40 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
     const int lane = cx.lane;
     const bool full_rows = ROWS < 0 ? iv.nchunks == 16 * NCH : ROWS == 1;
 #if HNSW_ASM_LOOP && !defined(HNSW_PHASE_TIMING)
-    // The hand-scheduled loops (hnsw_hop_asm.hip.h), same results.  ASM_B8: d <= 128 byte rows and a byte-valued query (L2: the
-    // headline shape; inner product), ef <= 64 / 65..128 / 129..256 / 257..512; ASM_F32: float32 rows of 65..128 dimensions (17..32 chunks), full, ragged or split, either metric.
+    // The hand-scheduled loops (hnsw_hop_asm.hip.h: HopLoop<NCH, NSLOT, METRIC, ROWS, SEM, BLK>, one instantiation per shape from the
+    // generated table hnsw_hop_instances.inc), same results.  Shapes: byte rows and a byte-valued query, or float32 rows (full,
+    // ragged, split), of 65..128 (NCH 2) or 129..256 (NCH 4) dimensions; W in 1, 2, 3, 4, 6 or 8 registers; either metric, either
+    // rule; Visited as the tag cache or (W in three or more registers; not the NCH 4 byte rows) as bitmap blocks.
     // (The blocks form the byte offset (id + 1) * S0 * 4 + lane * 4 of an adjacency row in 32 bits, one row ahead of the node
     // they fetch: the row AFTER the last node's must still be below 2^32 bytes whatever S0 is; and they restore EXEC with
     // s_mov_b64 exec, -1: they are entered with all 64 lanes on -- the kernel runs one full wave per query and reaches this
     // point through wave-uniform branches only.  A query whose tie list went to the global slab keeps the C++ loop.)
-    constexpr bool ASM_NSLOT = NSLOT == 1 || NSLOT == 2 || NSLOT == 4 || (NSLOT == 8 && HNSW_ASM_LOOP_8SLOTS);
-    constexpr bool ASM_SLOTS = NCH == 2 && ASM_NSLOT;
-    constexpr bool ASM_B8N4 = HNSW_ASM_LOOP_BYTES4 && NCH == 4 && ASM_NSLOT && ROWS == 2;      // byte rows of 129..256 dimensions
-    constexpr bool ASM_B8 = (ASM_SLOTS && ROWS == 2) || ASM_B8N4;
-    constexpr bool ASM_F32N4 = HNSW_ASM_LOOP_F32 && HNSW_ASM_LOOP_F32N4 && NCH == 4 && ASM_NSLOT &&
-                               (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT));                            // float32 rows of 129..256 dimensions
-    constexpr bool ASM_F32 = (HNSW_ASM_LOOP_F32 && ASM_SLOTS && (ROWS == 0 || ROWS == 1 || (ROWS == 3 && HNSW_ASM_LOOP_SPLIT))) || ASM_F32N4;
-    constexpr bool ASM_BLKF = BLK != 0 && ASM_F32 && !ASM_F32N4 && NSLOT >= 4 && NSLOT <= 8;        // float32 rows of 65..128 dimensions
-    constexpr bool ASM_BLKF4 = BLK != 0 && ASM_F32N4 && NSLOT >= 4 && NSLOT <= 8;                   // ... of 129..256 dimensions
-    constexpr bool ASM_BLKB = BLK != 0 && ASM_B8 && !ASM_B8N4 && NSLOT >= 4 && NSLOT <= 8;          // byte rows of 65..128 dimensions
-    constexpr bool ASM_BLK = ASM_BLKF || ASM_BLKF4 || ASM_BLKB;
+    constexpr int SEMK = SEM != 0 ? 1 : 0;
+    constexpr bool ASM_ANY = HopLoop<NCH, NSLOT, METRIC, ROWS, SEMK, BLK>::available;
     bool asm_ok = false;
-    if constexpr (ASM_B8 || ASM_F32) {
+    if constexpr (ASM_ANY) {
         asm_ok = layer == 0 && cx.ovf.g == nullptr && ((uint64_t)iv.n + 1) * (uint64_t)iv.S0 < (1ull << 30) &&
-                 (ASM_B8 ? cx.qint != 0 : iv.nchunks > (ASM_F32N4 ? 32 : 16));
-        // Visited as bitmap blocks: the loops over float32 rows of 65..256 dimensions and byte rows of 65..128 with W in four / eight registers have it
-        if constexpr (BLK != 0) asm_ok = asm_ok && ASM_BLK;
+                 (ROWS == 2 ? cx.qint != 0 : iv.nchunks > (NCH == 4 ? 32 : 16));
     }
-    if constexpr (ASM_BLKF && SEM == 0) {
-        if (asm_ok) { search_layer0_f32_blk_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status); return; }
-    }
-    if constexpr (ASM_BLKF4 && SEM == 0) {
-        if (asm_ok) { search_layer0_f32n4_blk_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status); return; }
-    }
-    if constexpr (ASM_BLKB && SEM == 0) {
-        if (asm_ok) { search_layer0_bytes_blk_asm<NSLOT, METRIC>(iv, w, cx, n_dist, n_hops, status); return; }
-    }
-    if constexpr (BLK == 0 && ASM_B8N4 && SEM == 0) {
-        if (asm_ok) { search_layer0_bytes4_asm<NSLOT, METRIC>(iv, w, cx, n_dist, n_hops, status); return; }
-    }
-    if constexpr (BLK == 0 && ASM_B8 && !ASM_B8N4 && SEM == 0 && METRIC == 1) {
-        if (asm_ok) { search_layer0_bytes_ip_asm<NSLOT>(iv, w, cx, n_dist, n_hops, status); return; }
-    }
-    if constexpr (BLK == 0 && ASM_B8 && !ASM_B8N4 && SEM == 0 && METRIC == 0) {
+    if constexpr (ASM_ANY && SEM == 0) {
         if (asm_ok) {
-            if constexpr (NSLOT == 1) { search_layer0_bytes_l2_asm1(iv, w, cx, n_dist, n_hops, status); return; }
-            if constexpr (NSLOT == 4) { search_layer0_bytes_l2_asm4(iv, w, cx, n_dist, n_hops, status); return; }
-            if constexpr (NSLOT == 8) { search_layer0_bytes_l2_asm8(iv, w, cx, n_dist, n_hops, status); return; }
-            if constexpr (NSLOT == 2) {
+            HopResume rs0;
 #ifdef HNSW_ASM_DEBUG
+            if constexpr (NCH == 2 && NSLOT == 2 && METRIC == 0 && ROWS == 2 && BLK == 0) {
+                // debugging: hops to run in the block, then the C++ loop goes on from there (the high half of ef, or a build constant)
 #ifdef HNSW_ASM_DEBUG_HOPS
-            search_layer0_bytes_l2_asm(iv, w, cx, n_dist, n_hops, status, HNSW_ASM_DEBUG_HOPS);
+                HopLoop<NCH, NSLOT, METRIC, ROWS, 0, BLK>::run(iv, w, cx, rs0, qv, n_dist, n_hops, status, HNSW_ASM_DEBUG_HOPS);
 #else
-            search_layer0_bytes_l2_asm(iv, w, cx, n_dist, n_hops, status, (uint32_t)ef >> 16);   // debugging: hops to run here (high half of ef)
+                HopLoop<NCH, NSLOT, METRIC, ROWS, 0, BLK>::run(iv, w, cx, rs0, qv, n_dist, n_hops, status, (uint32_t)ef >> 16);
 #endif
-#else
-            search_layer0_bytes_l2_asm(iv, w, cx, n_dist, n_hops, status);
-            return;
-#endif
+            } else {
+                HopLoop<NCH, NSLOT, METRIC, ROWS, 0, BLK>::run(iv, w, cx, rs0, qv, n_dist, n_hops, status);
+                return;
             }
-        }
-    }
-    if constexpr (BLK == 0 && ASM_F32 && SEM == 0) {
-        if (asm_ok) {
-            if constexpr (ASM_F32N4) search_layer0_f32n4_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status);
-            else search_layer0_f32_asm<NSLOT, METRIC, ROWS>(iv, w, cx, qv, n_dist, n_hops, status);
+#else
+            HopLoop<NCH, NSLOT, METRIC, ROWS, 0, BLK>::run(iv, w, cx, rs0, qv, n_dist, n_hops, status);
             return;
+#endif
         }
     }
 #endif
@@ -1228,22 +1199,14 @@ __device__ __forceinline__ void search_layer(const IndexView &iv, const float4 (
 #endif
     for (;;) {
 #if HNSW_ASM_LOOP && HNSW_ASM_LOOP_SEM1 && !defined(HNSW_PHASE_TIMING)
-        if constexpr ((ASM_B8 || ASM_F32) && SEM != 0) {
+        if constexpr (ASM_ANY && SEM != 0) {
             // The functor rule on the same hand-scheduled loops: while the tie set is empty the two rules differ only in the
             // moments an entry would ENTER the set (a neighbour evaluated AT max(W).d with W full; an entry evicted while tied
             // with the new maximum); the loop instantiated for this rule leaves at exactly those moments, in the middle of the
             // hop, and the hop is finished here.  The hops below then run while the set is alive (it dies when max(W).d drops).
             if (asm_ok && w.ovf_cnt == 0) {
                 HopResume rs;
-                bool left;
-                if constexpr (ASM_BLKF) left = search_layer0_f32_blk_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
-                else if constexpr (ASM_BLKF4) left = search_layer0_f32n4_blk_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
-                else if constexpr (ASM_BLKB) left = search_layer0_bytes_blk_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
-                else if constexpr (BLK != 0) left = false;       // (asm_ok is false for the block kernels of other shapes)
-                else if constexpr (ASM_B8N4) left = search_layer0_bytes4_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
-                else if constexpr (ASM_B8) left = search_layer0_bytes_sem1_asm<NSLOT, METRIC>(iv, w, cx, rs, n_dist, n_hops, status);
-                else if constexpr (ASM_F32N4) left = search_layer0_f32n4_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
-                else left = search_layer0_f32_sem1_asm<NSLOT, METRIC, ROWS>(iv, w, cx, rs, qv, n_dist, n_hops, status);
+                const bool left = HopLoop<NCH, NSLOT, METRIC, ROWS, 1, BLK>::run(iv, w, cx, rs, qv, n_dist, n_hops, status);
                 if (!left) break;
                 pref_id = -1;
                 if constexpr (NSLOT > 2) {        // the loop keeps the slots' maxima in scalar registers: wlist_insert's copy is stale
@@ -1447,7 +1410,7 @@ hnsw_search_kernel(const IndexView iv, const SearchArgs a) {
 #if HNSW_VT_THREE_WAYS
     // ef > 128: the walk visits several times what the cache holds; float32 rows from ef 65 on (a re-evaluation costs four times a
     // byte row's bytes there, and the two-slot byte-row loop -- the headline -- keeps its branch-free two-way filter)
-    if constexpr (NSLOT >= 4 || (NSLOT == 2 && ROWS != 2)) visited_three_ways(cx, iv.n);
+    if constexpr (NSLOT >= 3 || (NSLOT == 2 && ROWS != 2)) visited_three_ways(cx, iv.n);
 #endif
     // Issue priority inside an ordered launch (blocks run the walks predicted longest first): the launch ends with its
     // longest walk or with the last of the late starters (the blocks that had to wait for a free slot), so those two ends

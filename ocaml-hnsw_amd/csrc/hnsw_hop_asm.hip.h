@@ -3,8 +3,9 @@
 //
 // Shapes: rows of 65..128 dimensions (NCH = 2) -- and, for byte rows and for full / ragged float32 rows, of 129..256 (NCH = 4:
 // the rounds with twice the loads and arithmetic per batch) --, ef <= 64 / 65..128 / 129..256 / 257..512 (W in one / two / four / eight key
-// registers per lane; one loop body per slot count in hnsw_hop_loop.inc, included once per shape; the eight-slot insertion is
-// generated: hnsw_hop_slots8.inc):
+// registers per lane -- and three / six for ef 129..192 / 257..384; hnsw_hop_loop.inc has one body for one register, one for two
+// and one for three and more, included once per shape by the generated table hnsw_hop_instances.inc; what depends on the slot
+// count above two is generated too: hnsw_hop_slots.inc):
 //   * byte rows and a byte-valued query (exact integer arithmetic, see hop_round), L2 -- the headline shape; its descent too --
 //     and inner product;
 //   * float32 rows, L2 and inner product: full, ragged and split rows ("The same loops over FLOAT32 rows" below);
@@ -108,6 +109,14 @@ namespace hnsw_dev {
 #ifndef HNSW_ASM_PREFETCH
 #define HNSW_ASM_PREFETCH 1
 #endif
+
+// One hand-scheduled layer-0 loop per shape: an explicit specialisation of this template (hnsw_hop_loop.inc, instantiated by the
+// generated table hnsw_hop_instances.inc) with available = true and
+//     static bool run(iv, w, cx, rs, qv, n_dist, n_hops, status [, maxhops])
+// which runs the layer-0 search to completion (false) or -- functor rule, SEM 1 -- until an entry would enter the tie set (true:
+// the hop is finished by search_layer from `rs`).  On entry W holds the start node (unexpanded) and the visited set knows it.
+// qv: the query as float4 chunks (float32 rows; byte rows read cx.qb); maxhops: debugging builds of the two-slot loop only.
+template <int NCH, int NSLOT, int METRIC, int ROWS, int SEM, int BLK> struct HopLoop { static constexpr bool available = false; };
 
 __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
@@ -869,28 +878,6 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "9:\n\t"
 
 // Runs the layer-0 search to completion.  On entry W holds the start node (unexpanded) and the visited cache knows it.
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_asm
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
 
 // =====================================================================================================================
 // The same loop for W in FOUR key registers per lane (ef 129..256) and in ONE (ef <= 64).  Shared with the two-slot
@@ -1131,57 +1118,20 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     HNSW_EVICT_TIE("150", "801b", "%[l3]", "160")                                                                                                       \
     HNSW_EVICT_TIE("154", "141b", "%[l3]", "164")
 
-// Eight slots (ef 257..512): the same structure, written by tools/gen_hop_slots.py (the generator reproduces the four-slot text
-// above instruction for instruction; a test compares them)
-#include "hnsw_hop_slots8.inc"
+// Three, six and eight slots (ef 129..192, 257..384, 385..512): the same structure, written by tools/gen_hop_slots.py (the generator
+// reproduces the four-slot text above instruction for instruction; a test compares them), together with everything else in
+// hnsw_hop_loop.inc that depends on the slot count (pop / peek chains, declarations, operand lists: HNSW_NSX_*_<N>)
+#include "hnsw_hop_slots.inc"
 #ifndef HNSW_ASM_ALIGN_PAD8
 #define HNSW_ASM_ALIGN_PAD8 6
 #endif
+#ifndef HNSW_ASM_ALIGN_PAD3
+#define HNSW_ASM_ALIGN_PAD3 6
+#endif
+#ifndef HNSW_ASM_ALIGN_PAD6
+#define HNSW_ASM_ALIGN_PAD6 6
+#endif
 
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
 
 // ---- one slot (ef <= 64): no cascade; the same steps as the two-slot loop's upper slot --------------------------------
 #define HNSW_INSERT_LOOP1                                                                                                   \
@@ -1232,134 +1182,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
     "s_branch 11b\n"                                                                                                        \
     HNSW_EVICT_TIE("15", "12b", "%[l0]", "16")
 
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
 
 // byte rows of 129..256 dimensions (NCH = 4)
-#define HNSW_LOOP_NAME search_layer0_bytes4_l2_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_l2_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_l2_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_l2_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_l2_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_l2_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_l2_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_l2_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_ip_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_ip_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_ip_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_ip_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_ip_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_ip_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_ip_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes4_ip_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
 
 // =====================================================================================================================
 // The same loops over FLOAT32 rows of 65..128 dimensions (two float4 chunks per lane of a 16-lane group): the shape data
@@ -1616,1151 +1440,16 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_F32_ROUNDS_RARE HNSW_F32_ROUND_4ROWS HNSW_F32_ROUND_16ROWS
 
 
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-// ---- byte rows of 65..128 dimensions with Visited as bitmap blocks: W in four / eight registers
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_l2_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_bytes_ip_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 2
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-// ---- the same loops with Visited as bitmap blocks (HNSW_LOOP_BLK; hnsw_search_kernel<..., BLK = 1>): W in four / eight registers
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_full_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_ragged_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_l2_split_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_full_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_ragged_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32_ip_split_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-// float32 rows of 129..256 dimensions (NCH = 4), full and ragged
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-// split float32 rows of 129..256 dimensions (NCH = 4)
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_asm1
-#define HNSW_LOOP_NSLOT 1
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_asm2
-#define HNSW_LOOP_NSLOT 2
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#include "hnsw_hop_loop.inc"
-
-// ---- float32 rows of 129..256 dimensions with Visited as bitmap blocks: W in four / eight registers
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_blk_asm4
-#define HNSW_LOOP_NSLOT 4
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_full_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_ragged_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_l2_split_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 0
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_full_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 1
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_ragged_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 0
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-#define HNSW_LOOP_NAME search_layer0_f32n4_ip_split_sem1_blk_asm8
-#define HNSW_LOOP_NSLOT 8
-#define HNSW_LOOP_NCH 4
-#define HNSW_LOOP_ROWS 3
-#define HNSW_LOOP_METRIC 1
-#define HNSW_LOOP_SEM 1
-#define HNSW_LOOP_BLK 1
-#include "hnsw_hop_loop.inc"
-
-// the instantiation for a kernel variant's (slots, metric, row shape)
-template <int NSLOT, int METRIC, int ROWS>
-__device__ __forceinline__ void search_layer0_f32_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[2],
-                                                      uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
-    HNSW_F32_CALL(1, 0, 1, search_layer0_f32_l2_full_asm1)   HNSW_F32_CALL(2, 0, 1, search_layer0_f32_l2_full_asm2)   HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_asm4) HNSW_F32_CALL(8, 0, 1, search_layer0_f32_l2_full_asm8)
-    HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_asm4) HNSW_F32_CALL(8, 0, 0, search_layer0_f32_l2_ragged_asm8)
-    HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_asm4) HNSW_F32_CALL(8, 1, 1, search_layer0_f32_ip_full_asm8)
-    HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_asm4) HNSW_F32_CALL(8, 1, 0, search_layer0_f32_ip_ragged_asm8)
-    HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_asm4) HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_asm8)
-    HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_asm4) HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_asm8)
-#undef HNSW_F32_CALL
-}
-
-// float32 rows of 129..256 dimensions (NCH = 4)
-template <int NSLOT, int METRIC, int ROWS>
-__device__ __forceinline__ void search_layer0_f32n4_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[4],
-                                                        uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
-    HNSW_F4_CALL(1, 0, 1, search_layer0_f32n4_l2_full_asm1) HNSW_F4_CALL(2, 0, 1, search_layer0_f32n4_l2_full_asm2) HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_asm4) HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_asm8)
-    HNSW_F4_CALL(1, 0, 0, search_layer0_f32n4_l2_ragged_asm1) HNSW_F4_CALL(2, 0, 0, search_layer0_f32n4_l2_ragged_asm2) HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_asm8)
-    HNSW_F4_CALL(1, 0, 3, search_layer0_f32n4_l2_split_asm1) HNSW_F4_CALL(2, 0, 3, search_layer0_f32n4_l2_split_asm2) HNSW_F4_CALL(4, 0, 3, search_layer0_f32n4_l2_split_asm4) HNSW_F4_CALL(8, 0, 3, search_layer0_f32n4_l2_split_asm8)
-    HNSW_F4_CALL(1, 1, 1, search_layer0_f32n4_ip_full_asm1) HNSW_F4_CALL(2, 1, 1, search_layer0_f32n4_ip_full_asm2) HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_asm4) HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_asm8)
-    HNSW_F4_CALL(1, 1, 0, search_layer0_f32n4_ip_ragged_asm1) HNSW_F4_CALL(2, 1, 0, search_layer0_f32n4_ip_ragged_asm2) HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_asm8)
-    HNSW_F4_CALL(1, 1, 3, search_layer0_f32n4_ip_split_asm1) HNSW_F4_CALL(2, 1, 3, search_layer0_f32n4_ip_split_asm2) HNSW_F4_CALL(4, 1, 3, search_layer0_f32n4_ip_split_asm4) HNSW_F4_CALL(8, 1, 3, search_layer0_f32n4_ip_split_asm8)
-#undef HNSW_F4_CALL
-}
-
-template <int NSLOT, int METRIC, int ROWS>
-__device__ __forceinline__ bool search_layer0_f32n4_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
-                                                             const float4 (&qv)[4], uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
-    HNSW_F4_CALL(1, 0, 1, search_layer0_f32n4_l2_full_sem1_asm1) HNSW_F4_CALL(2, 0, 1, search_layer0_f32n4_l2_full_sem1_asm2) HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_sem1_asm4) HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_sem1_asm8)
-    HNSW_F4_CALL(1, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm1) HNSW_F4_CALL(2, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm2) HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_sem1_asm8)
-    HNSW_F4_CALL(1, 0, 3, search_layer0_f32n4_l2_split_sem1_asm1) HNSW_F4_CALL(2, 0, 3, search_layer0_f32n4_l2_split_sem1_asm2) HNSW_F4_CALL(4, 0, 3, search_layer0_f32n4_l2_split_sem1_asm4) HNSW_F4_CALL(8, 0, 3, search_layer0_f32n4_l2_split_sem1_asm8)
-    HNSW_F4_CALL(1, 1, 1, search_layer0_f32n4_ip_full_sem1_asm1) HNSW_F4_CALL(2, 1, 1, search_layer0_f32n4_ip_full_sem1_asm2) HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_sem1_asm4) HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_sem1_asm8)
-    HNSW_F4_CALL(1, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm1) HNSW_F4_CALL(2, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm2) HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_sem1_asm8)
-    HNSW_F4_CALL(1, 1, 3, search_layer0_f32n4_ip_split_sem1_asm1) HNSW_F4_CALL(2, 1, 3, search_layer0_f32n4_ip_split_sem1_asm2) HNSW_F4_CALL(4, 1, 3, search_layer0_f32n4_ip_split_sem1_asm4) HNSW_F4_CALL(8, 1, 3, search_layer0_f32n4_ip_split_sem1_asm8)
-#undef HNSW_F4_CALL
-    return false;
-}
-
-// byte rows of 129..256 dimensions (NCH = 4), both metrics, both rules
-template <int NSLOT, int METRIC>
-__device__ __forceinline__ void search_layer0_bytes4_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx,
-                                                         uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_B4_CALL(NS, M, NAME) if constexpr (NSLOT == NS && METRIC == M) NAME(iv, w, cx, n_dist, n_hops, status);
-    HNSW_B4_CALL(1, 0, search_layer0_bytes4_l2_asm1) HNSW_B4_CALL(2, 0, search_layer0_bytes4_l2_asm2) HNSW_B4_CALL(4, 0, search_layer0_bytes4_l2_asm4) HNSW_B4_CALL(8, 0, search_layer0_bytes4_l2_asm8)
-    HNSW_B4_CALL(1, 1, search_layer0_bytes4_ip_asm1) HNSW_B4_CALL(2, 1, search_layer0_bytes4_ip_asm2) HNSW_B4_CALL(4, 1, search_layer0_bytes4_ip_asm4) HNSW_B4_CALL(8, 1, search_layer0_bytes4_ip_asm8)
-#undef HNSW_B4_CALL
-}
-template <int NSLOT, int METRIC>
-__device__ __forceinline__ bool search_layer0_bytes4_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
-                                                              uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_B4_CALL(NS, M, NAME) if constexpr (NSLOT == NS && METRIC == M) return NAME(iv, w, cx, rs, n_dist, n_hops, status);
-    HNSW_B4_CALL(1, 0, search_layer0_bytes4_l2_sem1_asm1) HNSW_B4_CALL(2, 0, search_layer0_bytes4_l2_sem1_asm2) HNSW_B4_CALL(4, 0, search_layer0_bytes4_l2_sem1_asm4) HNSW_B4_CALL(8, 0, search_layer0_bytes4_l2_sem1_asm8)
-    HNSW_B4_CALL(1, 1, search_layer0_bytes4_ip_sem1_asm1) HNSW_B4_CALL(2, 1, search_layer0_bytes4_ip_sem1_asm2) HNSW_B4_CALL(4, 1, search_layer0_bytes4_ip_sem1_asm4) HNSW_B4_CALL(8, 1, search_layer0_bytes4_ip_sem1_asm8)
-#undef HNSW_B4_CALL
-    return false;
-}
-
-// ... and for the functor rule: true when the loop was left in the middle of a hop (HopResume), false when the search is done
-template <int NSLOT, int METRIC>
-__device__ __forceinline__ bool search_layer0_bytes_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
-                                                             uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-    if constexpr (METRIC == 0) {
-        if constexpr (NSLOT == 1) return search_layer0_bytes_l2_sem1_asm1(iv, w, cx, rs, n_dist, n_hops, status);
-        else if constexpr (NSLOT == 2) return search_layer0_bytes_l2_sem1_asm2(iv, w, cx, rs, n_dist, n_hops, status);
-        else if constexpr (NSLOT == 4) return search_layer0_bytes_l2_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
-        else return search_layer0_bytes_l2_sem1_asm8(iv, w, cx, rs, n_dist, n_hops, status);
-    } else {
-        if constexpr (NSLOT == 1) return search_layer0_bytes_ip_sem1_asm1(iv, w, cx, rs, n_dist, n_hops, status);
-        else if constexpr (NSLOT == 2) return search_layer0_bytes_ip_sem1_asm2(iv, w, cx, rs, n_dist, n_hops, status);
-        else if constexpr (NSLOT == 4) return search_layer0_bytes_ip_sem1_asm4(iv, w, cx, rs, n_dist, n_hops, status);
-        else return search_layer0_bytes_ip_sem1_asm8(iv, w, cx, rs, n_dist, n_hops, status);
-    }
-}
-// byte rows under the inner product, Ohnsw rule (the L2 instantiations are called by name in search_layer)
-template <int NSLOT>
-__device__ __forceinline__ void search_layer0_bytes_ip_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx,
-                                                           uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-    if constexpr (NSLOT == 1) search_layer0_bytes_ip_asm1(iv, w, cx, n_dist, n_hops, status);
-    else if constexpr (NSLOT == 2) search_layer0_bytes_ip_asm2(iv, w, cx, n_dist, n_hops, status);
-    else if constexpr (NSLOT == 4) search_layer0_bytes_ip_asm4(iv, w, cx, n_dist, n_hops, status);
-    else search_layer0_bytes_ip_asm8(iv, w, cx, n_dist, n_hops, status);
-}
-template <int NSLOT, int METRIC, int ROWS>
-__device__ __forceinline__ bool search_layer0_f32_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
-                                                           const float4 (&qv)[2], uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
-    HNSW_F32_CALL(1, 0, 1, search_layer0_f32_l2_full_sem1_asm1)   HNSW_F32_CALL(2, 0, 1, search_layer0_f32_l2_full_sem1_asm2)   HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_sem1_asm4) HNSW_F32_CALL(8, 0, 1, search_layer0_f32_l2_full_sem1_asm8)
-    HNSW_F32_CALL(1, 0, 0, search_layer0_f32_l2_ragged_sem1_asm1) HNSW_F32_CALL(2, 0, 0, search_layer0_f32_l2_ragged_sem1_asm2) HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_sem1_asm4) HNSW_F32_CALL(8, 0, 0, search_layer0_f32_l2_ragged_sem1_asm8)
-    HNSW_F32_CALL(1, 1, 1, search_layer0_f32_ip_full_sem1_asm1)   HNSW_F32_CALL(2, 1, 1, search_layer0_f32_ip_full_sem1_asm2)   HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_sem1_asm4) HNSW_F32_CALL(8, 1, 1, search_layer0_f32_ip_full_sem1_asm8)
-    HNSW_F32_CALL(1, 1, 0, search_layer0_f32_ip_ragged_sem1_asm1) HNSW_F32_CALL(2, 1, 0, search_layer0_f32_ip_ragged_sem1_asm2) HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_sem1_asm4) HNSW_F32_CALL(8, 1, 0, search_layer0_f32_ip_ragged_sem1_asm8)
-    HNSW_F32_CALL(1, 0, 3, search_layer0_f32_l2_split_sem1_asm1)  HNSW_F32_CALL(2, 0, 3, search_layer0_f32_l2_split_sem1_asm2)  HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_sem1_asm4) HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_sem1_asm8)
-    HNSW_F32_CALL(1, 1, 3, search_layer0_f32_ip_split_sem1_asm1)  HNSW_F32_CALL(2, 1, 3, search_layer0_f32_ip_split_sem1_asm2)  HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_sem1_asm4) HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_sem1_asm8)
-#undef HNSW_F32_CALL
-    return false;
-}
-
-
-// ... of 129..256 dimensions
-template <int NSLOT, int METRIC, int ROWS>
-__device__ __forceinline__ void search_layer0_f32n4_blk_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[4],
-                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
-    HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_blk_asm4)   HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_blk_asm8)
-    HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_blk_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_blk_asm8)
-    HNSW_F4_CALL(4, 0, 3, search_layer0_f32n4_l2_split_blk_asm4)  HNSW_F4_CALL(8, 0, 3, search_layer0_f32n4_l2_split_blk_asm8)
-    HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_blk_asm4)   HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_blk_asm8)
-    HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_blk_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_blk_asm8)
-    HNSW_F4_CALL(4, 1, 3, search_layer0_f32n4_ip_split_blk_asm4)  HNSW_F4_CALL(8, 1, 3, search_layer0_f32n4_ip_split_blk_asm8)
-#undef HNSW_F4_CALL
-}
-template <int NSLOT, int METRIC, int ROWS>
-__device__ __forceinline__ bool search_layer0_f32n4_blk_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
-                                                                 const float4 (&qv)[4], uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_F4_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
-    HNSW_F4_CALL(4, 0, 1, search_layer0_f32n4_l2_full_sem1_blk_asm4)   HNSW_F4_CALL(8, 0, 1, search_layer0_f32n4_l2_full_sem1_blk_asm8)
-    HNSW_F4_CALL(4, 0, 0, search_layer0_f32n4_l2_ragged_sem1_blk_asm4) HNSW_F4_CALL(8, 0, 0, search_layer0_f32n4_l2_ragged_sem1_blk_asm8)
-    HNSW_F4_CALL(4, 0, 3, search_layer0_f32n4_l2_split_sem1_blk_asm4)  HNSW_F4_CALL(8, 0, 3, search_layer0_f32n4_l2_split_sem1_blk_asm8)
-    HNSW_F4_CALL(4, 1, 1, search_layer0_f32n4_ip_full_sem1_blk_asm4)   HNSW_F4_CALL(8, 1, 1, search_layer0_f32n4_ip_full_sem1_blk_asm8)
-    HNSW_F4_CALL(4, 1, 0, search_layer0_f32n4_ip_ragged_sem1_blk_asm4) HNSW_F4_CALL(8, 1, 0, search_layer0_f32n4_ip_ragged_sem1_blk_asm8)
-    HNSW_F4_CALL(4, 1, 3, search_layer0_f32n4_ip_split_sem1_blk_asm4)  HNSW_F4_CALL(8, 1, 3, search_layer0_f32n4_ip_split_sem1_blk_asm8)
-#undef HNSW_F4_CALL
-    return false;
-}
-
-// byte rows of 65..128 dimensions with Visited as bitmap blocks
-template <int NSLOT, int METRIC>
-__device__ __forceinline__ void search_layer0_bytes_blk_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx,
-                                                            uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-    if constexpr (NSLOT == 4 && METRIC == 0) search_layer0_bytes_l2_blk_asm4(iv, w, cx, n_dist, n_hops, status);
-    if constexpr (NSLOT == 8 && METRIC == 0) search_layer0_bytes_l2_blk_asm8(iv, w, cx, n_dist, n_hops, status);
-    if constexpr (NSLOT == 4 && METRIC == 1) search_layer0_bytes_ip_blk_asm4(iv, w, cx, n_dist, n_hops, status);
-    if constexpr (NSLOT == 8 && METRIC == 1) search_layer0_bytes_ip_blk_asm8(iv, w, cx, n_dist, n_hops, status);
-}
-template <int NSLOT, int METRIC>
-__device__ __forceinline__ bool search_layer0_bytes_blk_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
-                                                                 uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-    if constexpr (NSLOT == 4 && METRIC == 0) return search_layer0_bytes_l2_sem1_blk_asm4(iv, w, cx, rs, n_dist, n_hops, status);
-    if constexpr (NSLOT == 8 && METRIC == 0) return search_layer0_bytes_l2_sem1_blk_asm8(iv, w, cx, rs, n_dist, n_hops, status);
-    if constexpr (NSLOT == 4 && METRIC == 1) return search_layer0_bytes_ip_sem1_blk_asm4(iv, w, cx, rs, n_dist, n_hops, status);
-    if constexpr (NSLOT == 8 && METRIC == 1) return search_layer0_bytes_ip_sem1_blk_asm8(iv, w, cx, rs, n_dist, n_hops, status);
-    return false;
-}
-
-// ... with Visited as bitmap blocks (search_layer<..., BLK = 1>)
-template <int NSLOT, int METRIC, int ROWS>
-__device__ __forceinline__ void search_layer0_f32_blk_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, const float4 (&qv)[2],
-                                                          uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) NAME(iv, w, cx, qv, n_dist, n_hops, status);
-    HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_blk_asm4)   HNSW_F32_CALL(8, 0, 1, search_layer0_f32_l2_full_blk_asm8)
-    HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_blk_asm4) HNSW_F32_CALL(8, 0, 0, search_layer0_f32_l2_ragged_blk_asm8)
-    HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_blk_asm4)  HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_blk_asm8)
-    HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_blk_asm4)   HNSW_F32_CALL(8, 1, 1, search_layer0_f32_ip_full_blk_asm8)
-    HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_blk_asm4) HNSW_F32_CALL(8, 1, 0, search_layer0_f32_ip_ragged_blk_asm8)
-    HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_blk_asm4)  HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_blk_asm8)
-#undef HNSW_F32_CALL
-}
-template <int NSLOT, int METRIC, int ROWS>
-__device__ __forceinline__ bool search_layer0_f32_blk_sem1_asm(const IndexView &iv, WList<NSLOT> &w, const WaveCtx &cx, HopResume &rs,
-                                                               const float4 (&qv)[2], uint32_t &n_dist, uint32_t &n_hops, uint32_t &status) {
-#define HNSW_F32_CALL(NS, M, R, NAME) if constexpr (NSLOT == NS && METRIC == M && ROWS == R) return NAME(iv, w, cx, rs, qv, n_dist, n_hops, status);
-    HNSW_F32_CALL(4, 0, 1, search_layer0_f32_l2_full_sem1_blk_asm4)   HNSW_F32_CALL(8, 0, 1, search_layer0_f32_l2_full_sem1_blk_asm8)
-    HNSW_F32_CALL(4, 0, 0, search_layer0_f32_l2_ragged_sem1_blk_asm4) HNSW_F32_CALL(8, 0, 0, search_layer0_f32_l2_ragged_sem1_blk_asm8)
-    HNSW_F32_CALL(4, 0, 3, search_layer0_f32_l2_split_sem1_blk_asm4)  HNSW_F32_CALL(8, 0, 3, search_layer0_f32_l2_split_sem1_blk_asm8)
-    HNSW_F32_CALL(4, 1, 1, search_layer0_f32_ip_full_sem1_blk_asm4)   HNSW_F32_CALL(8, 1, 1, search_layer0_f32_ip_full_sem1_blk_asm8)
-    HNSW_F32_CALL(4, 1, 0, search_layer0_f32_ip_ragged_sem1_blk_asm4) HNSW_F32_CALL(8, 1, 0, search_layer0_f32_ip_ragged_sem1_blk_asm8)
-    HNSW_F32_CALL(4, 1, 3, search_layer0_f32_ip_split_sem1_blk_asm4)  HNSW_F32_CALL(8, 1, 3, search_layer0_f32_ip_split_sem1_blk_asm8)
-#undef HNSW_F32_CALL
-    return false;
-}
-
+// =====================================================================================================================
+// The instantiations: HopLoop<NCH, NSLOT, METRIC, ROWS, SEM, BLK>::run, one explicit specialisation per shape, each made by
+// including hnsw_hop_loop.inc with the HNSW_LOOP_* macros set.  The table is GENERATED (tools/gen_hop_slots.py ->
+// hnsw_hop_instances.inc): row families bytes (NCH 2) / bytes of 129..256 dimensions (NCH 4) / float32 full, ragged, split
+// (NCH 2 and 4) x metric x accept rule x W in 1, 2, 3, 4, 6, 8 registers x visited structure (bitmap blocks: three or more
+// registers, not the NCH 4 byte rows), under the feature switches at the top of this file, and in a translation unit of
+// hnsw_search_variants.hip only the shapes of that unit's (metric, rule, row format).  search_layer asks
+// HopLoop<...>::available and calls run(); a shape without an instantiation (the primary template) keeps the C++ loop.
+// =====================================================================================================================
+#include "hnsw_hop_instances.inc"
 
 // =====================================================================================================================
 // The descent through the upper layers (greedy_descend; Ohnsw.search_one, lib/ohnsw.ml:492-508) for the same shape:

@@ -54,6 +54,18 @@ inline int pick_nslot(int ef) {
     for (int s : {1, 2, 4, 8, 16}) if (ef <= 64 * s) return s;
     return 0;
 }
+// ... of the knn kernel: rows of 65..256 dimensions (NCH 2 and 4: the shapes with hand-scheduled loops) also have W in three
+// (ef 129..192) and six (ef 257..384) registers -- a W window that needs three registers pays for three (pop chain, flag masks,
+// registers), not for four; the other row widths, the builder and the layer operators keep powers of two (pick_nslot)
+inline int pick_nslot_knn(int ef, int nch) {
+    if (nch == 2 || nch == 4) { for (int s : {1, 2, 3, 4, 6, 8, 16}) if (ef <= 64 * s) return s; return 0; }
+    return pick_nslot(ef);
+}
+// index of a slot count in per-shape tables (hnsw_index::blk_choice)
+inline int slot_class(int nslot) {
+    switch (nslot) { case 1: return 0; case 2: return 1; case 3: return 2; case 4: return 3; case 6: return 4; case 8: return 5; default: return 6; }
+}
+constexpr int SLOT_CLASSES = 7;
 inline int64_t padded_stride(int d) { return ((int64_t)d + 15) / 16 * 16; } // floats: rows are multiples of 64 B
 
 // {upper_off, upper_lvl} of every node side by side (IndexView::upper_ref) from the two host tables
@@ -86,7 +98,7 @@ struct hnsw_index {
     void *dLcode = nullptr, *dLcode0 = nullptr;
     int lcode_state = 0;
     int blk_mode = -1;                   // option "visited_blocks": -1 automatic (measured per kernel shape on the index's own vectors), 0 never, 1 always
-    int blk_choice[5][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};   // [log2 NSLOT][accept rule]: -1 undecided, 0 tag cache, else log2 of the block slots
+    int blk_choice[7][2] = {{-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};   // [slot_class(NSLOT)][accept rule]: -1 undecided, 0 tag cache, else log2 of the block slots
     void *dX = nullptr, *dNbr0 = nullptr, *dNbrU = nullptr, *dOff = nullptr, *dLvl = nullptr, *dRef = nullptr;
     int64_t rowsU = 0;
     hnsw_host::DevBuf sQ, sIds, sDist, sNd, sNh, sSt, sFlag; // scratch for the host-buffer entry points (sFlag: the launch's "any query flagged" word)

@@ -27,9 +27,9 @@ constexpr int RB1 = 8, RB2 = F_ == 2 ? HNSW_RB_BYTES_NCH2 : HNSW_RB_NCH2, RB4 = 
 template <int NCH, int RB, int NSLOT>
 hipError_t launch_one(const IndexView &iv, const SearchArgs &a, hipStream_t st) {
     const size_t lds = hnsw_dev::search_lds_words(a.vt_bits, a.blk_bits) * sizeof(uint32_t) + (size_t)a.lds_pad;
-    // Visited as bitmap blocks (a.blk_bits > 0; W in four or more registers only) is a kernel of its own: the tag-cache kernels
+    // Visited as bitmap blocks (a.blk_bits > 0; W in three or more registers only) is a kernel of its own: the tag-cache kernels
     // keep their registers
-    if constexpr (NSLOT >= 4) {
+    if constexpr (NSLOT >= 3) {
         if (a.blk_bits > 0 && iv.lcode0 && iv.lcode) {
             hipLaunchKernelGGL((hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_, 1>), dim3((unsigned)a.nq), dim3(64), lds, st, iv, a);
             return hipGetLastError();
@@ -45,7 +45,7 @@ template <int NCH, int RB, int NSLOT>
 int occupancy_one(size_t lds, int blk) {
     int nb = 0;
     hipError_t e;
-    if constexpr (NSLOT >= 4) {
+    if constexpr (NSLOT >= 3) {
         e = blk ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_, 1>, 64, lds)
                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hnsw_dev::hnsw_search_kernel<NCH, RB, NSLOT, M_, S_, F_>, 64, lds);
     } else {
@@ -62,6 +62,9 @@ hipError_t launch_slot(int nslot, const IndexView &iv, const SearchArgs &a, hipS
     case 2: return launch_one<NCH, RB, 2>(iv, a, st);
     case 4: return launch_one<NCH, RB, 4>(iv, a, st);
     case 8: return launch_one<NCH, RB, 8>(iv, a, st);
+    // three and six registers: rows of 65..256 dimensions only (pick_nslot_knn never asks for them elsewhere)
+    case 3: if constexpr (NCH == 2 || NCH == 4) return launch_one<NCH, RB, 3>(iv, a, st); else return hipErrorInvalidValue;
+    case 6: if constexpr (NCH == 2 || NCH == 4) return launch_one<NCH, RB, 6>(iv, a, st); else return hipErrorInvalidValue;
     default: return launch_one<NCH, RB, 16>(iv, a, st);
     }
 }
@@ -72,6 +75,8 @@ int occupancy_slot(int nslot, size_t lds, int blk) {
     case 2: return occupancy_one<NCH, RB, 2>(lds, blk);
     case 4: return occupancy_one<NCH, RB, 4>(lds, blk);
     case 8: return occupancy_one<NCH, RB, 8>(lds, blk);
+    case 3: if constexpr (NCH == 2 || NCH == 4) return occupancy_one<NCH, RB, 3>(lds, blk); else return 0;
+    case 6: if constexpr (NCH == 2 || NCH == 4) return occupancy_one<NCH, RB, 6>(lds, blk); else return 0;
     default: return occupancy_one<NCH, RB, 16>(lds, blk);
     }
 }

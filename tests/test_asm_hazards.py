@@ -79,10 +79,10 @@ def test_rules_on_hand_made_listings():
 
 
 def _wanted():
-    """(object, mangled-name fragment) of the kernels that contain hand-scheduled code: the layer-0 loops (W in 1 / 2 / 4 / 8 key
+    """(object, mangled-name fragment) of the kernels that contain hand-scheduled code: the layer-0 loops (W in 1 / 2 / 3 / 4 / 6 / 8 key
     registers) over byte rows and over float32 rows (L2 and inner product; full, ragged and split rows), with the tag cache and
     with the bitmap blocks, and the descent kernel with the hand-scheduled descent"""
-    want = [("hnsw_search_variants_0_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi0ELi2ELi0EE" % s) for s in (1, 2, 4)]
+    want = [("hnsw_search_variants_0_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi0ELi2ELi0EE" % s) for s in (1, 2, 3, 4, 6)]     # (3, 6: the generated insertions)
     for obj, metric, rows in (("hnsw_search_variants_0_0_1.o", 0, 1), ("hnsw_search_variants_0_0_0.o", 0, 0),
                               ("hnsw_search_variants_1_0_1.o", 1, 1), ("hnsw_search_variants_1_0_0.o", 1, 0)):
         want += [(obj, "hnsw_search_kernelILi2ELi4ELi%dELi%dELi0ELi%dELi0EE" % (s, metric, rows)) for s in (1, 2, 4)]
@@ -91,6 +91,7 @@ def _wanted():
     want += [("hnsw_search_variants_1_0_2.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi2ELi0EE" % s) for s in (2, 4)]              # byte rows, inner product
     want += [("hnsw_search_variants_1_0_3.o", "hnsw_search_kernelILi2ELi4ELi%dELi1ELi0ELi3ELi0EE" % s) for s in (4,)]               # split rows (C3's kernel)
     want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi8ELi0ELi0ELi0ELi0EE")]                                    # eight slots (C5's kernel)
+    want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi%dELi0ELi0ELi0ELi1EE" % s) for s in (3, 6)]                  # three / six slots with the bitmap blocks
     # Visited as bitmap blocks (BLK = 1): the block filter inside the eight-slot ragged-row loop (C5's kernel when its data is
     # clustered), inside the four-slot split-row inner-product loop (C3's) and inside the four-slot byte-row loop
     want += [("hnsw_search_variants_0_0_0.o", "hnsw_search_kernelILi2ELi4ELi8ELi0ELi0ELi0ELi1EE"),
@@ -174,8 +175,9 @@ def _owned_nops(body):
 
 def test_labels_are_unique_within_every_block(tmp_path):
     """The blocks use numeric local labels and assume each is defined once per asm statement ("66f" must mean THE 66): the
-    preprocessed text of one translation unit holds every instantiation (they are inline functions of a header); a label
-    defined twice in one statement -- an eight-slot pop label reused by a later addition, say -- fails here, not on the GPU."""
+    preprocessed text of one translation unit built with HNSW_HOP_ALL_INSTANCES holds every instantiation of the generated
+    table (a unit normally holds its own (metric, rule, row format) only); a label defined twice in one statement -- an
+    eight-slot pop label reused by a later addition, say -- fails here, not on the GPU."""
     import re
     import subprocess
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
@@ -183,7 +185,7 @@ def test_labels_are_unique_within_every_block(tmp_path):
         pytest.skip("hipcc not available")
     out = str(tmp_path / "pp.ii")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-DHNSW_V_METRIC=0", "-DHNSW_V_SEMF=0",
-                    "-DHNSW_V_FULL=0", "--cuda-device-only", "-E", "-P", os.path.join(ROOT, "ocaml-hnsw_amd", "csrc", "hnsw_search_variants.hip"),
+                    "-DHNSW_V_FULL=0", "-DHNSW_HOP_ALL_INSTANCES", "--cuda-device-only", "-E", "-P", os.path.join(ROOT, "ocaml-hnsw_amd", "csrc", "hnsw_search_variants.hip"),
                     "-o", out], check=True, capture_output=True)
     text = open(out).read()
     blocks = []
@@ -199,7 +201,12 @@ def test_labels_are_unique_within_every_block(tmp_path):
         body = "".join(parts)
         if re.search(r"^\s*\d+:", body, flags=re.M):
             blocks.append(body)
-    assert len(blocks) >= 60, len(blocks)            # 3 x 2 byte-row + 3 x 2 x 2 x 3 float32-row loops per slot count ..., the descent, the island
+    spec = importlib.util.spec_from_file_location("gen_hop_slots", os.path.join(ROOT, "tools", "gen_hop_slots.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    n_inst = len(gen.instances())
+    assert n_inst == 304                             # 4 row families x rows x 2 metrics x 2 rules x 6 slot counts (+ 4 with bitmap blocks)
+    assert len(blocks) >= n_inst + 2, len(blocks)    # ... the descent, the island
     for body in blocks:
         labels = re.findall(r"^\s*(\d+):", body, flags=re.M)
         dup = sorted({x for x in labels if labels.count(x) > 1})
@@ -207,7 +214,8 @@ def test_labels_are_unique_within_every_block(tmp_path):
 
 
 def test_generated_insertion_is_current_and_equals_the_hand_written_one():
-    """csrc/hnsw_hop_slots8.inc is what tools/gen_hop_slots.py writes, and the generator, asked for FOUR slots, reproduces the
+    """csrc/hnsw_hop_slots.inc (what depends on the slot count: W in 3, 4, 6, 8 registers) and csrc/hnsw_hop_instances.inc (the
+    table of instantiations) are what tools/gen_hop_slots.py writes, and the generator, asked for FOUR slots, reproduces the
     hand-written HNSW_INSERT_LOOP4 / HNSW_INSERT_RARE4 of hnsw_hop_asm.hip.h instruction for instruction"""
     import re
     spec = importlib.util.spec_from_file_location("gen_hop_slots", os.path.join(ROOT, "tools", "gen_hop_slots.py"))
@@ -271,11 +279,12 @@ def test_hand_scheduled_blocks_hand_m0_back():
     csrc = os.path.join(ROOT, "ocaml-hnsw_amd", "csrc")
     inc = open(os.path.join(csrc, "hnsw_hop_loop.inc")).read()
     blocks = inc.split("asm volatile(")[1:]
-    assert len(blocks) == 4                                   # W in 2 / 4 / 8 / 1 registers
+    assert len(blocks) == 3                                   # W in 2 / three and more / 1 registers
     for b in blocks:
         body = b.split("    w.wmax = wmax;")[0]
         assert body.count('"s_mov_b32 %[sm0], m0\\n\\t"') == 1 and body.count('s_mov_b32 m0, %[sm0]') == 1
-        assert body.index("s_mov_b32 %[sm0], m0") < body.index("v_alignbit_b32") < body.rindex("s_mov_b32 m0, %[sm0]")
+        first = "v_alignbit_b32" if "v_alignbit_b32" in body else "HNSW_NS(ALIGN_IN)"      # (the generic body: the slot set's macro)
+        assert body.index("s_mov_b32 %[sm0], m0") < body.index(first) < body.rindex("s_mov_b32 m0, %[sm0]")
         assert '[sm0] "=&s"(sm0)' in body
     for f in os.listdir(csrc):
         txt = open(os.path.join(csrc, f)).read()

@@ -1,6 +1,6 @@
 """The hand-scheduled layer-0 loops (csrc/hnsw_hop_asm.hip.h: byte rows of 65..128 and of 129..256 dimensions, byte-valued
-queries, L2 and inner product, both accept rules; W in one / two / four / eight key registers per lane = ef <= 64 / 65..128 /
-129..256 / 257..512) against the oracle on
+queries, L2 and inner product, both accept rules; W in one / two / three / four / six / eight key registers per lane = ef <= 64 /
+65..128 / 129..192 / 193..256 / 257..384 / 385..512, every boundary among the ef values below) against the oracle on
 data chosen to drive their seldom-taken paths: exact distance ties everywhere (the general rank with id comparison, the
 "node already in W" check), entries evicted while tied with the new maximum (the tie list in LDS, its pop when W has no
 unexpanded member left, its overflow and the host's exactness fallback), rounds of 1 / 2 / 4 batches and lists longer
@@ -47,7 +47,7 @@ def test_ties_everywhere_every_slot_count(H, oracle, levels, d):
     g = oracle.build_ohnsw(sp, 12, 60, seed=3)
     hg = _hgraph(H, X, g, 12)
     assert hg.to_device(0).row_bytes() == d                                # byte rows: the loops under test run
-    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256), (257, 10), (400, 400), (512, 64)):
+    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (160, 160), (192, 10), (193, 10), (256, 256), (257, 10), (384, 384), (385, 10), (400, 400), (512, 64)):
         _check(H, oracle, hg, g, sp, Q, ef, k, "levels %d d %d ef %d" % (levels, d, ef))
 
 
@@ -76,7 +76,7 @@ def test_functor_rule_through_the_loops(H, oracle, levels, d):
     g = oracle.build_ohnsw(sp, 12, 60, seed=3)
     hg = _hgraph(H, X, g, 12)
     assert hg.to_device(0).row_bytes() == d
-    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256), (257, 10), (400, 400), (512, 64)):
+    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (160, 160), (192, 10), (193, 10), (256, 256), (257, 10), (384, 384), (385, 10), (400, 400), (512, 64)):
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "functor levels %d d %d ef %d" % (levels, d, ef))
 
 
@@ -96,7 +96,7 @@ def test_inner_product_on_byte_rows_through_the_loops(H, oracle, levels, d):
     g = oracle.build_ohnsw(sp, 12, 60, seed=3)
     hg = H.Hgraph(X, g.deg0, g.nbr0, g.upper, entry_point=g.entry_point, id_base=0, max_degree=12, metric=1)
     assert hg.to_device(0).row_bytes() == d
-    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (128, 10), (129, 20), (256, 256), (300, 300), (512, 10)):
+    for ef, k in ((1, 1), (17, 5), (64, 64), (65, 10), (128, 10), (129, 20), (192, 100), (256, 256), (300, 300), (384, 10), (512, 10)):
         _check(H, oracle, hg, g, sp, Q, ef, k, "ip levels %d d %d ef %d" % (levels, d, ef))
         _check_functor(H, oracle, hg, g, sp, Q, ef, k, "ip functor levels %d d %d ef %d" % (levels, d, ef))
 
@@ -209,12 +209,12 @@ def test_tie_list_overflow_through_the_loops(H, oracle, ef):
 def test_random_configurations_of_the_loop_shapes(H, oracle):
     """Random small problems inside the loops' domain (d 65..128, byte values, L2, Ohnsw rule, ef 1..256)."""
     rng = np.random.default_rng(77)
-    for trial in range(40):
+    for trial in range(60):
         n = int(rng.integers(2, 700))
         d = int(rng.integers(65, 129))
         M = int(rng.choice([2, 4, 8, 16, 32]))
         levels = int(rng.choice([2, 4, 16, 219]))
-        ef = int(rng.choice([1, 3, 30, 63, 64, 65, 90, 127, 128, 129, 191, 255, 256, 257, 300, 511, 512]))
+        ef = int(rng.choice([1, 3, 30, 63, 64, 65, 90, 127, 128, 129, 160, 191, 192, 193, 255, 256, 257, 300, 384, 385, 511, 512]))
         k = int(rng.integers(1, min(ef, 100) + 1))
         X = rng.integers(0, levels, size=(n, d)).astype(np.float32)
         Q = rng.integers(0, levels, size=(20, d)).astype(np.float32)

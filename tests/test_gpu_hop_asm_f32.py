@@ -50,7 +50,8 @@ def _check_functor(H, oracle, hg, g, sp, Q, ef, k, ctx=""):
     assert (gnd > 0).all() and (gnh > 0).all(), ctx
 
 
-EFS = ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (256, 256), (257, 10), (400, 400), (512, 64))
+# every slot count (W in 1 / 2 / 3 / 4 / 6 / 8 registers: ef <= 64 / 128 / 192 / 256 / 384 / 512) at both ends of its range
+EFS = ((1, 1), (17, 5), (64, 64), (65, 10), (100, 100), (128, 10), (129, 20), (192, 10), (193, 30), (256, 256), (257, 10), (384, 60), (385, 10), (400, 400), (512, 64))
 
 
 # d: 68 = 17 chunks (one lane of the second chunk), 76 = 19, 100 = 25, 123 = 31 chunks with a partial last one, 125 = full rows

@@ -5,7 +5,7 @@ hand-scheduled twin HNSW_HOP_FILTER_*_BLK, the codes of hnsw_locality.hip) again
 A visited structure that forgets can only ADD evaluations; one that invents a visit would lose neighbours.  So for every
 mode (0 = the tag cache, 1 = the blocks, -1 = the handle's own measurement): ids, distance bits and hop counts equal the
 oracle's -- on small graphs built by the oracle's restatement of Ohnsw.insert (every kernel shape the blocks run in: the
-hand-scheduled loops over float32 rows with W in four / eight registers, both accept rules, and the C++ loop of other shapes)
+hand-scheduled loops over float32 rows with W in three / four / six / eight registers, both accept rules, and the C++ loop of other shapes)
 and on clustered unit vectors at moderate and at BASELINE configuration 5's full size, where the tag cache re-evaluated a
 third of the rows in round 4 -- plus the bound on the evaluations the device adds.
 """
@@ -59,19 +59,25 @@ def _hgraph(H, X, g, metric, M):
 
 
 SMALL = [
-    # name, d, metric, M, efC, ef, k: float32 rows of 65..128 dimensions -> the hand-scheduled block filter (W in 4 / 8 registers)
+    # name, d, metric, M, efC, ef, k: float32 rows of 65..128 dimensions -> the hand-scheduled block filter (W in 3 / 4 / 6 / 8 registers)
     ("ragged_l2_8slots", 96, 0, 16, 60, 512, 10),
     ("split_ip_4slots", 100, 1, 16, 60, 256, 50),
     ("full_l2_4slots", 128, 0, 12, 60, 200, 10),
-    ("ragged_ip_8slots", 72, 1, 12, 60, 300, 10),
+    ("ragged_ip_6slots", 72, 1, 12, 60, 300, 10),
+    ("ragged_l2_8slots_ef400", 80, 0, 12, 60, 400, 10),
+    ("full_ip_3slots", 128, 1, 12, 60, 129, 10),
+    ("ragged_l2_6slots", 96, 0, 16, 60, 384, 384),
     # byte-valued data of 65..128 dimensions (searched through the byte rows): the byte-row loops' block filter
     ("bytes_l2_4slots", 128, 0, 16, 60, 200, 10),
     ("bytes_l2_8slots", 100, 0, 12, 60, 400, 10),
     ("bytes_ip_4slots", 96, 1, 12, 60, 256, 20),
+    ("bytes_l2_3slots", 128, 0, 16, 60, 180, 10),
+    ("bytes_ip_6slots", 100, 1, 12, 60, 320, 10),
     # float32 rows of 129..256 dimensions: the four-chunk loops' block filter
     ("d200_ragged_8slots", 200, 0, 8, 40, 400, 10),
     ("d256_full_ip_4slots", 256, 1, 8, 40, 200, 10),
-    ("d132_split_4slots", 132, 0, 8, 40, 160, 10),
+    ("d132_split_3slots", 132, 0, 8, 40, 160, 10),
+    ("d132_split_4slots", 132, 0, 8, 40, 250, 10),
     # other shapes: the C++ loop's block filter
     ("d32_4slots", 32, 0, 8, 40, 200, 10),
     ("d300_8slots", 300, 0, 8, 40, 400, 10),

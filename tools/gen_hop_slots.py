@@ -1,20 +1,35 @@
 #!/usr/bin/env python3
-"""Writes ocaml-hnsw_amd/csrc/hnsw_hop_slots8.inc: the insertion of the hand-scheduled layer-0 loop for W in EIGHT key
-registers per lane (ef 257..512), i.e. HNSW_INSERT_LOOP8 / HNSW_INSERT_RARE8 -- the text of HNSW_INSERT_LOOP4 /
-HNSW_INSERT_RARE4 (csrc/hnsw_hop_asm.hip.h, written by hand) with the slot-dependent parts repeated per slot: the chain over
-the slots' maxima that finds the rank's slot, one block per slot (tie check, position, the cascade of every slot above it,
-the shift, the maxima that moved), the general rank over all slots and one eviction-tie block per way back.
+"""Writes the two GENERATED includes of the hand-scheduled layer-0 loop (ocaml-hnsw_amd/csrc/hnsw_hop_asm.hip.h):
 
-    python tools/gen_hop_slots.py            # rewrite the file
-    python tools/gen_hop_slots.py --check    # exit 1 if the committed file differs from what this script writes
-    python tools/gen_hop_slots.py --n 4      # print the same text for four slots (compared with the hand-written macros by
-                                             # tests/test_asm_hazards.py::test_generated_insertion_equals_the_hand_written_one)
+  hnsw_hop_slots.inc      everything in hnsw_hop_loop.inc that depends on HOW MANY key registers per lane hold W, as one macro set
+                          per slot count N in SLOTS = 3, 4, 6, 8 (ef 129..192 / 193..256 / 257..384 / 385..512): the insertion
+                          (HNSW_INSERT_LOOP<N> / HNSW_INSERT_RARE<N> -- the text of the hand-written four-slot macros of
+                          hnsw_hop_asm.hip.h with the slot-dependent parts repeated per slot: the chain over the slots' maxima that
+                          finds the rank's slot, one block per slot (tie check, position, the cascade of every slot above it, the
+                          shift, the maxima that moved), the general rank over all slots and one eviction-tie block per way back),
+                          the pop / peek chains over the slots' unexpanded masks, the register declarations and operand lists.
+                          hnsw_hop_loop.inc has ONE body for all of them (HNSW_NS(...) picks the set of HNSW_LOOP_NSLOT); the
+                          four-slot insertion stays the hand-written, commented text and the generator must reproduce it.
+  hnsw_hop_instances.inc  the table of instantiations: one `#define HNSW_LOOP_* ... #include "hnsw_hop_loop.inc"` stanza per
+                          (row family, metric, accept rule, slot count, visited structure), each under the feature switches of
+                          hnsw_hop_asm.hip.h and -- in the translation units of hnsw_search_variants.hip, which are compiled per
+                          (metric, rule, row format) -- only where the unit can reach it (rounds 2-5 wrote 184 stanzas by hand and
+                          every unit parsed all of them).
+
+    python tools/gen_hop_slots.py            # rewrite both files
+    python tools/gen_hop_slots.py --check    # exit 1 if a committed file differs from what this script writes
+    python tools/gen_hop_slots.py --n 4      # print the insertion for four slots (compared with the hand-written macros by
+                                             # tests/test_asm_hazards.py::test_generated_insertion_is_current_and_equals_the_hand_written_one)
 """
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "ocaml-hnsw_amd", "csrc", "hnsw_hop_slots8.inc")
+CSRC = os.path.join(ROOT, "ocaml-hnsw_amd", "csrc")
+OUT_SLOTS = os.path.join(CSRC, "hnsw_hop_slots.inc")
+OUT_INST = os.path.join(CSRC, "hnsw_hop_instances.inc")
+SLOTS = (3, 4, 6, 8)            # slot counts served by the generic body of hnsw_hop_loop.inc (1 and 2 have bodies of their own)
+HAND_WRITTEN = (4,)             # ... whose insertion is the hand-written text of hnsw_hop_asm.hip.h
 DPP = '" HNSW_DPP_ALL "'
 
 
@@ -141,30 +156,140 @@ def emit(name, L, n):
 
 
 def text(n):
-    head = ('// hnsw_hop_slots%d.inc -- GENERATED by tools/gen_hop_slots.py (do not edit; `python tools/gen_hop_slots.py` rewrites it,\n'
-            '// tests/test_asm_hazards.py checks that it is current): HNSW_INSERT_LOOP%d / HNSW_INSERT_RARE%d, the insertion of the\n'
-            '// hand-scheduled layer-0 loop for W in %d key registers per lane.  Same structure as the four-slot text in\n'
-            '// hnsw_hop_asm.hip.h (which explains it): the slot of the rank from the slots\' maxima (mx0..mx%d, scalar registers), one block\n'
-            '// per slot, the cascade of the slots above it, the general rank for distance ties, one eviction-tie block per way back.\n' % (n, n, n, n, n - 2))
-    return head + emit('HNSW_INSERT_LOOP%d' % n, lines_loop(n), n) + '\n\n' + emit('HNSW_INSERT_RARE%d' % n, lines_rare(n), n) + '\n'
+    """HNSW_INSERT_LOOP<n> / HNSW_INSERT_RARE<n>"""
+    return emit('HNSW_INSERT_LOOP%d' % n, lines_loop(n), n) + '\n\n' + emit('HNSW_INSERT_RARE%d' % n, lines_rare(n), n) + '\n'
+
+
+def macro(name, lines):
+    """a multi-line #define from already quoted / C text lines"""
+    if not lines:
+        return '#define %s' % name
+    return '#define %s \\\n' % name + ' \\\n'.join('    ' + ln for ln in lines)
+
+
+def slot_set(n):
+    """the macro set HNSW_NSX_<WHAT>_<n> that hnsw_hop_loop.inc's generic body is made of"""
+    t = n - 1
+    out = []
+    q = lambda txt: '"%s"' % txt
+    out.append(macro('HNSW_NSX_DECL_%d' % n,
+                     ['uint64_t %s;' % ', '.join('um%d' % j for j in range(n)),
+                      'uint32_t %s;' % ', '.join('mx%d' % j for j in range(t))]))
+    out.append(macro('HNSW_NSX_ALIGN_IN_%d' % n, [q('v_alignbit_b32 %%[l%d], %%[l%d], %%[l%d], 1\\n\\t' % (j, j, j)) for j in range(n)]))
+    out.append(macro('HNSW_NSX_ALIGN_OUT_%d' % n, [q('\\n\\tv_alignbit_b32 %%[l%d], %%[l%d], %%[l%d], 31' % (j, j, j)) for j in range(n)]))
+    out.append(macro('HNSW_NSX_MX_INIT_%d' % n, [q('v_readlane_b32 %%[mx%d], %%[h%d], 63\\n\\t' % (j, j)) for j in range(t)]))
+    out.append(macro('HNSW_NSX_UM_INIT_%d' % n, [q('v_cmp_lt_i32_e64 %%[um%d], -1, %%[l%d]\\n%s' % (j, j, '' if j == t else '\\t')) for j in range(n)]))
+    out.append(macro('HNSW_NSX_POP_CHAIN_%d' % n,
+                     ['HNSW_POP_SLOT("6%d", "%%[um%d]", "%%[l%d]", "%s")' % (j, j, j, '90f' if j == t else '6%df' % (j + 1)) for j in range(1, n)]))
+    out.append(macro('HNSW_NSX_PEEK_CHAIN_%d' % n,
+                     ['HNSW_PEEK_SLOT("7%d", "%%[um%d]", "%%[l%d]", "%s")' % (j, j, j, '9b' if j == t else '7%df' % (j + 1)) for j in range(1, n)]))
+    out.append(macro('HNSW_NSX_WOUT_%d' % n,
+                     [', '.join('[h%d] "+&v"(w.hi[%d])' % (j, j) for j in range(n)) + ',',
+                      ', '.join('[l%d] "+&v"(w.lo[%d])' % (j, j) for j in range(n)) + ',']))
+    out.append(macro('HNSW_NSX_UMOUT_%d' % n, [', '.join('[um%d] "=&s"(um%d)' % (j, j) for j in range(n)) + ',']))
+    out.append(macro('HNSW_NSX_MXOUT_%d' % n, [', ' + ', '.join('[mx%d] "=&s"(mx%d)' % (j, j) for j in range(t))]))
+    out.append('#define HNSW_NSX_INSERT_LOOP_%d HNSW_INSERT_LOOP%d' % (n, n))
+    out.append('#define HNSW_NSX_INSERT_RARE_%d HNSW_INSERT_RARE%d' % (n, n))
+    out.append('#define HNSW_NSX_ALIGN_PAD_%d HNSW_ASM_ALIGN_PAD%d' % (n, n))
+    return '\n'.join(out) + '\n'
+
+
+def slots_text():
+    head = ('// hnsw_hop_slots.inc -- GENERATED by tools/gen_hop_slots.py (do not edit; `python tools/gen_hop_slots.py` rewrites it,\n'
+            '// tests/test_asm_hazards.py checks that it is current).  For every slot count N in %s -- key registers per lane that hold W --\n'
+            '// the parts of the hand-scheduled layer-0 loop that depend on N: HNSW_INSERT_LOOP<N> / HNSW_INSERT_RARE<N> (same structure as\n'
+            '// the four-slot text in hnsw_hop_asm.hip.h, which explains it: the slot of the rank from the slots\' maxima mx0..mx<N-2>, one\n'
+            '// block per slot, the cascade of the slots above it, the general rank for distance ties, one eviction-tie block per way back;\n'
+            '// N = %s: hand-written there) and the macro set HNSW_NSX_*_<N> the generic body of hnsw_hop_loop.inc is made of.\n'
+            % (', '.join(map(str, SLOTS)), ', '.join(map(str, HAND_WRITTEN))))
+    parts = [head]
+    for n in SLOTS:
+        parts.append('// ---- W in %d key registers per lane ----' % n)
+        if n not in HAND_WRITTEN:
+            parts.append(text(n))
+        parts.append(slot_set(n))
+    return '\n'.join(parts)
+
+
+# ---- the instantiation table ----------------------------------------------------------------------------------------------
+# row families: (name, NCH, ROWS values, feature guard)
+FAMILIES = (("bytes", 2, (2,), "1"),
+            ("bytes4", 4, (2,), "HNSW_ASM_LOOP_BYTES4"),
+            ("f32", 2, (1, 0, 3), "HNSW_ASM_LOOP_F32"),
+            ("f32n4", 4, (1, 0, 3), "HNSW_ASM_LOOP_F32 && HNSW_ASM_LOOP_F32N4"))
+NSLOTS = (1, 2, 3, 4, 6, 8)
+
+
+def instances():
+    """(nch, rows, metric, sem, nslot, blk, guard) of every instantiation"""
+    out = []
+    for fam, nch, rows_list, fguard in FAMILIES:
+        for rows in rows_list:
+            for metric in (0, 1):
+                for sem in (0, 1):
+                    for nslot in NSLOTS:
+                        for blk in (0, 1):
+                            if blk and (nslot < 3 or fam == "bytes4"):
+                                continue            # bitmap blocks: W in three or more registers; not for byte rows of 129..256 dimensions
+                            g = [fguard]
+                            if rows == 3:
+                                g.append("HNSW_ASM_LOOP_SPLIT")
+                            if sem:
+                                g.append("HNSW_ASM_LOOP_SEM1")
+                            if nslot > 4:
+                                g.append("HNSW_ASM_LOOP_8SLOTS")
+                            g = [x for x in g if x != "1"]
+                            out.append((nch, rows, metric, sem, nslot, blk, " && ".join(g) if g else "1"))
+    return out
+
+
+def instances_text():
+    L = ['// hnsw_hop_instances.inc -- GENERATED by tools/gen_hop_slots.py (do not edit; `python tools/gen_hop_slots.py` rewrites it,',
+         '// tests/test_asm_hazards.py checks that it is current): the instantiations HopLoop<NCH, NSLOT, METRIC, ROWS, SEM, BLK> of the',
+         '// hand-scheduled layer-0 loop, one stanza each.  A stanza is compiled when the feature switches of hnsw_hop_asm.hip.h allow it',
+         '// and the translation unit can reach it: the units of hnsw_search_variants.hip are compiled per (metric, accept rule, row',
+         '// format) and define HNSW_V_METRIC / HNSW_V_SEMF / HNSW_V_FULL; every other unit (the builder, the layer operators: row format',
+         '// decided at run time) takes search_layer\'s C++ loop and instantiates nothing.',
+         '#if defined(HNSW_HOP_ALL_INSTANCES)      /* (tests: every instantiation in one preprocessed unit) */',
+         '#define HNSW_HOP_UNIT(M, S, R) 1',
+         '#elif defined(HNSW_V_METRIC)',
+         '#define HNSW_HOP_UNIT(M, S, R) (HNSW_V_METRIC == (M) && HNSW_V_SEMF == (S) && HNSW_V_FULL == (R))',
+         '#else',
+         '#define HNSW_HOP_UNIT(M, S, R) 0',
+         '#endif']
+    for nch, rows, metric, sem, nslot, blk, guard in instances():
+        cond = 'HNSW_HOP_UNIT(%d, %d, %d)' % (metric, sem, rows) + ('' if guard == '1' else ' && ' + guard)
+        L.append('#if %s' % cond)
+        L.append('#define HNSW_LOOP_NCH %d' % nch)
+        L.append('#define HNSW_LOOP_NSLOT %d' % nslot)
+        L.append('#define HNSW_LOOP_ROWS %d' % rows)
+        L.append('#define HNSW_LOOP_METRIC %d' % metric)
+        L.append('#define HNSW_LOOP_SEM %d' % sem)
+        L.append('#define HNSW_LOOP_BLK %d' % blk)
+        L.append('#include "hnsw_hop_loop.inc"')
+        L.append('#endif')
+    L.append('#undef HNSW_HOP_UNIT')
+    return '\n'.join(L) + '\n'
 
 
 def main(argv):
-    n = 8
     if '--n' in argv:
         n = int(argv[argv.index('--n') + 1])
         sys.stdout.write(text(n))
         return 0
-    t = text(8)
+    want = {OUT_SLOTS: slots_text(), OUT_INST: instances_text()}
     if '--check' in argv:
-        cur = open(OUT).read() if os.path.exists(OUT) else ''
-        if cur != t:
-            print('%s is not what tools/gen_hop_slots.py writes' % OUT)
-            return 1
-        return 0
-    with open(OUT, 'w') as f:
-        f.write(t)
-    print('wrote', OUT)
+        rc = 0
+        for path, t in want.items():
+            cur = open(path).read() if os.path.exists(path) else ''
+            if cur != t:
+                print('%s is not what tools/gen_hop_slots.py writes' % path)
+                rc = 1
+        return rc
+    for path, t in want.items():
+        with open(path, 'w') as f:
+            f.write(t)
+        print('wrote', path)
     return 0
 
 
