@@ -173,26 +173,35 @@ def driver_line(detail):
     roof = d_.get("roofline") or {}
     out = {k_: d_.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                       "scaling", "vs_baseline", "dtype", "data")}
-    c_ = _pick(cfg, "workload", "n", "d", "M", "ef_construction", "ef", "k", "queries_per_gpu", "global_batch", "parallelism", "rows",
-               "batches_rotated") or {}
+    c_ = _pick(cfg, "workload", "n", "d", "M", "ef_construction", "ef", "k", "queries_per_gpu", "global_batch", "parallelism") or {}
     c_["workload"] = str(c_.get("workload", ""))[:300]
+    c_["rows"] = str(cfg.get("rows", ""))[:8].split(" ")[0]
     out["config"] = c_
     r_ = _pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_query", "row_bytes",
-               "n_dist_per_query", "n_hops_per_query", "latency_floor")
+               "n_dist_per_query", "n_hops_per_query")
     if r_ is not None:
+        r_["latency_floor"] = _pick(roof.get("latency_floor"), "longest_walk_hops", "lone_hop_us", "floor_ms", "kernel_over_floor",
+                                    "wave_occupancy", "full_load_ms_per_batch")
         alg = (roof.get("bytes_per_query") or 0) * (cfg.get("queries_per_gpu") or 0)
         r_["traffic_over_algorithmic"] = round(roof["traffic"] / alg, 3) if roof.get("traffic") and alg else None
         iss = roof.get("issue") or {}
-        r_["issue"] = _pick(iss, "valu", "salu", "clock_GHz", "instructions_per_hop", "wave_occupancy")
+        r_["issue"] = _pick(iss, "valu", "salu", "clock_GHz", "instructions_per_hop")
     out["roofline"] = r_
     cb = d_.get("cpu_baseline")
     if isinstance(cb, dict):
         ac = cb.get("all_cores") or {}
         out["cpu_baseline"] = dict(_pick(cb, "value", "unit", "cores", "kind", "value_min", "value_max"),
-                                   sample=str(cb.get("sample", ""))[:160], all_cores_value=ac.get("value"), all_cores=ac.get("cores"))
+                                   sample=str(cb.get("sample", ""))[:110], all_cores_value=ac.get("value"), all_cores=ac.get("cores"))
     else:
         out["cpu_baseline"] = None
-    out["checks"] = d_.get("checks")
+    # the run's self-checks: every boolean one by name only if it FAILED (the names of the passed ones are in the detail), numbers kept
+    ck = d_.get("checks")
+    if isinstance(ck, dict):
+        flags = {k_: v_ for k_, v_ in ck.items() if isinstance(v_, bool)}
+        out["checks"] = dict({k_: v_ for k_, v_ in ck.items() if not isinstance(v_, bool)},
+                             passed=sum(1 for v_ in flags.values() if v_), failed=sorted(k_ for k_, v_ in flags.items() if not v_))
+    else:
+        out["checks"] = None
     out["recall_at_10"] = (d_.get("checks") or {}).get("recall_at_10")
     fl, rfl = d_.get("float32_rows"), roof.get("float32_rows") or {}
     out["float32_rows"] = None if not isinstance(fl, dict) else dict(
@@ -1591,9 +1600,9 @@ def main():
                 checks["cpu_all_cores_ids_equal"] = bool(np.array_equal(mids, got))
                 cpu_baseline = {"value": round(nq / ref_s, 1), "unit": "queries/s", "cores": 1, "kind": "port",
                                 "passes": 3, "statistic": "median", "value_min": round(nq / ref_ts[2], 1), "value_max": round(nq / ref_ts[0], 1),
-                                "sample": "all %d queries of one batch x 3 passes (median %.1f s), 1 thread: C restatement of Ohnsw.knn_batch_bigarray, "
-                                          "reference arithmetic (not OCaml)" % (nq, ref_s),
-                                "sample_note": "same graph, ef=%d k=%d; sequential fp32 sum, sqrt in double; the reference is single-threaded" % (ef, k),
+                                "sample": "all %d queries of one batch, median of 3 passes (%.1f s), 1 thread, C restatement (not OCaml)" % (nq, ref_s),
+                                "sample_note": "C restatement of Ohnsw.knn_batch_bigarray with the reference's arithmetic (sequential fp32 sum, sqrt in "
+                                               "double), same graph, ef=%d k=%d; the reference is single-threaded" % (ef, k),
                                 "all_cores": {"value": round(nq / mt_s, 1), "cores": ncores,
                                               "sample": "all %d queries split over %d host threads" % (nq, ncores)}}
                 log("cpu restatement (reference arithmetic): %.1f q/s single-thread, %.1f q/s on %d threads" % (nq / ref_s, nq / mt_s, ncores))
@@ -1701,8 +1710,8 @@ def main():
             "dtype": "u8" if byte_rows else "f32",
             "dtype_note": "u8 rows, u32 dot products (exact) -> f32 distances" if byte_rows else "f32",
             "data": ("file:" + os.path.basename(os.path.normpath(args.dataset))) if args.dataset else "synthetic",
-            "config": {"workload": "C2: %s (n=%d d=%d), M=%d efConstruction=%d (graph built on the GPU), ef=%d k=%d, %d queries per GPU per step, "
-                                   "replicated index%s; easier than SIFT1M (%s evaluations/query vs ~2.5-3k): see harder_set_at_recall_gate (%s)"
+            "config": {"workload": "C2: %s (n=%d d=%d), M=%d efC=%d (built on the GPU), ef=%d k=%d, %d queries/GPU/step, "
+                                   "replicated index%s; easier than SIFT1M (%s evals/query vs ~2.5-3k): see harder_set_at_recall_gate (%s)"
                                    % ("vectors from " + args.dataset if args.dataset else "SIFT1M-shaped synthetic, clustered ints 0..218 as fp32",
                                       n, d, args.M, args.efc, ef, k, nq,
                                       ", RCCL all-gather of results" if world > 1 else "", nd_head, nd_hard),

@@ -61,8 +61,13 @@ extern "C" {
  *      asynchronous readers and refuse pointers that are not theirs (HNSW_ERR_BAD_ARG); and, since version 1 was first cut:
  *      hnsw_search_batch_h2d, hnsw_host_alloc / hnsw_host_free, hnsw_index_layer_isolated, hnsw_multi_debug_counters,
  *      hnsw_index_info.row_format (was `reserved`), hnsw_index_layer_stats' values for a layer without nodes
- *      (min 1000000, max -1, mean nan: the reference's fold), Hgraph.stats()['isolated'] a list of ids */
-#define HNSW_ABI_VERSION 2
+ *      (min 1000000, max -1, mean nan: the reference's fold), Hgraph.stats()['isolated'] a list of ids
+ *   3  (round 6) hnsw_index_desc.expected_ef / expected_semantics and hnsw_build_params.expected_ef / expected_semantics (the
+ *      structures GROW: a caller compiled against version 2 passes too short a structure), hnsw_index_prepare; the index file
+ *      (hnsw_index_save, format 2) also carries the locality codes and the prepared shapes' decisions, hnsw_index_load applies
+ *      them (format 1 files still load); W in three and six key registers (ef 129..192, 257..384: no interface change);
+ *      hnsw_multi_search_batch* abort their communicators when an exchange is refused part-way */
+#define HNSW_ABI_VERSION 3
 
 typedef struct hnsw_index hnsw_index;
 
@@ -110,6 +115,13 @@ typedef struct hnsw_index_desc {
     const int32_t *deg0;  /* [n]                                                             */
     const int32_t *nbr0;  /* [n][max_degree0], reference iteration order                     */
     const hnsw_layer_desc *upper; /* [max_layer]; upper[l-1] describes layer l               */
+    /* Optional (0 = not known): the ef (~num_neighbours_search; Ohnsw: k) and accept rule (HNSW_SEM_*) the index will be searched
+     * with.  When given, hnsw_index_create does NOW, once, what the first search with these parameters would otherwise do inside
+     * the call (hnsw_index_prepare below): construction is where the reference's benchmark pays one-time costs too
+     * (benchmark/benchmark.ml:66-80 before :89-96).  A value the library cannot serve (ef > 1024) is ignored here and
+     * reported by the search. */
+    int32_t expected_ef;
+    int32_t expected_semantics;
 } hnsw_index_desc;
 
 /* Which accept rule W uses (they differ only when a neighbour is exactly as far as max(W)):
@@ -197,8 +209,9 @@ int32_t hnsw_index_get_info(const hnsw_index *idx, hnsw_index_info *info);
  *                   cache of BITMAP BLOCKS over "locality codes" -- a second numbering of the nodes, derived from the
  *                   index's own upper layers, under which graph-close nodes are consecutive, so that the nodes a walk
  *                   visits share blocks and cost one bit each (ocaml-hnsw_amd/csrc/hnsw_locality.hip); -1 (default) = the
- *                   handle decides per kernel shape by searching 256 of the index's own vectors both ways and counting
- *                   evaluations, inside the first search call that needs the answer (which then also builds the codes: one
+ *                   handle decides per kernel shape by searching 256 probe queries (midpoints between a stored vector and
+ *                   its first neighbour) both ways and counting evaluations, inside the first search call that needs the answer --
+ *                   or ahead of it: hnsw_index_prepare, expected_ef -- (which then also builds the codes: one
  *                   small layer search per node, n * (1 + max_degree0) * 4 bytes of tables, a device synchronisation --
  *                   1.2 s for 10 M nodes; indices below 200 000 nodes are not measured).  MEMORY: the n * max_degree0 * 4 bytes of
  *                   per-slot codes (2.56 GB for 10 M nodes at M 32; counted in hnsw_index_info.device_bytes while they exist) are kept
@@ -394,6 +407,8 @@ typedef struct hnsw_build_params {
     uint64_t seed;                         /* level draws (own RNG)                            */
     int32_t max_batch;                     /* 0 = default (8192)                               */
     int32_t batch_div;                     /* batch <= nodes already inserted / batch_div; 0 = 16 */
+    int32_t expected_ef;                   /* as hnsw_index_desc.expected_ef: 0 = not known      */
+    int32_t expected_semantics;
 } hnsw_build_params;
 
 int32_t hnsw_build(const float *vectors, int64_t n, int32_t d, int64_t row_stride,
@@ -431,6 +446,16 @@ int32_t hnsw_index_locality_codes(hnsw_index *idx, int32_t *out);
  * calls this once per ef at set-up. */
 int32_t hnsw_index_visited_blocks(hnsw_index *idx, const hnsw_search_params *params, int32_t *log2_slots);
 
+/* Everything a handle does ONCE for searches with these parameters, done now instead of inside the first such search call:
+ * the visited-structure decision of option "visited_blocks" at -1 (building the locality codes and the measurement: 0.1-1.3 s
+ * and a device synchronisation for an eligible shape), the kernel variant's residency query, and loading the code object of
+ * the variant's translation unit (one query searched and discarded: ~1.4 ms).  hnsw_index_create / hnsw_build call it for
+ * desc->expected_ef / params->expected_ef; hnsw_index_load for every shape the saved handle had prepared.  Any number of
+ * parameter sets may be prepared; preparing is never needed for correctness.  The measurement draws its 256 probe queries from
+ * midpoints between a stored vector and its first layer-0 neighbour (in-distribution, not themselves stored); an index whose
+ * real queries come from elsewhere can still be steered with option "visited_blocks" 0 / 1.  Results never depend on any of it. */
+int32_t hnsw_index_prepare(hnsw_index *idx, const hnsw_search_params *params);
+
 /* Per-layer degree statistics: Hgraph.Stats.compute (lib/hnsw.ml:353-375; printed by
  * benchmark/benchmark.ml:70-71): layer size (layer_sizes) and the layer's mima record -- min / max / mean of the
  * neighbour-list lengths, the nodes without a neighbour.  Computed on the device from the resident tables.  The keys of
@@ -451,7 +476,11 @@ int32_t hnsw_index_layer_isolated(const hnsw_index *idx, int32_t layer, int64_t 
 /* Flattened-index file (new: the reference has no persistence; its types derive sexp but values
  * are sexp_opaque and nothing reads one back, lib/hnsw.ml:348, lib/ohnsw.ml:312).  Little-endian
  * header + vectors + layer 0 + upper layers; hnsw_index_load re-validates everything through
- * hnsw_index_create. */
+ * hnsw_index_create.  Format 2 (this version writes it; format 1 files still load) appends what the handle had learnt:
+ * the locality codes, if built (n int32), and for every prepared / measured kernel shape whether it took the bitmap blocks --
+ * hnsw_index_load adopts the codes (a permutation check: a corrupt table is dropped and rebuilt on demand) and the decisions
+ * instead of building and measuring again, and prepares the saved shapes, so the first search after a load runs at the
+ * steady-state rate. */
 int32_t hnsw_index_save(const hnsw_index *idx, const char *path);
 int32_t hnsw_index_load(const char *path, int32_t device, hnsw_index **out);
 

@@ -28,14 +28,14 @@ FILL_OHNSW, FILL_BA = 0, 1
 SEM_OHNSW, SEM_FUNCTOR, SEM_FUNCTOR_NEAREST_K = 0, 1, 2
 
 # every symbol include/hnsw_mi355x.h declares (tests check the .so exports all of them)
-ABI_VERSION = 2          # HNSW_ABI_VERSION of include/hnsw_mi355x.h this mirror was written against
+ABI_VERSION = 3          # HNSW_ABI_VERSION of include/hnsw_mi355x.h this mirror was written against
 
 ABI_SYMBOLS = [
     "hnsw_abi_version", "hnsw_last_error", "hnsw_device_count", "hnsw_index_create",
     "hnsw_index_destroy", "hnsw_index_get_info", "hnsw_index_set_option", "hnsw_index_row_bytes", "hnsw_search_batch",
     "hnsw_search_batch_device", "hnsw_search_batch_h2d", "hnsw_knn", "hnsw_distance_batch", "hnsw_distance_batch_device",
     "hnsw_build", "hnsw_select_neighbours_batch", "hnsw_index_export_layer0", "hnsw_index_export_upper_count", "hnsw_index_export_upper",
-    "hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_locality_codes", "hnsw_index_visited_blocks", "hnsw_index_save", "hnsw_index_load",
+    "hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_locality_codes", "hnsw_index_visited_blocks", "hnsw_index_prepare", "hnsw_index_save", "hnsw_index_load",
     "hnsw_search_layer_batch", "hnsw_search_one_batch",
     "hnsw_search_submit", "hnsw_search_wait", "hnsw_index_kernel_times",
     "hnsw_multi_create", "hnsw_multi_destroy", "hnsw_multi_num_replicas", "hnsw_multi_replica", "hnsw_multi_search_batch",
@@ -62,7 +62,7 @@ class _IndexDesc(_C.Structure):
                 ("row_stride", _C.c_int64), ("metric", _C.c_int32), ("id_base", _C.c_int32),
                 ("max_degree0", _C.c_int32), ("max_degree", _C.c_int32), ("max_layer", _C.c_int32),
                 ("entry_point", _C.c_int64), ("deg0", _C.c_void_p), ("nbr0", _C.c_void_p),
-                ("upper", _C.c_void_p)]
+                ("upper", _C.c_void_p), ("expected_ef", _C.c_int32), ("expected_semantics", _C.c_int32)]
 
 
 class _SearchParams(_C.Structure):
@@ -72,7 +72,7 @@ class _SearchParams(_C.Structure):
 class _BuildParams(_C.Structure):
     _fields_ = [("num_connections", _C.c_int32), ("num_nodes_search_construction", _C.c_int32),
                 ("metric", _C.c_int32), ("id_base", _C.c_int32), ("seed", _C.c_uint64),
-                ("max_batch", _C.c_int32), ("batch_div", _C.c_int32)]
+                ("max_batch", _C.c_int32), ("batch_div", _C.c_int32), ("expected_ef", _C.c_int32), ("expected_semantics", _C.c_int32)]
 
 
 class LayerStats(_C.Structure):
@@ -126,6 +126,8 @@ def load():
     L.hnsw_index_locality_codes.restype = i32
     L.hnsw_index_visited_blocks.argtypes = [vp, vp, vp]
     L.hnsw_index_visited_blocks.restype = i32
+    L.hnsw_index_prepare.argtypes = [vp, vp]
+    L.hnsw_index_prepare.restype = i32
     L.hnsw_index_save.argtypes = [vp, _C.c_char_p]
     L.hnsw_index_load.argtypes = [_C.c_char_p, i32, vp]
     for f in ("hnsw_index_layer_stats", "hnsw_index_layer_isolated", "hnsw_index_save", "hnsw_index_load"):
@@ -210,7 +212,7 @@ class Hgraph:
     layers 1..max_layer; entry_point id_base-based or None (empty hgraph)."""
 
     def __init__(self, vectors, deg0, nbr0, upper=(), entry_point=None, id_base=0,
-                 max_degree=None, metric=METRIC_L2):
+                 max_degree=None, metric=METRIC_L2, expected_ef=0, expected_sem=SEM_OHNSW):
         self.vectors, self.row_stride = _rows(vectors)
         if self.vectors.ndim != 2:
             raise InvalidArgument("vectors must be [n][d]")
@@ -232,6 +234,8 @@ class Hgraph:
         self.id_base = int(id_base)
         self.entry_point = None if entry_point is None or entry_point < id_base else int(entry_point)
         self.metric = int(metric)
+        # hnsw_index_desc.expected_ef / expected_semantics: the upload then also prepares searches with these parameters
+        self.expected_ef, self.expected_sem = int(expected_ef), int(expected_sem)
         self._index = None
         self._device = None
 
@@ -281,6 +285,13 @@ class Hgraph:
         out = _C.c_int32(0)
         _check(load().hnsw_index_visited_blocks(self.handle, _C.byref(p), _C.byref(out)))
         return out.value
+
+    def prepare(self, ef, sem=SEM_OHNSW):
+        """hnsw_index_prepare: everything the first search with this ef and accept rule would do once (the visited-structure
+        decision, the kernel's residency, its code object), now"""
+        p = _SearchParams(ef, 1, FILL_OHNSW, sem)
+        _check(load().hnsw_index_prepare(self.handle, _C.byref(p)))
+        return self
 
     def stats(self):
         """Hgraph.Stats.compute (lib/hnsw.ml:353-375): {num_nodes, layer_sizes, layer_connectivity}; a layer's
@@ -338,6 +349,7 @@ class Hgraph:
         d.entry_point = self.id_base - 1 if self.entry_point is None else self.entry_point
         d.deg0, d.nbr0 = self.deg0.ctypes.data, self.nbr0.ctypes.data
         d.upper = _C.cast(layers, _C.c_void_p)
+        d.expected_ef, d.expected_semantics = getattr(self, "expected_ef", 0), getattr(self, "expected_sem", 0)
         return d, layers
 
     def to_device(self, device=0):
@@ -572,14 +584,15 @@ class Ohnsw:
 
     @staticmethod
     def build_batch_bigarray(batch, num_connections, num_nodes_search_construction, seed=0,
-                             metric=METRIC_L2, device=0, max_batch=0, batch_div=0):
+                             metric=METRIC_L2, device=0, max_batch=0, batch_div=0, expected_ef=0, expected_sem=SEM_OHNSW):
         """Ohnsw.build_batch_bigarray distance batch ~num_connections ~num_nodes_search_construction
         (lib/ohnsw.ml:840-857), batched on the device (the OCaml builder itself stays OCaml; this
-        is for hosts without one).  -> Hgraph resident in HBM."""
+        is for hosts without one).  -> Hgraph resident in HBM.  expected_ef (optional): the finished index
+        is also prepared for searches with that ef (hnsw_build_params.expected_ef)."""
         X = _np.ascontiguousarray(batch, dtype=_np.float32)
         if X.ndim != 2 or X.shape[0] < 1:
             raise InvalidArgument("batch must be [n][d], n >= 1")
-        p = _BuildParams(num_connections, num_nodes_search_construction, metric, 0, seed, max_batch, batch_div)
+        p = _BuildParams(num_connections, num_nodes_search_construction, metric, 0, seed, max_batch, batch_div, expected_ef, expected_sem)
         h = _C.c_void_p()
         _check(load().hnsw_build(_ptr(X), X.shape[0], X.shape[1], X.shape[1], _C.byref(p), device, _C.byref(h)))
         return Hgraph._from_handle(h, device, X, 0, metric)

@@ -305,8 +305,9 @@ done:
     if (st) (void)hipStreamDestroy(st);
     if (!rc) rc = make_byte_rows(idx);      // the finished index serves searches from the byte copy where the data allows
     if (!rc) rc = make_split_rows(idx);     // ... or from split rows where a row ends just past a 128-byte line
-    if (!rc) rc = warm_up(idx);             // ... and its first search call does not pay for the process's code loading
     if (rc) { hnsw_index_destroy(idx); return rc; }
+    (void)warm_up(idx);                     // ... and its first search call does not pay for the process's code loading (an optimisation:
+    prepare_quietly(idx, p->expected_ef, p->expected_semantics);      //  failures are left to the first search) nor for its shape's one-time decisions
     *out = idx;
     return HNSW_OK;
 }
@@ -536,7 +537,7 @@ int32_t hnsw_index_layer_isolated(const hnsw_index *idx, int32_t layer, int64_t 
 namespace {
 struct FileHeader {
     char magic[8];        // "HNSWMI35"
-    uint32_t version;     // 1
+    uint32_t version;     // 1: vectors + graph; 2: + the trailer "PREP" (decisions, locality codes)
     int32_t d, metric, id_base, max_degree0, max_degree, max_layer, reserved;
     int64_t n, entry_point;
 };
@@ -551,7 +552,7 @@ int32_t hnsw_index_save(const hnsw_index *idx, const char *path) {
     FILE *f = fopen(path, "wb");
     if (!f) return fail(HNSW_ERR_BAD_ARG, "cannot open %s for writing", path);
     FileHeader h{};
-    memcpy(h.magic, "HNSWMI35", 8); h.version = 1; h.d = d; h.metric = idx->info.metric; h.id_base = idx->iv.id_base;
+    memcpy(h.magic, "HNSWMI35", 8); h.version = 2; h.d = d; h.metric = idx->info.metric; h.id_base = idx->iv.id_base;
     h.max_degree0 = S0; h.max_degree = idx->info.max_degree; h.max_layer = idx->iv.max_layer; h.n = n;
     h.entry_point = idx->info.entry_point;
     bool ok = wr(f, &h, sizeof h);
@@ -577,6 +578,21 @@ int32_t hnsw_index_save(const hnsw_index *idx, const char *path) {
         ok = ok && hnsw_index_export_upper(idx, l, nodes.data(), deg.data(), nbr.data()) == HNSW_OK;
         ok = ok && wr(f, &c, 8) && wr(f, nodes.data(), (size_t)c * 8) && wr(f, deg.data(), (size_t)c * 4) && wr(f, nbr.data(), (size_t)c * SU * 4);
     }
+    {   // format 2: what the handle has learnt -- the locality codes (if built) and the visited-structure decisions per kernel shape
+        std::vector<int32_t> dec;
+        list_blk_choices(idx, dec);
+        for (const auto &pr : idx->prepared) {                       // prepared shapes without a decision of their own (W in one / two registers): kept
+            bool have = false;
+            for (size_t i = 0; i + 2 < dec.size(); i += 3) have = have || (dec[i] == pr.first && dec[i + 1] == (pr.second ? 1 : 0));
+            if (!have) { dec.push_back(pr.first); dec.push_back(pr.second); dec.push_back(-1); }
+        }
+        const uint32_t n_dec = (uint32_t)(dec.size() / 3), has_codes = idx->lcode_state == 1 && idx->dLcode ? 1u : 0u;
+        ok = ok && wr(f, "PREP", 4) && wr(f, &n_dec, 4) && wr(f, dec.data(), dec.size() * 4) && wr(f, &has_codes, 4);
+        if (ok && has_codes) {
+            std::vector<int32_t> codes((size_t)n);
+            ok = hipMemcpy(codes.data(), idx->dLcode, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess && wr(f, codes.data(), (size_t)n * 4);
+        }
+    }
     ok = (fclose(f) == 0) && ok;
     if (!ok) return fail(HNSW_ERR_HIP, "writing %s failed", path);
     return HNSW_OK;
@@ -588,7 +604,7 @@ int32_t hnsw_index_load(const char *path, int32_t device, hnsw_index **out) {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(HNSW_ERR_BAD_ARG, "cannot open %s", path);
     FileHeader h{};
-    if (!rd(f, &h, sizeof h) || memcmp(h.magic, "HNSWMI35", 8) != 0 || h.version != 1) { fclose(f); return fail(HNSW_ERR_BAD_ARG, "%s is not a flattened hnsw index (version 1)", path); }
+    if (!rd(f, &h, sizeof h) || memcmp(h.magic, "HNSWMI35", 8) != 0 || (h.version != 1 && h.version != 2)) { fclose(f); return fail(HNSW_ERR_BAD_ARG, "%s is not a flattened hnsw index (format 1 or 2)", path); }
     if (h.n < 0 || h.n > 0x7FFFFFF0LL || h.d < 1 || h.max_degree0 < 1 || h.max_degree0 > 64 || h.max_layer < 0 || h.max_layer > 255) { fclose(f); return fail(HNSW_ERR_BAD_ARG, "%s: corrupt header", path); }
     const int64_t n = h.n;
     const int SU = h.max_layer > 0 ? h.max_degree : 1;
@@ -607,13 +623,39 @@ int32_t hnsw_index_load(const char *path, int32_t device, hnsw_index **out) {
         ok = rd(f, nodes[(size_t)l].data(), (size_t)c * 8) && rd(f, deg[(size_t)l].data(), (size_t)c * 4) && rd(f, nbr[(size_t)l].data(), (size_t)c * SU * 4);
         layers[(size_t)l] = hnsw_layer_desc{c, nodes[(size_t)l].data(), deg[(size_t)l].data(), nbr[(size_t)l].data()};
     }
+    // format 2: decisions and codes (an unreadable trailer is ignored: everything in it can be made again)
+    std::vector<int32_t> dec, codes;
+    if (ok && h.version >= 2) {
+        char tag[4];
+        uint32_t n_dec = 0, has_codes = 0;
+        bool tok = rd(f, tag, 4) && memcmp(tag, "PREP", 4) == 0 && rd(f, &n_dec, 4) && n_dec <= 64;
+        if (tok) { dec.resize((size_t)n_dec * 3); tok = rd(f, dec.data(), dec.size() * 4) && rd(f, &has_codes, 4); }
+        if (tok && has_codes == 1 && n > 0) { codes.resize((size_t)n); tok = rd(f, codes.data(), (size_t)n * 4); }
+        if (tok && !codes.empty()) {          // a permutation of 0 .. n-1, or not used
+            std::vector<uint8_t> seen((size_t)n, 0);
+            for (int64_t i = 0; tok && i < n; ++i) {
+                const int32_t c = codes[(size_t)i];
+                tok = c >= 0 && c < n && !seen[(size_t)c];
+                if (tok) seen[(size_t)c] = 1;
+            }
+        }
+        if (!tok) { dec.clear(); codes.clear(); }
+    }
     fclose(f);
     if (!ok) return fail(HNSW_ERR_BAD_ARG, "%s: truncated or corrupt", path);
     hnsw_index_desc d{};
     d.vectors = X.data(); d.n = n; d.d = h.d; d.row_stride = h.d; d.metric = h.metric; d.id_base = h.id_base;
     d.max_degree0 = h.max_degree0; d.max_degree = h.max_degree; d.max_layer = h.max_layer; d.entry_point = h.entry_point;
     d.deg0 = deg0.data(); d.nbr0 = nbr0.data(); d.upper = layers.data();
-    return hnsw_index_create(&d, device, out);   // re-validates every id and degree
+    const int rc = hnsw_index_create(&d, device, out);   // re-validates every id and degree
+    if (rc) return rc;
+    hnsw_index *idx = *out;
+    if (!codes.empty()) (void)adopt_locality_codes(idx, codes.data());
+    for (size_t i = 0; i + 2 < dec.size(); i += 3)
+        if (dec[i + 2] >= 0) adopt_blk_choice(idx, dec[i], dec[i + 1], dec[i + 2] > 0);
+    // every saved shape is prepared again (residency, code objects); its decision is already in place, nothing is measured
+    for (size_t i = 0; i + 2 < dec.size(); i += 3) prepare_quietly(idx, dec[i], dec[i + 1]);
+    return HNSW_OK;
 }
 
 } // extern "C"

@@ -115,6 +115,17 @@ HNSW_DECL_VARIANT(1, 0, 0) HNSW_DECL_VARIANT(1, 0, 1) HNSW_DECL_VARIANT(1, 0, 2)
 HNSW_DECL_VARIANT(1, 1, 0) HNSW_DECL_VARIANT(1, 1, 1) HNSW_DECL_VARIANT(1, 1, 2) HNSW_DECL_VARIANT(1, 1, 3)
 #undef HNSW_DECL_VARIANT
 
+// probe queries of the visited-structure measurement (knn_blk_bits): query j = the midpoint between node j * step's vector and
+// its first layer-0 neighbour's (the node's own vector if it has none); rows of `stride` floats, padding zero as in the table
+__global__ void __launch_bounds__(64)
+probe_queries_kernel(const IndexView iv, int64_t step, float *out) {
+    const int64_t v = (int64_t)blockIdx.x * step;
+    const int32_t nb = iv.nbr0[v * iv.S0];
+    const int64_t u = nb >= 0 ? (int64_t)nb : v;
+    for (int64_t i = threadIdx.x; i < iv.stride; i += 64)
+        out[(int64_t)blockIdx.x * iv.stride + i] = 0.5f * (iv.X[v * iv.stride + i] + iv.X[u * iv.stride + i]);
+}
+
 namespace {
 
 typedef hipError_t (*search_launch_fn)(int, int, const IndexView &, const SearchArgs &, hipStream_t);
@@ -137,14 +148,26 @@ inline int variant_full(const hnsw_index *idx) {
 template <int METRIC>
 hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t qs, int64_t nq,
                          const int32_t *ids, int32_t m, float *out, hipStream_t st) {
-    const unsigned gy = (unsigned)std::max(1, std::min(256, (m + 15) / 16));
+    // blockIdx.y strides over a query's ids: enough blocks to fill the chip several times over (16 384 waves: four rounds of
+    // what it holds at four waves per SIMD), no more -- every block starts by loading its query, and a block that then
+    // evaluates sixteen batches amortises that better than one that evaluates four (HNSW_DIST_WAVES: tuning)
+    const int64_t want_waves = env_int("HNSW_DIST_WAVES", 16384);
+    const int64_t per_query = std::max<int64_t>(1, (want_waves + std::max<int64_t>(nq, 1) - 1) / std::max<int64_t>(nq, 1));
+    const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(256, (m + 15) / 16), per_query));
     dim3 grid((unsigned)nq, gy), block(64);
+    static const int qlds = env_int("HNSW_DIST_QLDS", 1);      // (A/B: 0 keeps the query of wide rows in registers, as rounds 1-5)
     switch (nch) {
     case 1: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<1, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
     case 2: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<2, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
     case 4: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<4, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
-    case 8: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<8, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
-    default: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
+    case 8:
+        if (qlds) hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<8, METRIC, true>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out);
+        else hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<8, METRIC, false>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out);
+        break;
+    default:
+        if (qlds) hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC, true>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out);
+        else hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC, false>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out);
+        break;
     }
     return hipGetLastError();
 }
@@ -195,23 +218,10 @@ void release_unused_lcode0(hnsw_index *idx) {
     drop_lcode0(idx);
 }
 
-int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
-    const int nslot = pick_nslot_knn(ef, pick_nch(idx->iv.nchunks));
-    const int ls = slot_class(nslot);
-    const int mode = idx->blk_mode >= 0 ? idx->blk_mode : env_int("HNSW_VISITED_BLOCKS", -1);
-    if (mode == 0 || nslot < 3 || idx->lcode_state < 0) return 0;
-    if (mode < 0 && idx->iv.n < env_int("HNSW_VISITED_BLOCKS_MIN_N", 200000)) return 0;
-    // Left to itself the handle only considers the FLOAT32 shapes whose hand-scheduled loop has the block filter (rows of 65..256
-    // dimensions -- full, ragged or split --, W in four or eight registers: C3's and C5's kernels): those kernels are bound by
-    // row requests, so fewer evaluations are less time.  The byte-row loops have the filter too (an explicit "visited_blocks" 1
-    // runs it, and the C++ loop of every other shape), but a byte-row kernel is bound by the LATENCY of a hop, and the filter's
-    // four dependent LDS round trips and ~90 vector instructions cost a hop more than the evaluations it saves: the harder
-    // SIFT-like set at ef 192, 8 % fewer evaluations, 0.98 -> 1.10 ms per 10 k batch (profiles/r05_ab_bytes_blocks.txt).
-    if (mode < 0 && !(variant_full(idx) != 2 && idx->iv.nchunks > 16 && idx->iv.nchunks <= 64 && nslot <= 8)) return 0;
-    int &choice = idx->blk_choice[ls][semf];
-    if (choice >= 0) return choice;
-    // the largest directory that keeps the variant's waves per CU
-    const int nch = pick_nch(idx->iv.nchunks), vt = knn_vt_bits(idx, ef, semf);
+// the largest block directory (log2 slots) that keeps the waves per CU of this shape's kernel, 0 = the shape cannot run the blocks
+int blk_capacity_bits(hnsw_index *idx, int ef, int semf) {
+    const int nch = pick_nch(idx->iv.nchunks), nslot = pick_nslot_knn(ef, nch), vt = knn_vt_bits(idx, ef, semf);
+    if (nslot < 3) return 0;
     const search_occupancy_fn occ = k_occupancy[idx->info.metric == HNSW_METRIC_L2 ? 0 : 1][semf][variant_full(idx)];
     // (the waves per CU of the tag-cache kernel, or of the block kernel at its smallest directory if its registers allow fewer)
     const int occ0 = std::min(occ(nch, nslot, hnsw_dev::wave_lds_words(vt) * sizeof(uint32_t), 0),
@@ -220,22 +230,50 @@ int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
     for (int b = 6; b <= 10; ++b)
         if (hnsw_dev::wave_lds_words_blocks(b) * sizeof(uint32_t) <= 65536 && occ0 > 0 &&
             occ(nch, nslot, hnsw_dev::search_lds_words(vt, b) * sizeof(uint32_t), 1) >= occ0) bits = b;
-    if (bits == 0) return choice = 0;
+    if (bits == 0) return 0;
     {   // HNSW_BLK_BITS (tests): a smaller directory than fits, down to one set of eight slots -- evictions and contested slots on small graphs
         const int forced = env_int("HNSW_BLK_BITS", 0);
         if (forced >= 3) bits = std::min(bits, forced);
     }
-    if (build_locality_codes(idx) != HNSW_OK || idx->lcode_state != 1) return choice = 0;
+    return bits;
+}
+
+// does option "visited_blocks" at -1 consider this shape at all?
+bool blk_auto_eligible(const hnsw_index *idx, int nslot) {
+    if (idx->iv.n < env_int("HNSW_VISITED_BLOCKS_MIN_N", 200000)) return false;
+    // Left to itself the handle only considers the FLOAT32 shapes whose hand-scheduled loop has the block filter (rows of 65..256
+    // dimensions -- full, ragged or split --, W in three to eight registers: C3's and C5's kernels): those kernels are bound by
+    // row requests, so fewer evaluations are less time.  The byte-row loops have the filter too (an explicit "visited_blocks" 1
+    // runs it, and the C++ loop of every other shape), but a byte-row kernel is bound by the LATENCY of a hop, and the filter's
+    // four dependent LDS round trips and ~90 vector instructions cost a hop more than the evaluations it saves: the harder
+    // SIFT-like set at ef 192, 8 % fewer evaluations, 0.98 -> 1.10 ms per 10 k batch (profiles/r05_ab_bytes_blocks.txt).
+    return variant_full(idx) != 2 && idx->iv.nchunks > 16 && idx->iv.nchunks <= 64 && nslot <= 8;
+}
+
+int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
+    const int nslot = pick_nslot_knn(ef, pick_nch(idx->iv.nchunks));
+    const int ls = slot_class(nslot);
+    const int mode = idx->blk_mode >= 0 ? idx->blk_mode : env_int("HNSW_VISITED_BLOCKS", -1);
+    if (mode == 0 || nslot < 3 || idx->lcode_state < 0) return 0;
+    if (mode < 0 && !blk_auto_eligible(idx, nslot)) return 0;
+    int &choice = idx->blk_choice[ls][semf];
+    if (choice >= 0) return choice;
+    const int bits = blk_capacity_bits(idx, ef, semf), vt = knn_vt_bits(idx, ef, semf);
+    if (bits == 0) return choice = 0;
+    if (build_locality_codes(idx) != HNSW_OK || idx->lcode_state != 1 || !idx->dLcode0) return choice = 0;
     if (mode == 1) return choice = bits;
-    // measure: every (n / 256)-th vector of the index as a query (a strided view of the vector table), k = 1
+    // measure: 256 probe queries -- the midpoint between every (n / 256)-th vector of the index and its first layer-0 neighbour:
+    // where queries of the data's own distribution fall, without being stored vectors themselves (a stored vector finds itself
+    // at distance 0 and its walk is shorter than a real query's) -- searched both ways, k = 1, evaluations counted
     const int64_t nq = std::min<int64_t>(256, idx->iv.n), step = idx->iv.n / nq;
-    DevBuf out;
-    if (out.ensure((size_t)nq * 16) != HNSW_OK) return choice = 0;
+    DevBuf out, probes;
+    if (out.ensure((size_t)nq * 16) != HNSW_OK || probes.ensure((size_t)nq * idx->iv.stride * 4) != HNSW_OK) { out.release(); probes.release(); return choice = 0; }
+    hipLaunchKernelGGL(probe_queries_kernel, dim3((unsigned)nq), dim3(64), 0, nullptr, idx->iv, step, (float *)probes.p);
     uint64_t sum[2] = {0, 0};
-    bool ok = true;
+    bool ok = hipGetLastError() == hipSuccess;
     for (int pass = 0; pass < 2 && ok; ++pass) {
         SearchArgs a{};
-        a.Q = (const float *)idx->dX; a.q_stride = step * idx->iv.stride; a.nq = nq; a.ef = ef; a.k = 1; a.fill = HNSW_FILL_OHNSW; a.sem = semf;
+        a.Q = (const float *)probes.p; a.q_stride = idx->iv.stride; a.nq = nq; a.ef = ef; a.k = 1; a.fill = HNSW_FILL_OHNSW; a.sem = semf;
         a.vt_bits = vt; a.blk_bits = pass ? bits : 0; a.prio_tail = 0x7FFFFFFF;
         a.out_ids = (int32_t *)out.p; a.out_dist = (float *)out.p + nq; a.out_ndist = (uint32_t *)out.p + 2 * nq; a.out_nhops = (uint32_t *)out.p + 3 * nq;
         std::vector<uint32_t> nd((size_t)nq);
@@ -243,12 +281,12 @@ int knn_blk_bits(hnsw_index *idx, int ef, int semf) {
              hipMemcpy(nd.data(), a.out_ndist, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess;
         for (uint32_t v : nd) sum[pass] += v;
     }
-    out.release();
+    out.release(); probes.release();
     if (!ok) { (void)hipGetLastError(); choice = 0; release_unused_lcode0(idx); return 0; }
     choice = (double)sum[1] <= 0.95 * (double)sum[0] ? bits : 0;
     release_unused_lcode0(idx);     // the tags won and no other shape uses the blocks: the per-slot table (GBs at 10 M nodes) goes again
     if (env_int("HNSW_DEBUG_VISITED", 0))
-        fprintf(stderr, "hnsw: visited set for ef %d (W in %d registers, rule %d): tag cache %.0f evaluations per sample query, 2^%d blocks %.0f -> %s\n",
+        fprintf(stderr, "hnsw: visited set for ef %d (W in %d registers, rule %d): tag cache %.0f evaluations per probe query, 2^%d blocks %.0f -> %s\n",
                 ef, nslot, semf, (double)sum[0] / (double)nq, bits, (double)sum[1] / (double)nq, choice ? "blocks" : "tags");
     return choice;
 }
@@ -535,6 +573,7 @@ int32_t hnsw_index_create(const hnsw_index_desc *d, int32_t device, hnsw_index *
     { int rc8 = make_byte_rows(idx); if (rc8) return bail(rc8); }
     { int rcs = make_split_rows(idx); if (rcs) return bail(rcs); }
     (void)warm_up(idx);      // an optimisation: whatever fails in it is left to the first search call
+    prepare_quietly(idx, d->expected_ef, d->expected_semantics);
     *out = idx;
     return HNSW_OK;
 }
@@ -584,6 +623,68 @@ int32_t hnsw_index_visited_blocks(hnsw_index *idx, const hnsw_search_params *par
     HIP_TRY(hipSetDevice(idx->device));
     *log2_slots = knn_blk_bits(idx, params->ef, params->semantics ? 1 : 0);
     return HNSW_OK;
+}
+
+int32_t hnsw_index_prepare(hnsw_index *idx, const hnsw_search_params *params) {
+    int rc = check_params(idx, params);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(idx->device));
+    const int semf = params->semantics ? 1 : 0;
+    (void)knn_blk_bits(idx, params->ef, semf);            // the visited structure of this kernel shape (codes, measurement)
+    (void)resident_queries(idx, params->ef, semf);        // the shape's residency, cached in the handle
+    // the code object of the shape's translation unit: one query (node 0's vector) through the plain and the ordered launch
+    if ((rc = ensure_host_call_state(idx))) return rc;
+    DevBuf out;
+    if ((rc = out.ensure(64))) return rc;
+    hnsw_search_params p = *params;
+    p.k = 1;
+    const int mode = idx->order_mode;
+    for (int ordered = 0; ordered < 2 && !rc; ++ordered) {
+        idx->order_mode = ordered;
+        rc = search_batch_device_flag(idx, (const float *)idx->dX, 1, idx->iv.stride, &p, (int32_t *)out.p, (float *)out.p + 1,
+                                      nullptr, nullptr, (uint32_t *)out.p + 2, nullptr, idx->hs[0]);
+    }
+    idx->order_mode = mode;
+    const hipError_t e = hipStreamSynchronize(idx->hs[0]);
+    out.release();
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(HNSW_ERR_HIP, "hnsw_index_prepare: the trial search failed: %s", hipGetErrorString(e));
+    const std::pair<int, int> key(params->ef, params->semantics);
+    if (std::find(idx->prepared.begin(), idx->prepared.end(), key) == idx->prepared.end()) idx->prepared.push_back(key);
+    return HNSW_OK;
+}
+
+extern "C++" {
+namespace hnsw_host {
+void prepare_quietly(hnsw_index *idx, int32_t ef, int32_t semantics) {
+    if (ef <= 0 || idx->iv.n < 1 || idx->iv.entry_point < 0) return;
+    hnsw_search_params p{};
+    p.ef = ef; p.k = 1; p.fill = HNSW_FILL_OHNSW; p.semantics = semantics;
+    const std::string keep = g_last_error;
+    if (hnsw_index_prepare(idx, &p) != HNSW_OK) { (void)hipGetLastError(); g_last_error = keep; }     // an optimisation: the search reports its own errors
+}
+void adopt_blk_choice(hnsw_index *idx, int32_t ef, int32_t semantics, bool blocks) {
+    if (ef < 1 || ef > 1024) return;
+    const int semf = semantics ? 1 : 0, nslot = pick_nslot_knn(ef, pick_nch(idx->iv.nchunks));
+    if (nslot < 3 || idx->blk_choice[slot_class(nslot)][semf] >= 0) return;
+    int bits = 0;
+    if (blocks && idx->lcode_state == 1 && (bits = blk_capacity_bits(idx, ef, semf)) > 0 && materialise_lcode0(idx) == HNSW_OK && idx->dLcode0) {
+        idx->blk_choice[slot_class(nslot)][semf] = bits;
+        return;
+    }
+    if (!blocks) idx->blk_choice[slot_class(nslot)][semf] = 0;       // (blocks that cannot be honoured here stay undecided: measured on demand)
+}
+void list_blk_choices(const hnsw_index *idx, std::vector<int32_t> &out3) {
+    static const int rep_ef[SLOT_CLASSES] = {64, 128, 192, 256, 384, 512, 1024};     // an ef of every slot class
+    const bool wide = pick_nch(idx->iv.nchunks) == 2 || pick_nch(idx->iv.nchunks) == 4;
+    for (int c = 0; c < SLOT_CLASSES; ++c)
+        for (int s = 0; s < 2; ++s) {
+            if (idx->blk_choice[c][s] < 0) continue;
+            if (!wide && (c == 2 || c == 4)) continue;              // three / six registers: rows of 65..256 dimensions only
+            out3.push_back(rep_ef[c]); out3.push_back(s); out3.push_back(idx->blk_choice[c][s] > 0 ? 1 : 0);
+        }
+}
+} // namespace hnsw_host
 }
 
 int32_t hnsw_index_row_bytes(const hnsw_index *idx, int64_t *row_bytes) {

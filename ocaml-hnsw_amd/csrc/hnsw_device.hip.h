@@ -1535,30 +1535,57 @@ hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_
 // ---- gathered distances (bench_dist/bench_dist.ml counterpart) --------------------------------
 // One 16-lane group per (query, id) pair, UB x 4 pairs of the same query in flight per wave; same
 // arithmetic and summation order as the search kernel.
-template <int NCH, int METRIC>
+// Rows of more than 512 dimensions (NCH 16, 8: bench_dist's d = 784 is 3136 bytes a row) keep the QUERY IN LDS instead of in 4 * NCH
+// registers per lane (hnsw_distance_kernel<16>: 169 VGPRs, two waves per SIMD in rounds 1-5): the kernel is then the row's registers
+// and a handful more, four waves per SIMD hide the dependent id -> row round trip of one another, and the next batch's ids are
+// requested before the current batch's rows are consumed.  The four groups of a wave read the same LDS words (a broadcast).
+template <int NCH, int METRIC, bool QLDS = (NCH >= 8)>
 __global__ void __launch_bounds__(64)
 hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq,
                      const int32_t *ids, int32_t m, float *out) {
     constexpr int UB = NCH <= 2 ? 4 : (NCH <= 4 ? 2 : 1);
+    __shared__ float4 qs[QLDS ? 16 * NCH : 1];
     const int lane = threadIdx.x;
     const int r = lane >> 4, l16 = lane & 15;
     const int64_t q = blockIdx.x;
     if (q >= nq) return;
-    float4 qv[NCH];
-    load_query<NCH>(qv, Q + q * q_stride, iv.d, l16);
+    float4 qv[QLDS ? 1 : NCH];
+    if constexpr (QLDS) {
+        float4 t[NCH / 4];                       // the wave's 64 lanes load the 16 * NCH chunks once (zero beyond d)
+#pragma unroll
+        for (int j = 0; j < NCH / 4; ++j) {
+            const int c = j * 64 + lane, e0 = 4 * c;
+            const float *qp = Q + q * q_stride;
+            t[j].x = (e0 + 0 < iv.d) ? qp[e0 + 0] : 0.f; t[j].y = (e0 + 1 < iv.d) ? qp[e0 + 1] : 0.f;
+            t[j].z = (e0 + 2 < iv.d) ? qp[e0 + 2] : 0.f; t[j].w = (e0 + 3 < iv.d) ? qp[e0 + 3] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NCH / 4; ++j) qs[j * 64 + lane] = t[j];
+        __syncthreads();
+    } else {
+        load_query<NCH>(qv, Q + q * q_stride, iv.d, l16);
+    }
     const uint32_t stride_b = (uint32_t)iv.stride * 4u;
-    for (int base = blockIdx.y * 4 * UB; base < m; base += 4 * UB * gridDim.y) {
+    const int step = 4 * UB * gridDim.y;
+    int base = blockIdx.y * 4 * UB;
+    int32_t idn[UB];                             // the ids of the batch about to be loaded
+#pragma unroll
+    for (int u = 0; u < UB; ++u) { const int j = base + 4 * u + r; idn[u] = base < m ? ids[q * m + (j < m ? j : base)] : iv.id_base; }
+    for (; base < m; base += step) {
         float4 v[UB][NCH];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int j = base + 4 * u + r;
-            const int je = j < m ? j : base;            // past the end: re-read a row already in flight
-            const char *row = reinterpret_cast<const char *>(iv.X) + (uint64_t)(uint32_t)(ids[q * m + je] - iv.id_base) * stride_b;   // 64-bit: no table-size limit
+        for (int u = 0; u < UB; ++u) {           // past the end: a row already in flight is read again (see idn)
+            const char *row = reinterpret_cast<const char *>(iv.X) + (uint64_t)(uint32_t)(idn[u] - iv.id_base) * stride_b;   // 64-bit: no table-size limit
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int c = i * 16 + l16;
                 v[u][i] = *reinterpret_cast<const float4 *>(row + 16u * (uint32_t)(c < iv.nchunks ? c : 0));
             }
+        }
+        const int nbase = base + step;           // the next batch's ids travel with this batch's rows
+        if (nbase < m) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { const int j = nbase + 4 * u + r; idn[u] = ids[q * m + (j < m ? j : nbase)]; }
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -1566,18 +1593,19 @@ hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 float4 z = v[u][i];
+                const float4 qi = QLDS ? qs[i * 16 + l16] : qv[QLDS ? 0 : i];
                 const bool cv = (i * 16 + l16) < iv.nchunks;
                 z.x = cv ? z.x : 0.f; z.y = cv ? z.y : 0.f; z.z = cv ? z.z : 0.f; z.w = cv ? z.w : 0.f;
                 if (METRIC == 0) {
-                    float dx = z.x - qv[i].x; acc = __builtin_fmaf(dx, dx, acc);
-                    float dy = z.y - qv[i].y; acc = __builtin_fmaf(dy, dy, acc);
-                    float dz = z.z - qv[i].z; acc = __builtin_fmaf(dz, dz, acc);
-                    float dw = z.w - qv[i].w; acc = __builtin_fmaf(dw, dw, acc);
+                    float dx = z.x - qi.x; acc = __builtin_fmaf(dx, dx, acc);
+                    float dy = z.y - qi.y; acc = __builtin_fmaf(dy, dy, acc);
+                    float dz = z.z - qi.z; acc = __builtin_fmaf(dz, dz, acc);
+                    float dw = z.w - qi.w; acc = __builtin_fmaf(dw, dw, acc);
                 } else {
-                    acc = __builtin_fmaf(z.x, qv[i].x, acc);
-                    acc = __builtin_fmaf(z.y, qv[i].y, acc);
-                    acc = __builtin_fmaf(z.z, qv[i].z, acc);
-                    acc = __builtin_fmaf(z.w, qv[i].w, acc);
+                    acc = __builtin_fmaf(z.x, qi.x, acc);
+                    acc = __builtin_fmaf(z.y, qi.y, acc);
+                    acc = __builtin_fmaf(z.z, qi.z, acc);
+                    acc = __builtin_fmaf(z.w, qi.w, acc);
                 }
             }
             acc = reduce16(acc);

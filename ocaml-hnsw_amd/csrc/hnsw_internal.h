@@ -128,6 +128,7 @@ struct hnsw_index {
     int vt_bits_override = 0;
     int vt_grow_key = -1, vt_grow_bits = 0;   // knn_vt_bits' cached choice for (kernel variant, base size)
     int lds_pad = -1;                    // option "lds_pad": extra LDS bytes per search wave (-1 = balanced_lds_pad's choice)
+    std::vector<std::pair<int, int>> prepared;   // (ef, accept rule) of every hnsw_index_prepare: what hnsw_index_save writes down
 };
 
 namespace hnsw_host {
@@ -145,6 +146,12 @@ int descent_entries(::hnsw_index *idx, const float *d_queries, int64_t nq, int64
 // hnsw_capi.hip: the one-time costs of a process's first search (code objects, the handle's stream and flag word), paid at
 // index construction: one query through the plain and the ordered launch
 int warm_up(::hnsw_index *idx);
+// hnsw_capi.hip: hnsw_index_prepare for construction paths (expected_ef): failures are swallowed, a search reports its own
+void prepare_quietly(::hnsw_index *idx, int32_t ef, int32_t semantics);
+// hnsw_capi.hip: a saved decision of the visited structure for the shape of (ef, rule): blocks (true) or the tag cache
+void adopt_blk_choice(::hnsw_index *idx, int32_t ef, int32_t semantics, bool blocks);
+// ... and the decisions a handle has made so far, as (ef representative of the shape, rule, blocks?) triples
+void list_blk_choices(const ::hnsw_index *idx, std::vector<int32_t> &out3);
 // hnsw_layer_ops.hip: Ohnsw.search_k on one layer for device-resident targets (one start node each, W bounded by ef): the
 // nearest node found per target
 int layer_nearest_device(::hnsw_index *idx, int32_t layer, const float *d_targets, int64_t t_stride, int64_t nq, const int32_t *d_qmap,

@@ -122,8 +122,8 @@ namespace Ohnsw {
 // Ohnsw.build_batch_bigarray distance batch ~num_connections ~num_nodes_search_construction
 // (lib/ohnsw.ml:840-857), batched on the device.
 inline Hgraph build_batch_bigarray(const Mat &batch, int num_connections, int num_nodes_search_construction,
-                                   uint64_t seed = 0, int metric = HNSW_METRIC_L2, int device = 0) {
-    hnsw_build_params p{num_connections, num_nodes_search_construction, metric, 0, seed, 0, 0};
+                                   uint64_t seed = 0, int metric = HNSW_METRIC_L2, int device = 0, int expected_ef = 0) {
+    hnsw_build_params p{num_connections, num_nodes_search_construction, metric, 0, seed, 0, 0, expected_ef, HNSW_SEM_OHNSW};
     hnsw_index *h = nullptr;
     check(hnsw_build(batch.data, batch.dim2, batch.dim1, batch.dim1, &p, device, &h));
     return Hgraph::adopt(h, 0, batch.dim1);

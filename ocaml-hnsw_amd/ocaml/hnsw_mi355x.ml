@@ -38,6 +38,8 @@ let d_entry_point = field index_desc "entry_point" int64_t
 let d_deg0 = field index_desc "deg0" (ptr int32_t)
 let d_nbr0 = field index_desc "nbr0" (ptr int32_t)
 let d_upper = field index_desc "upper" (ptr layer_desc)
+let d_expected_ef = field index_desc "expected_ef" int32_t
+let d_expected_semantics = field index_desc "expected_semantics" int32_t
 let () = seal index_desc
 
 type search_params
@@ -132,6 +134,8 @@ let b_id_base = field build_params "id_base" int32_t
 let b_seed = field build_params "seed" uint64_t
 let b_max_batch = field build_params "max_batch" int32_t
 let b_batch_div = field build_params "batch_div" int32_t
+let b_expected_ef = field build_params "expected_ef" int32_t
+let b_expected_semantics = field build_params "expected_semantics" int32_t
 let () = seal build_params
 let hnsw_build =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_build"
@@ -156,11 +160,14 @@ let hnsw_index_locality_codes =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_index_locality_codes" (index @-> ptr int32_t @-> returning int32_t)
 let hnsw_index_visited_blocks =
   foreign ~from:lib ~release_runtime_lock:true "hnsw_index_visited_blocks" (index @-> ptr search_params @-> ptr int32_t @-> returning int32_t)
+let hnsw_index_prepare =
+  foreign ~from:lib ~release_runtime_lock:true "hnsw_index_prepare" (index @-> ptr search_params @-> returning int32_t)
 let hnsw_abi_version = foreign ~from:lib "hnsw_abi_version" (void @-> returning int32_t)
 (* HNSW_ABI_VERSION of include/hnsw_mi355x.h this binding was written against: an older or newer library is refused at load
    time (version 2: hnsw_search_batch_h2d, hnsw_host_alloc / hnsw_host_free, hnsw_index_layer_isolated, hnsw_multi_debug_counters,
-   hnsw_index_locality_codes; hnsw_index_info.row_format; the empty-layer values of hnsw_index_layer_stats) *)
-let expected_abi_version = 2l
+   hnsw_index_locality_codes; hnsw_index_info.row_format; the empty-layer values of hnsw_index_layer_stats; version 3:
+   expected_ef / expected_semantics at the end of hnsw_index_desc and hnsw_build_params, hnsw_index_prepare, index file format 2) *)
+let expected_abi_version = 3l
 let () =
   let v = hnsw_abi_version () in
   if v <> expected_abi_version then
@@ -411,7 +418,9 @@ let unflatten_ohnsw (distance : 'a Ohnsw.distance) (value : 'a Ohnsw.value) (f :
 type result_scratch = (int * int, (int32, Bigarray.int32_elt, Bigarray.fortran_layout) A2.t * Lacaml.S.mat) Hashtbl.t
 type t = { handle : index; k_base : int; dim : int; scratch : result_scratch }
 
-let create ?(device = 0) ?(metric = 0) ~id_base (vectors : Lacaml.S.mat) (f : flat) : t =
+(* ?expected_ef (and ?expected_semantics: 0 Ohnsw's accept rule, 1 the functor's): the upload also does, once, what the first
+   search with these parameters would otherwise do inside the call (hnsw_index_prepare) *)
+let create ?(device = 0) ?(metric = 0) ?(expected_ef = 0) ?(expected_semantics = 0) ~id_base (vectors : Lacaml.S.mat) (f : flat) : t =
   (* a Lacaml.S.mat is a Fortran-layout dim x n Bigarray: in memory, n rows of dim floats *)
   let dim = A2.dim1 vectors and n = A2.dim2 vectors in
   let layers = CArray.make layer_desc (max 1 f.max_layer) in
@@ -431,6 +440,7 @@ let create ?(device = 0) ?(metric = 0) ~id_base (vectors : Lacaml.S.mat) (f : fl
   setf d d_entry_point (Int64.of_int f.entry_point);
   setf d d_deg0 (bigarray_start array1 f.deg0); setf d d_nbr0 (bigarray_start array2 f.nbr0);
   setf d d_upper (CArray.start layers);
+  setf d d_expected_ef (Int32.of_int expected_ef); setf d d_expected_semantics (Int32.of_int expected_semantics);
   let out = allocate index null in
   check (hnsw_index_create (addr d) (Int32.of_int device) out);
   let t = { handle = !@out; k_base = id_base; dim; scratch = Hashtbl.create 4 } in
@@ -723,7 +733,7 @@ let select_neighbours ?(keep_all_if_few = false) ?degrees (t : t) (target : Laca
 
 (* the device builder: the body of Ohnsw.build_batch_bigarray (lib/ohnsw.ml:840-857) in batches on the GPU
    (~max_batch:1 = Ohnsw.insert link for link); the OCaml builder stays the reference path, this is the fast one *)
-let build ?(device = 0) ?(metric = 0) ?(seed = 0) ?(max_batch = 0) ?(batch_div = 0) ~id_base ~num_connections
+let build ?(device = 0) ?(metric = 0) ?(seed = 0) ?(max_batch = 0) ?(batch_div = 0) ?(expected_ef = 0) ?(expected_semantics = 0) ~id_base ~num_connections
     ~num_nodes_search_construction (vectors : Lacaml.S.mat) : t =
   let dim = A2.dim1 vectors and n = A2.dim2 vectors in
   let b = make build_params in
@@ -731,6 +741,7 @@ let build ?(device = 0) ?(metric = 0) ?(seed = 0) ?(max_batch = 0) ?(batch_div =
   setf b b_metric (Int32.of_int metric); setf b b_id_base (Int32.of_int id_base);
   setf b b_seed (Unsigned.UInt64.of_int seed); setf b b_max_batch (Int32.of_int max_batch);
   setf b b_batch_div (Int32.of_int batch_div);
+  setf b b_expected_ef (Int32.of_int expected_ef); setf b b_expected_semantics (Int32.of_int expected_semantics);
   let out = allocate index null in
   check (hnsw_build (bigarray_start array2 vectors) (Int64.of_int n) (Int32.of_int dim) (Int64.of_int dim) (addr b)
            (Int32.of_int device) out);
@@ -766,11 +777,21 @@ let isolated (t : t) ~layer : int list =
     List.map Int64.to_int (CArray.to_list ids)
   end
 
-(* the permutation of 0 .. n-1 behind the option "visited_blocks" (hnsw_index_locality_codes): introspection only *)
-let locality_codes (t : t) ~n : (int32, Bigarray.int32_elt, Bigarray.c_layout) A1.t =
-  let out = A1.create Bigarray.int32 Bigarray.c_layout n in
+(* the permutation of 0 .. n-1 behind the option "visited_blocks" (hnsw_index_locality_codes): introspection only.  The
+   library writes the INDEX's n codes: the length comes from the handle, never from the caller *)
+let locality_codes (t : t) : (int32, Bigarray.int32_elt, Bigarray.c_layout) A1.t =
+  let inf = make index_info in
+  check (hnsw_index_get_info t.handle (addr inf));
+  let out = A1.create Bigarray.int32 Bigarray.c_layout (max 1 (Int64.to_int (getf inf ii_n))) in
   check (hnsw_index_locality_codes t.handle (bigarray_start array1 out));
   out
+
+(* everything the first search with this ef (and accept rule) would do once -- the visited-structure decision, the kernel's
+   residency, its code object -- now (hnsw_index_prepare); [create ~expected_ef] / [build ~expected_ef] call it themselves *)
+let prepare ?(semantics = 0) (t : t) ~ef : unit =
+  let p = make search_params in
+  setf p p_ef (Int32.of_int ef); setf p p_k 1l; setf p p_fill 0l; setf p p_semantics (Int32.of_int semantics);
+  check (hnsw_index_prepare t.handle (addr p))
 
 (* 0: searches at this ef use the tag cache; else log2 of the bitmap-block slots (hnsw_index_visited_blocks) *)
 let visited_blocks ?(semantics = 0) (t : t) ~ef : int =

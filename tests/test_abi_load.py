@@ -31,7 +31,7 @@ def test_exports_every_declared_symbol(H):
     assert sorted(H.ABI_SYMBOLS) == declared
     for s in declared:
         assert hasattr(L, s), s
-    assert L.hnsw_abi_version() == H.ABI_VERSION == 2
+    assert L.hnsw_abi_version() == H.ABI_VERSION == 3
 
 
 def test_ctypes_mirror_declares_every_argument_list(H):

@@ -50,7 +50,7 @@ def test_driver_line_is_short_strict_and_complete():
     assert r["latency_floor"]["kernel_over_floor"] == 1.253
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "queries/s" and c["sample"]
-    assert out["checks"]["parity_ids_equal"] is True and out["recall_at_10"] == 1.0
+    assert out["checks"]["failed"] == [] and out["checks"]["passed"] == 10 and out["checks"]["parity_queries"] == 4000 and out["recall_at_10"] == 1.0
     assert out["harder_set_at_recall_gate"]["ef"] == 176 and out["harder_set_at_recall_gate"]["parity"] is True
     assert set(out["others"]) == {"C1", "C3", "C3_clustered", "C5", "C5_clustered"}
     assert out["others"]["C5_clustered"]["parity"] is True and out["others"]["C5"]["frac"] == 0.7838
@@ -61,6 +61,13 @@ def test_driver_line_is_short_strict_and_complete():
             return max([longest(v) for v in o.values()] + [0])
         return len(o) if isinstance(o, str) else 0
     assert longest({k: v for k, v in out.items() if k != "config"}) <= 160
+
+
+def test_a_failed_check_is_named_on_the_line():
+    d = canned()
+    d["checks"]["parity_dist_bits_equal"] = False
+    out = strict(bench.driver_line(d))
+    assert out["checks"]["failed"] == ["parity_dist_bits_equal"] and out["checks"]["passed"] == 9
 
 
 def test_driver_line_has_no_nan_or_infinity():
@@ -74,7 +81,7 @@ def test_driver_line_has_no_nan_or_infinity():
 
 def test_driver_line_drops_optional_objects_before_it_outgrows_the_limit():
     d = canned()
-    d["checks"] = dict(d["checks"], **{"check_%03d" % i: True for i in range(400)})     # a future leg that adds 6 KB of flags
+    d["checks"] = dict(d["checks"], **{"count_%03d" % i: i for i in range(400)})        # a future leg that adds 6 KB of counters
     line = bench.driver_line(d)
     assert len(line) < bench.LINE_LIMIT
     out = strict(line)
