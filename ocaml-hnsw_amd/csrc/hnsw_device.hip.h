@@ -1539,11 +1539,12 @@ hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_
 // registers per lane (hnsw_distance_kernel<16>: 169 VGPRs, two waves per SIMD in rounds 1-5): the kernel is then the row's registers
 // and a handful more, four waves per SIMD hide the dependent id -> row round trip of one another, and the next batch's ids are
 // requested before the current batch's rows are consumed.  The four groups of a wave read the same LDS words (a broadcast).
-template <int NCH, int METRIC, bool QLDS = (NCH >= 8)>
+template <int NCH, int METRIC>
 __global__ void __launch_bounds__(64)
 hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq,
                      const int32_t *ids, int32_t m, float *out) {
     constexpr int UB = NCH <= 2 ? 4 : (NCH <= 4 ? 2 : 1);
+    constexpr bool QLDS = NCH >= 8;
     __shared__ float4 qs[QLDS ? 16 * NCH : 1];
     const int lane = threadIdx.x;
     const int r = lane >> 4, l16 = lane & 15;

@@ -10,7 +10,10 @@ import ocaml_hnsw_amd as H
 
 dev = torch.device("cuda", 0)
 L = H.load()
-for d, n in ((784, 1_000_000), (128, 4_000_000), (100, 4_000_000), (96, 4_000_000)):
+SHAPES = ((784, 1_000_000), (128, 4_000_000), (100, 4_000_000), (96, 4_000_000))
+if os.environ.get("DIST_ONLY"):          # one shape only (tools/dist_ab.sh, profiling)
+    SHAPES = tuple(s_ for s_ in SHAPES if s_[0] == int(os.environ["DIST_ONLY"]))
+for d, n in SHAPES:
     g = torch.Generator(device=dev); g.manual_seed(d)
     X = torch.rand((n, d), generator=g, device=dev).cpu().numpy()
     hg = H.Hgraph(X, np.zeros(n, np.int32), np.full((n, 2), -1, np.int32), entry_point=0).to_device(0)
@@ -24,7 +27,7 @@ for d, n in ((784, 1_000_000), (128, 4_000_000), (100, 4_000_000), (96, 4_000_00
         assert rc == 0, L.hnsw_last_error()
     go(); torch.cuda.synchronize()
     ts = []
-    for _ in range(5):
+    for _ in range(int(os.environ.get('DIST_REPS', 9))):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(st); go(); b.record(st); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     ms = float(np.median(ts))
