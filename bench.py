@@ -1265,7 +1265,7 @@ def main():
             med_ = ts_[len(ts_) // 2]
             # where the handle chose the bitmap blocks: the same index, batch and steps with the tag cache (round 4's structure), for the record
             tags_ = None
-            if hgo.visited_blocks(ef_):
+            if hgo.visited_blocks(ef_) and not os.environ.get("BENCH_NO_TAGS_AB"):      # (tools/profile_bench.sh sets it: one workload per kernel line)
                 hgo.set_option("visited_blocks", 0)
                 go(True)
                 torch.cuda.synchronize()

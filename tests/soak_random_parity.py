@@ -19,7 +19,8 @@ from oracle import oracle as o  # noqa: E402
 o.build(); o.lib(); H.load()
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-efs = [1, 2, 3, 7, 31, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 513, 700, 1024]
+# every boundary between slot counts (W in 1 / 2 / 3 / 4 / 6 / 8 / 16 registers: ef 64 | 128 | 192 | 256 | 384 | 512 | 1024) from both sides
+efs = [1, 2, 3, 7, 31, 63, 64, 65, 100, 127, 128, 129, 160, 191, 192, 193, 200, 255, 256, 257, 300, 320, 383, 384, 385, 511, 512, 513, 700, 1024]
 ds = [1, 2, 3, 4, 5, 7, 16, 31, 33, 63, 64, 65, 96, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 513, 784]
 if os.environ.get("SOAK_DS"):       # e.g. SOAK_DS=65-128 SOAK_EFS=1-256: one kernel family (here: the hand-scheduled loops' domain)
     lo, hi = (int(x) for x in os.environ["SOAK_DS"].split("-"))

@@ -6,6 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export BENCH_NO_TAGS_AB=1     # no tag-cache comparison launches on the clustered sets: every kernel line below is ONE workload
 # the default bench command minus the legs that would add dispatches of the same kernel on OTHER inputs (the
 # secondary data set), need the CPU oracle, or start rocprofv3 themselves: every hnsw_search_kernel dispatch below is the
 # headline workload (C2) -- the harder set at the ef of its recall gate has a profile of its own: tools/profile_gate.py under
