@@ -161,7 +161,10 @@ hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t q
     case 2: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<2, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
     case 4: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<4, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
     case 8: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<8, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
-    default: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
+    default:
+        if (env_int("HNSW_DIST_QPIN", 1)) hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC, true>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out);
+        else hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC, false>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out);     // (A/B of round 6: the query hoisted into registers)
+        break;
     }
     return hipGetLastError();
 }

@@ -1539,7 +1539,7 @@ hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_
 // registers per lane (hnsw_distance_kernel<16>: 169 VGPRs, two waves per SIMD in rounds 1-5): the kernel is then the row's registers
 // and a handful more, four waves per SIMD hide the dependent id -> row round trip of one another, and the next batch's ids are
 // requested before the current batch's rows are consumed.  The four groups of a wave read the same LDS words (a broadcast).
-template <int NCH, int METRIC>
+template <int NCH, int METRIC, bool QPIN = true>
 __global__ void __launch_bounds__(64)
 hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq,
                      const int32_t *ids, int32_t m, float *out) {
@@ -1588,13 +1588,18 @@ hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64
 #pragma unroll
             for (int u = 0; u < UB; ++u) { const int j = nbase + 4 * u + r; idn[u] = ids[q * m + (j < m ? j : nbase)]; }
         }
+        // (the query is loop-invariant: left alone the compiler reads all of it from LDS once, in front of the loop, into the 4 * NCH
+        // registers per lane the LDS copy was meant to save -- hnsw_distance_kernel<16>: 166 VGPRs, three waves per SIMD.  The pointer is
+        // laundered through an empty asm once per batch so that the reads stay where they are used.)
+        const float4 *qsp = qs;
+        if constexpr (QLDS && QPIN) asm volatile("" : "+v"(qsp));
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 float4 z = v[u][i];
-                const float4 qi = QLDS ? qs[i * 16 + l16] : qv[QLDS ? 0 : i];
+                const float4 qi = QLDS ? qsp[i * 16 + l16] : qv[QLDS ? 0 : i];
                 const bool cv = (i * 16 + l16) < iv.nchunks;
                 z.x = cv ? z.x : 0.f; z.y = cv ? z.y : 0.f; z.z = cv ? z.z : 0.f; z.w = cv ? z.w : 0.f;
                 if (METRIC == 0) {
