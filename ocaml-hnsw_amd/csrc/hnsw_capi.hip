@@ -150,8 +150,8 @@ hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t q
                          const int32_t *ids, int32_t m, float *out, hipStream_t st) {
     // blockIdx.y strides over a query's ids: enough blocks to fill the chip twice over (8 192 waves: what it holds at four waves
     // per SIMD, twice), no more -- every block starts by loading its query, and a block that then evaluates thirty-two batches
-    // amortises that better than one that evaluates four (bench_dist's shape, profiles/r06_dist_ab.txt: 6.07 TB/s at 8 192 waves,
-    // 5.86 at 16 384 and at 65 536 -- rounds 1-5's grid --; HNSW_DIST_WAVES: tuning)
+    // amortises that better than one that evaluates four (bench_dist's shape, profiles/r06_dist_ab.txt: 6.07 / 5.77 TB/s at 8 192
+    // waves on two boxes, 5.85 / 5.76 at 65 536 -- rounds 1-5's grid: within the noise of one box; HNSW_DIST_WAVES: tuning)
     const int64_t want_waves = env_int("HNSW_DIST_WAVES", 8192);
     const int64_t per_query = std::max<int64_t>(1, (want_waves + std::max<int64_t>(nq, 1) - 1) / std::max<int64_t>(nq, 1));
     const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(256, (m + 15) / 16), per_query));
@@ -161,10 +161,7 @@ hipError_t dispatch_dist(int nch, const IndexView &iv, const float *Q, int64_t q
     case 2: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<2, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
     case 4: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<4, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
     case 8: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<8, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
-    default:
-        if (env_int("HNSW_DIST_QPIN", 1)) hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC, true>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out);
-        else hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC, false>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out);     // (A/B of round 6: the query hoisted into registers)
-        break;
+    default: hipLaunchKernelGGL((hnsw_dev::hnsw_distance_kernel<16, METRIC>), grid, block, 0, st, iv, Q, qs, nq, ids, m, out); break;
     }
     return hipGetLastError();
 }

@@ -1535,11 +1535,13 @@ hnsw_descent_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_
 // ---- gathered distances (bench_dist/bench_dist.ml counterpart) --------------------------------
 // One 16-lane group per (query, id) pair, UB x 4 pairs of the same query in flight per wave; same
 // arithmetic and summation order as the search kernel.
-// Rows of more than 512 dimensions (NCH 16, 8: bench_dist's d = 784 is 3136 bytes a row) keep the QUERY IN LDS instead of in 4 * NCH
-// registers per lane (hnsw_distance_kernel<16>: 169 VGPRs, two waves per SIMD in rounds 1-5): the kernel is then the row's registers
-// and a handful more, four waves per SIMD hide the dependent id -> row round trip of one another, and the next batch's ids are
-// requested before the current batch's rows are consumed.  The four groups of a wave read the same LDS words (a broadcast).
-template <int NCH, int METRIC, bool QPIN = true>
+// Rows of more than 512 dimensions (NCH 16, 8: bench_dist's d = 784 is 3136 bytes a row): the wave's 64 lanes load the query ONCE and
+// hand it to the four 16-lane groups through LDS (rounds 1-5: every group loaded all of it from global memory), and the next batch's
+// ids are requested before the current batch's rows are consumed.  The compiler then keeps the query in registers across the loop
+// (hnsw_distance_kernel<16>: 166 VGPRs, three waves per SIMD; pinning the LDS reads inside the loop -- 128 VGPRs, four waves -- was
+// measured: no faster, profiles/r06_dist_ab.txt): a gather kernel with 12.5 KB of rows in flight per wave is at the memory
+// system's random-row ceiling at either occupancy.
+template <int NCH, int METRIC>
 __global__ void __launch_bounds__(64)
 hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64_t nq,
                      const int32_t *ids, int32_t m, float *out) {
@@ -1588,18 +1590,13 @@ hnsw_distance_kernel(const IndexView iv, const float *Q, int64_t q_stride, int64
 #pragma unroll
             for (int u = 0; u < UB; ++u) { const int j = nbase + 4 * u + r; idn[u] = ids[q * m + (j < m ? j : nbase)]; }
         }
-        // (the query is loop-invariant: left alone the compiler reads all of it from LDS once, in front of the loop, into the 4 * NCH
-        // registers per lane the LDS copy was meant to save -- hnsw_distance_kernel<16>: 166 VGPRs, three waves per SIMD.  The pointer is
-        // laundered through an empty asm once per batch so that the reads stay where they are used.)
-        const float4 *qsp = qs;
-        if constexpr (QLDS && QPIN) asm volatile("" : "+v"(qsp));
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 float4 z = v[u][i];
-                const float4 qi = QLDS ? qsp[i * 16 + l16] : qv[QLDS ? 0 : i];
+                const float4 qi = QLDS ? qs[i * 16 + l16] : qv[QLDS ? 0 : i];
                 const bool cv = (i * 16 + l16) < iv.nchunks;
                 z.x = cv ? z.x : 0.f; z.y = cv ? z.y : 0.f; z.z = cv ? z.z : 0.f; z.w = cv ? z.w : 0.f;
                 if (METRIC == 0) {

@@ -2,7 +2,7 @@
 """A/B of environment knobs the library reads per call, on C2's shape: host call and device-resident call, eight rotating batches.  (GPU box)
 
     SETTINGS="HNSW_ORDER_STOP_LAYER=2;HNSW_ORDER_STOP_LAYER=3" python tools/env_ab.py
-Each setting is a comma-separated list of NAME=VALUE; the plain library is measured first and last."""
+Each setting is an &-separated list of NAME=VALUE (values may hold commas: HNSW_PRIO=1024,8192); the plain library is measured first and last."""
 import os
 import sys
 import time
@@ -37,8 +37,8 @@ settings = [""] + [s for s in os.environ.get("SETTINGS", "").split(";") if s] + 
 ref = None
 for s in settings:
     names = []
-    for kv in [x for x in s.split(",") if x]:
-        a, b = kv.split("=")
+    for kv in [x for x in s.split("&") if x]:
+        a, b = kv.split("=", 1)
         os.environ[a] = b; names.append(a)
     got = []
     for b in range(NB):
