@@ -878,6 +878,7 @@ def main():
             except Exception as e:     # never lose the line to a secondary leg
                 one_process = {"skipped": "failed: %r" % (e,)}
                 log("one-process leg failed: %r" % (e,))
+            torch.cuda.set_device(gpu)     # (the library leaves the process on the last device it touched)
         dist.barrier(group=host_pg) if host_pg is not None else dist.barrier()
     if fp32_leg is not None:
         checks["byte_rows_equal_float32_rows"] = bool(np.array_equal(fp32_leg["ids"], got) and
