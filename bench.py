@@ -123,21 +123,6 @@ def search_nslot(ef, nch=2):
     return 16
 
 
-def kernel_nslot_of(name):
-    """the NSLOT template argument (third) of a hnsw_search_kernel<...> name from a rocprofv3 trace, or -1"""
-    try:
-        return int(name.split("hnsw_search_kernel<", 1)[1].split(">", 1)[0].split(",")[2])
-    except Exception:
-        return -1
-
-
-def kernel_rows_of(name):
-    """ROWS template argument of a (demangled) hnsw_search_kernel name, or None"""
-    import re
-    m = re.search(r"hnsw_search_kernel<([^>]*)>", name.replace(" ", ""))
-    return int(m.group(1).split(",")[5]) if m else None
-
-
 LINE_LIMIT = 4096          # bytes of the ONE stdout line (round 5's 25 KB line fell off the driver's record)
 DETAIL_FILE = "bench_detail.json"
 
