@@ -571,6 +571,39 @@ def test_beyond_the_supported_range_is_refused(H, oracle, tiny):
         H.Hgraph(np.zeros((4, 8), np.float32), np.zeros(4, np.int32), np.full((4, 65), -1, np.int32), entry_point=0).to_device(0)
 
 
+def test_prepare_and_expected_ef_change_nothing_but_the_first_call(H, oracle, tiny):
+    """hnsw_index_prepare / hnsw_index_desc.expected_ef (ABI 3): one-time work moved in front of the first search; parameter
+    errors are those of a search (an explicit prepare reports them, construction with an unusable expected_ef ignores it);
+    results are the same bits with and without."""
+    X, sp, g = tiny
+    plain = _hgraph(H, X, g, M=6)
+    want = H.Ohnsw.knn_batch_bigarray(plain, 5, X[:40], ef=20, counters=True)
+    fw = H.Ba.knn_batch(plain, X[:40], 20, 5)
+    for kw in ({"expected_ef": 20}, {"expected_ef": 20, "expected_sem": H.SEM_FUNCTOR}, {"expected_ef": 5000}, {"expected_ef": -3}):
+        up = [(nodes, deg, nbr) for nodes, deg, nbr in g.upper]
+        hg = H.Hgraph(X, g.deg0, g.nbr0, up, entry_point=g.entry_point, id_base=0, max_degree=6, **kw).to_device(0)
+        got = H.Ohnsw.knn_batch_bigarray(hg, 5, X[:40], ef=20, counters=True)
+        for a, b in zip(want, got):
+            np.testing.assert_array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+        np.testing.assert_array_equal(H.Ba.knn_batch(hg, X[:40], 20, 5).view(np.uint32), fw.view(np.uint32))
+        hg.release()
+    plain.prepare(20).prepare(300, sem=H.SEM_FUNCTOR).prepare(20)          # any number of shapes, twice the same
+    got = H.Ohnsw.knn_batch_bigarray(plain, 5, X[:40], ef=20, counters=True)
+    for a, b in zip(want, got):
+        np.testing.assert_array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+    with pytest.raises(H.Failure, match="ef=1025"):
+        plain.prepare(1025)
+    with pytest.raises(H.InvalidArgument):
+        plain.prepare(0)
+    empty = H.Hgraph(np.zeros((0, 4), np.float32), np.zeros(0, np.int32), np.zeros((0, 4), np.int32), expected_ef=16).to_device(0)
+    with pytest.raises(H.InvalidArgument, match="empty hgraph"):
+        empty.prepare(16)
+    built = H.Ohnsw.build_batch_bigarray(X, 6, 40, seed=2, expected_ef=20)  # hnsw_build_params.expected_ef
+    unbuilt = H.Ohnsw.build_batch_bigarray(X, 6, 40, seed=2)
+    for a, b in zip(H.Ohnsw.knn_batch_bigarray(built, 5, X[:40], ef=20), H.Ohnsw.knn_batch_bigarray(unbuilt, 5, X[:40], ef=20)):
+        np.testing.assert_array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
 def test_nearest_k_compat_reproduces_the_reference_output(H, oracle):
     """Hnsw.Ba.knn* with ~num_neighbours_search > ~num_neighbours returns, in the reference, the k FARTHEST
     members of W (Nearest.nearest_k, lib/hnsw.ml:522-525).  HNSW_SEM_FUNCTOR_NEAREST_K reproduces that
