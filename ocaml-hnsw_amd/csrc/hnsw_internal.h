@@ -58,7 +58,8 @@ inline int pick_nslot(int ef) {
 // (ef 129..192) and six (ef 257..384) registers -- a W window that needs three registers pays for three (pop chain, flag masks,
 // registers), not for four; the other row widths, the builder and the layer operators keep powers of two (pick_nslot)
 inline int pick_nslot_knn(int ef, int nch) {
-    if (nch == 2 || nch == 4) { for (int s : {1, 2, 3, 4, 6, 8, 16}) if (ef <= 64 * s) return s; return 0; }
+    static const int pow2 = env_int("HNSW_NSLOT_POW2", 0);      // (A/B: W in powers of two only, as rounds 1-5: profiles/r06_hop_phases.txt)
+    if (!pow2 && (nch == 2 || nch == 4)) { for (int s : {1, 2, 3, 4, 6, 8, 16}) if (ef <= 64 * s) return s; return 0; }
     return pick_nslot(ef);
 }
 // index of a slot count in per-shape tables (hnsw_index::blk_choice)
