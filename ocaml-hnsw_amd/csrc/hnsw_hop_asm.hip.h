@@ -567,20 +567,25 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 // One round of 4 / 8 / 16 rows -> ckey, cid, the accept mask in `fresh`, cnt reduced by the round's size, then the insertion
 // (50).  Label 20 picks the shape; the 8-row round (5..8 candidates left: the usual case of an M = 16 graph) follows in
 // line and falls into 50, the other two shapes (25, 40: HNSW_HOP_ROUNDS_RARE) sit behind the loop and branch back.
-#define HNSW_HOP_ROUND_COMMON \
-        "20:\n\t"                                                                                                                     \
-        "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
-        "s_cbranch_scc1 40f\n\t"                                                                                                      \
-        "s_cmp_lt_u32 %[cnt], 5\n\t"                                                                                                  \
-        "s_cbranch_scc1 25f\n\t"                                                                                                      \
-  /* ---- 8 rows: two batches */                                                                                                      \
-        "30:\n\t"                                                                                                                     \
+// Every shape in two halves: ISSUE (ids from LDS, row addresses, the loads) and CONSUME (dot products, the transposing
+// reduction, keys, accept mask, cnt).  A round runs them back to back; a hop with MORE than one round (more than 16 fresh
+// neighbours: four hops in ten on a hard set at ef 176) issues the next round's loads BEFORE the current round's insertions
+// and consumes them behind -- HNSW_ASM_RPIPE, round 6: the next round's memory round trip (400 cycles idle, 1000 loaded) runs
+// under the 1000-1500 cycles of insertions instead of behind them.  Nothing the insertions touch is live in the issued half
+// (rows d0..d7, ids id0..id3, addresses ad0 / ad1; the select into cid belongs to CONSUME: cid still holds the current
+// round's ids), cnt does not change in between (the shape picked at issue is the shape consumed), evaluation and accept
+// order are those of the unpipelined loop: same bits, same counters.
+#ifndef HNSW_ASM_RPIPE
+#define HNSW_ASM_RPIPE 1
+#endif
+#define HNSW_B8_ISSUE_8                                                                                                               \
         HNSW_ID_READ0("%[id0]", 1)                                                                                                  \
         HNSW_ID_READN("%[id1]")                                                                                                  \
         "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
         HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
-        HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")                                                                           \
+        HNSW_ROW_LOAD("%[id1]", "%[ad1]", "%[d2]", "%[d3]")
+#define HNSW_B8_CONSUME_8                                                                                                             \
         "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"                                                                        \
         "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
         HNSW_B8_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
@@ -602,13 +607,11 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         HNSW_B8_KEY("%[ta]")                                                                                        \
         HNSW_ACCEPT_LATE                                                                                                              \
         "s_sub_u32 %[cnt], %[cnt], 8\n"
-
-#define HNSW_HOP_ROUNDS_RARE \
-        "25:\n\t"                                                                                                                     \
-  /* ---- 4 rows: one batch */                                                                                                        \
+#define HNSW_B8_ISSUE_4                                                                                                               \
         HNSW_ID_READ0("%[id0]", 0)                                                                                                  \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
-        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")                                                                           \
+        HNSW_ROW_LOAD("%[id0]", "%[ad0]", "%[d0]", "%[d1]")
+#define HNSW_B8_CONSUME_4                                                                                                             \
         "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
         HNSW_B8_DOTS("%[d0]", "%[d1]", "%[ta]")                                                                                          \
         "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
@@ -624,10 +627,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[d0], %[d0], %[d0] row_ror:1" HNSW_DPP_BC "\n\t"                                                              \
         HNSW_B8_KEY("%[d0]")                                                                                        \
         HNSW_ACCEPT_LATE                                                                                                              \
-        "s_sub_u32 %[cnt], %[cnt], 4\n\t"                                                                                           \
-        "s_branch 50b\n"                                                                                                              \
-  /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
-        "40:\n\t"                                                                                                                     \
+        "s_sub_u32 %[cnt], %[cnt], 4\n\t"
+#define HNSW_B8_ISSUE_16                                                                                                              \
         HNSW_ID_READ0("%[id0]", 2)                                                                                                  \
         HNSW_ID_READN("%[id1]")                                                                                                  \
         HNSW_ID_READN("%[id2]")                                                                                                  \
@@ -639,7 +640,8 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_waitcnt lgkmcnt(1)\n\t"                                                                                                    \
         HNSW_ROW_LOAD("%[id2]", "%[ad0]", "%[d4]", "%[d5]")                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                                    \
-        HNSW_ROW_LOAD("%[id3]", "%[ad1]", "%[d6]", "%[d7]")                                                                           \
+        HNSW_ROW_LOAD("%[id3]", "%[ad1]", "%[d6]", "%[d7]")
+#define HNSW_B8_CONSUME_16                                                                                                            \
         "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"                                                                        \
         "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"                                                                        \
         "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"                                                                        \
@@ -674,8 +676,88 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "v_add_u32_dpp %[d0], %[d0], %[d0] quad_perm:[2,3,0,1]" HNSW_DPP_BC "\n\t"                                                    \
         HNSW_B8_KEY("%[d0]")                                                                                        \
         HNSW_ACCEPT_LATE                                                                                                              \
-        "s_sub_u32 %[cnt], %[cnt], 16\n\t"                                                                                            \
+        "s_sub_u32 %[cnt], %[cnt], 16\n\t"
+
+#define HNSW_HOP_ROUND_SELECT \
+        "20:\n\t"                                                                                                                     \
+        "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
+        "s_cbranch_scc1 40f\n\t"                                                                                                      \
+        "s_cmp_lt_u32 %[cnt], 5\n\t"                                                                                                  \
+        "s_cbranch_scc1 25f\n\t"
+// behind the insertions of a round: nothing left -> next hop (1b); else the next round
+#define HNSW_HOP_AFTER_INSERT_PLAIN \
+        "s_cmp_gt_i32 %[cnt], 0\n\t"  \
+        "s_cbranch_scc0 1b\n\t"       \
+        HNSW_HOP_NEXT_ROUND
+#if HNSW_ASM_RPIPE
+// (an 8-row or a 4-row round never leaves candidates behind: 5..8 / 1..4 were left when it was picked; only the 16-row round
+// does, and it sits behind the loop: the in-line path is the unpipelined text)
+#define HNSW_HOP_ROUND_COMMON \
+        HNSW_HOP_ROUND_SELECT                                                                                                         \
+  /* ---- 8 rows: two batches */                                                                                                      \
+        "30:\n\t"                                                                                                                     \
+        HNSW_B8_ISSUE_8                                                                                                               \
+        "31:\n\t"                                                                                                                     \
+        HNSW_B8_CONSUME_8
+// ... the next round's loads are in flight (45): the shape they were issued for, from the unchanged cnt
+#define HNSW_HOP_AFTER_INSERT \
+        "s_cmp_gt_i32 %[cnt], 0\n\t"  \
+        "s_cbranch_scc0 1b\n\t"       \
+        "s_cmp_gt_u32 %[cnt], 8\n\t"  \
+        "s_cbranch_scc1 41f\n\t"      \
+        "s_cmp_lt_u32 %[cnt], 5\n\t"  \
+        "s_cbranch_scc1 26f\n\t"      \
+        "s_branch 31b\n"
+#define HNSW_HOP_ROUNDS_RARE \
+        "25:\n\t"                                                                                                                     \
+  /* ---- 4 rows: one batch */                                                                                                        \
+        HNSW_B8_ISSUE_4                                                                                                               \
+        "26:\n\t"                                                                                                                     \
+        HNSW_B8_CONSUME_4                                                                                                             \
+        "s_branch 50b\n"                                                                                                              \
+  /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
+        "40:\n\t"                                                                                                                     \
+        HNSW_B8_ISSUE_16                                                                                                              \
+        "41:\n\t"                                                                                                                     \
+        HNSW_B8_CONSUME_16                                                                                                            \
+        "s_cmp_gt_i32 %[cnt], 0\n\t"                                                                                                  \
+        "s_cbranch_scc0 50b\n\t"                                                                                                      \
+  /* ---- more than 16 fresh neighbours: the next round's loads go out now, its sums are taken behind this round's insertions */     \
+        "s_lshl_b32 %[tmp], %[cnt], 2\n\t"                                                                                            \
+        "s_sub_u32 %[sx], %[lastad], %[tmp]\n\t"                                                                                      \
+        "s_add_u32 %[sx], %[sx], 4\n\t"                                                                                               \
+        "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
+        "s_cbranch_scc1 46f\n\t"                                                                                                      \
+        "s_cmp_lt_u32 %[cnt], 5\n\t"                                                                                                  \
+        "s_cbranch_scc1 47f\n\t"                                                                                                      \
+        HNSW_B8_ISSUE_8                                                                                                               \
+        "s_branch 50b\n"                                                                                                              \
+        "46:\n\t"                                                                                                                     \
+        HNSW_B8_ISSUE_16                                                                                                              \
+        "s_branch 50b\n"                                                                                                              \
+        "47:\n\t"                                                                                                                     \
+        HNSW_B8_ISSUE_4                                                                                                               \
         "s_branch 50b\n"
+#else
+#define HNSW_HOP_ROUND_COMMON \
+        HNSW_HOP_ROUND_SELECT                                                                                                         \
+  /* ---- 8 rows: two batches */                                                                                                      \
+        "30:\n\t"                                                                                                                     \
+        HNSW_B8_ISSUE_8                                                                                                               \
+        HNSW_B8_CONSUME_8
+#define HNSW_HOP_AFTER_INSERT HNSW_HOP_AFTER_INSERT_PLAIN
+#define HNSW_HOP_ROUNDS_RARE \
+        "25:\n\t"                                                                                                                     \
+  /* ---- 4 rows: one batch */                                                                                                        \
+        HNSW_B8_ISSUE_4                                                                                                               \
+        HNSW_B8_CONSUME_4                                                                                                             \
+        "s_branch 50b\n"                                                                                                              \
+  /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
+        "40:\n\t"                                                                                                                     \
+        HNSW_B8_ISSUE_16                                                                                                              \
+        HNSW_B8_CONSUME_16                                                                                                            \
+        "s_branch 50b\n"
+#endif
 
 // ---- the rounds of byte rows of 129..256 dimensions (NCH = 4: four dwords per lane and row at +0, +64, +128, +192; batch b in
 // d[4b .. 4b+3], its sum in d[4b]): the text above with twice the loads and dot products per batch (derived from it mechanically)
