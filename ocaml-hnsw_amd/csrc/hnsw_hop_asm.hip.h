@@ -1419,6 +1419,101 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
 #define HNSW_F32_ROUND_PICK16                                                                                                         \
         "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
         "s_cbranch_scc1 40f\n\t"
+// The float32 rounds in two halves, ISSUE (ids -- and, split rows, slots -- from LDS, row addresses, the loads) and CONSUME (distances, the
+// folding reduction, keys, accept mask, cnt), as the byte-row rounds (HNSW_B8_ISSUE_* / HNSW_B8_CONSUME_*, HNSW_ASM_RPIPE): a hop of rows of
+// 65..128 dimensions with more than 16 fresh neighbours -- C5's and C3's graphs have rows of 64 -- issues its next round's loads before the
+// current round's insertions.  (The row registers are named and clobbered, the address pairs of the split rows too: nothing the insertions
+// use.)  Rows of 129..256 dimensions keep the unpipelined flow (their rounds are 4 and 8 rows: HNSW_F32_ROUND_PICK is empty there).
+#define HNSW_F32_ISSUE_8 \
+        HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 1) \
+        HNSW_F32_ID_READN("%[id1]", "%[pj1]") \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG1 ")\n\t" \
+        HNSW_F32_ROW_LOAD("%[id0]", "%[pj0]", "%[ad0]", 0) \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t" \
+        HNSW_F32_ROW_LOAD("%[id1]", "%[pj1]", "%[ad1]", 1)
+#define HNSW_F32_CONSUME_8 \
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t" \
+        "s_waitcnt vmcnt(" HNSW_F32_VM1B ")\n\t" \
+        HNSW_F32_DIST(0) \
+        "s_waitcnt vmcnt(0)\n\t" \
+        HNSW_F32_DIST(1) \
+        "v_cndmask_b32_e64 %[ta], " HNSW_FX(0, 0, 0) ", " HNSW_FX(1, 0, 0) ", %[b3m]\n\t"  /* keep: the sum this half of the group is for */ \
+        "v_cndmask_b32_e64 %[tb], " HNSW_FX(1, 0, 0) ", " HNSW_FX(0, 0, 0) ", %[b3m]\n\t"  /* give: the other half's */ \
+        HNSW_ACCEPT_EARLY(1) \
+        "v_add_f32_dpp %[ta], %[tb], %[ta] row_ror:8" HNSW_DPP_ALL "\n\t" \
+        "s_nop 1\n\t" \
+        HNSW_F32_XOR4("%[tb]", "%[ta]", "%[ta]", HNSW_FX(0, 0, 1)) \
+        "s_nop 1\n\t" \
+        "v_add_f32_dpp %[tb], %[tb], %[tb] quad_perm:[2,3,0,1]" HNSW_DPP_ALL "\n\t" \
+        "s_nop 1\n\t" \
+        "v_add_f32_dpp " HNSW_F32_SUM ", %[tb], %[tb] quad_perm:[1,0,3,2]" HNSW_DPP_ALL "\n\t" \
+        HNSW_F32_KEY \
+        HNSW_ACCEPT_LATE \
+        "s_sub_u32 %[cnt], %[cnt], 8\n"
+#define HNSW_F32_ISSUE_4 \
+        HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 0) \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t" \
+        HNSW_F32_ROW_LOAD("%[id0]", "%[pj0]", "%[ad0]", 0)
+#define HNSW_F32_CONSUME_4 \
+        "s_waitcnt vmcnt(0)\n\t" \
+        HNSW_F32_DIST(0) \
+        "v_mov_b32_e32 %[cid], %[id0]\n\t" \
+        HNSW_ACCEPT_EARLY(0) \
+        "v_add_f32_dpp %[ta], " HNSW_FX(0, 0, 0) ", " HNSW_FX(0, 0, 0) " row_ror:8" HNSW_DPP_ALL "\n\t" \
+        "s_nop 1\n\t" \
+        "v_add_f32_dpp %[ta], %[ta], %[ta] row_ror:4" HNSW_DPP_ALL "\n\t" \
+        "s_nop 1\n\t" \
+        "v_add_f32_dpp %[ta], %[ta], %[ta] row_ror:2" HNSW_DPP_ALL "\n\t" \
+        "s_nop 1\n\t" \
+        "v_add_f32_dpp " HNSW_F32_SUM ", %[ta], %[ta] row_ror:1" HNSW_DPP_ALL "\n\t" \
+        HNSW_F32_KEY \
+        HNSW_ACCEPT_LATE \
+        "s_sub_u32 %[cnt], %[cnt], 4\n\t"
+#define HNSW_F32_ISSUE_16 \
+        HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 2) \
+        HNSW_F32_ID_READN("%[id1]", "%[pj1]") \
+        HNSW_F32_ID_READN("%[id2]", "%[pj2]") \
+        HNSW_F32_ID_READN("%[id3]", "%[pj3]") \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG3 ")\n\t" \
+        HNSW_F32_ROW_LOAD("%[id0]", "%[pj0]", "%[ad0]", 0) \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG2 ")\n\t" \
+        HNSW_F32_ROW_LOAD("%[id1]", "%[pj1]", "%[ad1]", 1) \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG1 ")\n\t" \
+        HNSW_F32_ROW_LOAD("%[id2]", "%[pj2]", "%[ad0]", 2) \
+        "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t" \
+        HNSW_F32_ROW_LOAD("%[id3]", "%[pj3]", "%[ad1]", 3)
+#define HNSW_F32_CONSUME_16 \
+        "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t" \
+        "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t" \
+        "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t" \
+        "s_waitcnt vmcnt(6)\n\t" \
+        HNSW_F32_DIST(0) \
+        "s_waitcnt vmcnt(4)\n\t" \
+        HNSW_F32_DIST(1) \
+        "s_waitcnt vmcnt(2)\n\t" \
+        HNSW_F32_DIST(2) \
+        "s_waitcnt vmcnt(0)\n\t" \
+        HNSW_F32_DIST(3) \
+  /* sums of candidates 0..3 of the group in batch registers 0..3 -> quads of the group's 16 lanes (scratch: two row registers) */ \
+        "v_cndmask_b32_e64 %[ta], " HNSW_FX(0, 0, 0) ", " HNSW_FX(2, 0, 0) ", %[b3m]\n\t"  /* keep 0 | 2 */ \
+        "v_cndmask_b32_e64 " HNSW_FX(0, 0, 1) ", " HNSW_FX(2, 0, 0) ", " HNSW_FX(0, 0, 0) ", %[b3m]\n\t"  /* give */ \
+        "v_cndmask_b32_e64 %[tb], " HNSW_FX(1, 0, 0) ", " HNSW_FX(3, 0, 0) ", %[b3m]\n\t"  /* keep 1 | 3 */ \
+        "v_cndmask_b32_e64 " HNSW_FX(1, 0, 1) ", " HNSW_FX(3, 0, 0) ", " HNSW_FX(1, 0, 0) ", %[b3m]\n\t"  /* give */ \
+        HNSW_ACCEPT_EARLY_A \
+        "v_add_f32_dpp %[ta], " HNSW_FX(0, 0, 1) ", %[ta] row_ror:8" HNSW_DPP_ALL "\n\t" \
+        "v_add_f32_dpp %[tb], " HNSW_FX(1, 0, 1) ", %[tb] row_ror:8" HNSW_DPP_ALL "\n\t" \
+        "v_cndmask_b32_e64 " HNSW_FX(0, 0, 1) ", %[ta], %[tb], %[b2m]\n\t"  /* keep */ \
+        "v_cndmask_b32_e64 " HNSW_FX(1, 0, 1) ", %[tb], %[ta], %[b2m]\n\t"  /* give */ \
+        HNSW_ACCEPT_EARLY_B(2) \
+        "s_nop 0\n\t" \
+        HNSW_F32_XOR4(HNSW_FX(0, 0, 1), HNSW_FX(1, 0, 1), HNSW_FX(0, 0, 1), "%[ta]") \
+        "s_nop 1\n\t" \
+        "v_add_f32_dpp %[ta], " HNSW_FX(0, 0, 1) ", " HNSW_FX(0, 0, 1) " quad_perm:[2,3,0,1]" HNSW_DPP_ALL "\n\t" \
+        "s_nop 1\n\t" \
+        "v_add_f32_dpp " HNSW_F32_SUM ", %[ta], %[ta] quad_perm:[1,0,3,2]" HNSW_DPP_ALL "\n\t" \
+        HNSW_F32_KEY \
+        HNSW_ACCEPT_LATE \
+        "s_sub_u32 %[cnt], %[cnt], 16\n\t"
 #define HNSW_F32_ROUND_COMMON \
         "20:\n\t"                                                                                                                     \
         HNSW_F32_ROUND_PICK                                                                                                           \
@@ -1426,99 +1521,54 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) {
         "s_cbranch_scc1 25f\n\t"                                                                                                      \
   /* ---- 8 rows: two batches */                                                                                                      \
         "30:\n\t"                                                                                                                     \
-        HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 1)                                                                                                    \
-        HNSW_F32_ID_READN("%[id1]", "%[pj1]")                                                                                                       \
-        "s_waitcnt lgkmcnt(" HNSW_F32_LG1 ")\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id0]", "%[pj0]", "%[ad0]", 0)                                                                                      \
-        "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id1]", "%[pj1]", "%[ad1]", 1)                                                                                      \
-        "v_cndmask_b32_e64 %[cid], %[id0], %[id1], %[b3m]\n\t"                                                                        \
-        "s_waitcnt vmcnt(" HNSW_F32_VM1B ")\n\t"                                                                                                      \
-        HNSW_F32_DIST(0)                                                                                                              \
-        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
-        HNSW_F32_DIST(1)                                                                                                              \
-        "v_cndmask_b32_e64 %[ta], " HNSW_FX(0, 0, 0) ", " HNSW_FX(1, 0, 0) ", %[b3m]\n\t"  /* keep: the sum this half of the group is for */ \
-        "v_cndmask_b32_e64 %[tb], " HNSW_FX(1, 0, 0) ", " HNSW_FX(0, 0, 0) ", %[b3m]\n\t"  /* give: the other half's */                      \
-        HNSW_ACCEPT_EARLY(1)                                                                                                          \
-        "v_add_f32_dpp %[ta], %[tb], %[ta] row_ror:8" HNSW_DPP_ALL "\n\t"                                                             \
-        "s_nop 1\n\t"                                                                                                                 \
-        HNSW_F32_XOR4("%[tb]", "%[ta]", "%[ta]", HNSW_FX(0, 0, 1))                                                                    \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_f32_dpp %[tb], %[tb], %[tb] quad_perm:[2,3,0,1]" HNSW_DPP_ALL "\n\t"                                                   \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_f32_dpp " HNSW_F32_SUM ", %[tb], %[tb] quad_perm:[1,0,3,2]" HNSW_DPP_ALL "\n\t"                                        \
-        HNSW_F32_KEY                                                                                                                  \
-        HNSW_ACCEPT_LATE                                                                                                              \
-        "s_sub_u32 %[cnt], %[cnt], 8\n"
+        HNSW_F32_ISSUE_8                                                                                                              \
+        HNSW_F32_LABEL_31                                                                                                             \
+        HNSW_F32_CONSUME_8
 
 #define HNSW_F32_ROUND_4ROWS \
         "25:\n\t"                                                                                                                     \
   /* ---- 4 rows: one batch */                                                                                                        \
-        HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 0)                                                                                                    \
-        "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id0]", "%[pj0]", "%[ad0]", 0)                                                                                      \
-        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
-        HNSW_F32_DIST(0)                                                                                                              \
-        "v_mov_b32_e32 %[cid], %[id0]\n\t"                                                                                            \
-        HNSW_ACCEPT_EARLY(0)                                                                                                          \
-        "v_add_f32_dpp %[ta], " HNSW_FX(0, 0, 0) ", " HNSW_FX(0, 0, 0) " row_ror:8" HNSW_DPP_ALL "\n\t"                               \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_f32_dpp %[ta], %[ta], %[ta] row_ror:4" HNSW_DPP_ALL "\n\t"                                                             \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_f32_dpp %[ta], %[ta], %[ta] row_ror:2" HNSW_DPP_ALL "\n\t"                                                             \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_f32_dpp " HNSW_F32_SUM ", %[ta], %[ta] row_ror:1" HNSW_DPP_ALL "\n\t"                                                  \
-        HNSW_F32_KEY                                                                                                                  \
-        HNSW_ACCEPT_LATE                                                                                                              \
-        "s_sub_u32 %[cnt], %[cnt], 4\n\t"                                                                                             \
+        HNSW_F32_ISSUE_4                                                                                                              \
+        HNSW_F32_LABEL_26                                                                                                             \
+        HNSW_F32_CONSUME_4                                                                                                            \
         "s_branch 50b\n"
+#if HNSW_ASM_RPIPE
+#define HNSW_F32_LABEL_31 "31:\n\t"
+#define HNSW_F32_LABEL_26 "26:\n\t"
 #define HNSW_F32_ROUND_16ROWS \
   /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
         "40:\n\t"                                                                                                                     \
-        HNSW_F32_ID_READ0("%[id0]", "%[pj0]", 2)                                                                                                    \
-        HNSW_F32_ID_READN("%[id1]", "%[pj1]")                                                                                                       \
-        HNSW_F32_ID_READN("%[id2]", "%[pj2]")                                                                                                       \
-        HNSW_F32_ID_READN("%[id3]", "%[pj3]")                                                                                                       \
-        "s_waitcnt lgkmcnt(" HNSW_F32_LG3 ")\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id0]", "%[pj0]", "%[ad0]", 0)                                                                                      \
-        "s_waitcnt lgkmcnt(" HNSW_F32_LG2 ")\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id1]", "%[pj1]", "%[ad1]", 1)                                                                                      \
-        "s_waitcnt lgkmcnt(" HNSW_F32_LG1 ")\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id2]", "%[pj2]", "%[ad0]", 2)                                                                                      \
-        "s_waitcnt lgkmcnt(" HNSW_F32_LG0 ")\n\t"                                                                                                    \
-        HNSW_F32_ROW_LOAD("%[id3]", "%[pj3]", "%[ad1]", 3)                                                                                      \
-        "v_cndmask_b32_e64 %[id0], %[id0], %[id1], %[b2m]\n\t"                                                                        \
-        "v_cndmask_b32_e64 %[id2], %[id2], %[id3], %[b2m]\n\t"                                                                        \
-        "v_cndmask_b32_e64 %[cid], %[id0], %[id2], %[b3m]\n\t"                                                                        \
-        "s_waitcnt vmcnt(6)\n\t"                                                                                                      \
-        HNSW_F32_DIST(0)                                                                                                              \
-        "s_waitcnt vmcnt(4)\n\t"                                                                                                      \
-        HNSW_F32_DIST(1)                                                                                                              \
-        "s_waitcnt vmcnt(2)\n\t"                                                                                                      \
-        HNSW_F32_DIST(2)                                                                                                              \
-        "s_waitcnt vmcnt(0)\n\t"                                                                                                      \
-        HNSW_F32_DIST(3)                                                                                                              \
-  /* sums of candidates 0..3 of the group in batch registers 0..3 -> quads of the group's 16 lanes (scratch: two row registers) */  \
-        "v_cndmask_b32_e64 %[ta], " HNSW_FX(0, 0, 0) ", " HNSW_FX(2, 0, 0) ", %[b3m]\n\t"  /* keep 0 | 2 */                            \
-        "v_cndmask_b32_e64 " HNSW_FX(0, 0, 1) ", " HNSW_FX(2, 0, 0) ", " HNSW_FX(0, 0, 0) ", %[b3m]\n\t"  /* give */                   \
-        "v_cndmask_b32_e64 %[tb], " HNSW_FX(1, 0, 0) ", " HNSW_FX(3, 0, 0) ", %[b3m]\n\t"  /* keep 1 | 3 */                            \
-        "v_cndmask_b32_e64 " HNSW_FX(1, 0, 1) ", " HNSW_FX(3, 0, 0) ", " HNSW_FX(1, 0, 0) ", %[b3m]\n\t"  /* give */                   \
-        HNSW_ACCEPT_EARLY_A                                                                                                           \
-        "v_add_f32_dpp %[ta], " HNSW_FX(0, 0, 1) ", %[ta] row_ror:8" HNSW_DPP_ALL "\n\t"                                              \
-        "v_add_f32_dpp %[tb], " HNSW_FX(1, 0, 1) ", %[tb] row_ror:8" HNSW_DPP_ALL "\n\t"                                              \
-        "v_cndmask_b32_e64 " HNSW_FX(0, 0, 1) ", %[ta], %[tb], %[b2m]\n\t"  /* keep */                                                \
-        "v_cndmask_b32_e64 " HNSW_FX(1, 0, 1) ", %[tb], %[ta], %[b2m]\n\t"  /* give */                                                \
-        HNSW_ACCEPT_EARLY_B(2)                                                                                                        \
-        "s_nop 0\n\t"                                                                                                                 \
-        HNSW_F32_XOR4(HNSW_FX(0, 0, 1), HNSW_FX(1, 0, 1), HNSW_FX(0, 0, 1), "%[ta]")                                                  \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_f32_dpp %[ta], " HNSW_FX(0, 0, 1) ", " HNSW_FX(0, 0, 1) " quad_perm:[2,3,0,1]" HNSW_DPP_ALL "\n\t"                     \
-        "s_nop 1\n\t"                                                                                                                 \
-        "v_add_f32_dpp " HNSW_F32_SUM ", %[ta], %[ta] quad_perm:[1,0,3,2]" HNSW_DPP_ALL "\n\t"                                        \
-        HNSW_F32_KEY                                                                                                                  \
-        HNSW_ACCEPT_LATE                                                                                                              \
-        "s_sub_u32 %[cnt], %[cnt], 16\n\t"                                                                                            \
+        HNSW_F32_ISSUE_16                                                                                                             \
+        "41:\n\t"                                                                                                                     \
+        HNSW_F32_CONSUME_16                                                                                                           \
+        "s_cmp_gt_i32 %[cnt], 0\n\t"                                                                                                  \
+        "s_cbranch_scc0 50b\n\t"                                                                                                      \
+  /* ---- more than 16 fresh neighbours: the next round's loads go out now, its sums are taken behind this round's insertions */     \
+        "s_lshl_b32 %[tmp], %[cnt], 2\n\t"                                                                                            \
+        "s_sub_u32 %[sx], %[lastad], %[tmp]\n\t"                                                                                      \
+        "s_add_u32 %[sx], %[sx], 4\n\t"                                                                                               \
+        "s_cmp_gt_u32 %[cnt], 8\n\t"                                                                                                  \
+        "s_cbranch_scc1 46f\n\t"                                                                                                      \
+        "s_cmp_lt_u32 %[cnt], 5\n\t"                                                                                                  \
+        "s_cbranch_scc1 47f\n\t"                                                                                                      \
+        HNSW_F32_ISSUE_8                                                                                                              \
+        "s_branch 50b\n"                                                                                                              \
+        "46:\n\t"                                                                                                                     \
+        HNSW_F32_ISSUE_16                                                                                                             \
+        "s_branch 50b\n"                                                                                                              \
+        "47:\n\t"                                                                                                                     \
+        HNSW_F32_ISSUE_4                                                                                                              \
         "s_branch 50b\n"
+#else
+#define HNSW_F32_LABEL_31
+#define HNSW_F32_LABEL_26
+#define HNSW_F32_ROUND_16ROWS \
+  /* ---- 16 rows: four batches (a list of 9..12 re-reads its last row in the groups past the end) */                                 \
+        "40:\n\t"                                                                                                                     \
+        HNSW_F32_ISSUE_16                                                                                                             \
+        HNSW_F32_CONSUME_16                                                                                                           \
+        "s_branch 50b\n"
+#endif
 #define HNSW_F32_ROUNDS_RARE HNSW_F32_ROUND_4ROWS HNSW_F32_ROUND_16ROWS
 
 
